@@ -1,0 +1,217 @@
+"""Deterministic synthetic T5 checkpoints (no network, no real weights anywhere offline).
+
+A counter-based generator (splitmix64 -> Box-Muller) so that the build container, the
+GPU box, the oracle and the HIP engine can all regenerate bit-identical weights from
+(dims, seed) without shipping multi-GB files.  Tensor names and shapes follow the
+HuggingFace T5 state-dict (hf: models/t5/modeling_t5.py:590-616 gives the init scales
+we imitate so activations stay well conditioned).
+
+All values are rounded to fp16-representable numbers: the reference's accelerator path
+loads the checkpoint as fp16 (ref: llmrankers/pointwise.py:20-24), so "the model" both
+the oracle (fp32 math) and the engine (fp16 MFMA inputs) see is the same set of numbers.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict
+from typing import Dict, Iterator, Tuple
+
+import numpy as np
+
+
+@dataclass(frozen=True)
+class T5Dims:
+    vocab: int
+    d_model: int
+    n_heads: int
+    d_kv: int
+    d_ff: int
+    n_enc: int
+    n_dec: int
+    gated: bool = True          # T5 v1.1 / flan: gated-gelu; v1.0 / monoT5: relu
+    tied_head: bool = False     # v1.0 ties lm_head to shared and scales by d_model**-0.5
+    n_buckets: int = 32
+    max_distance: int = 128
+    eps: float = 1e-6
+
+    @property
+    def inner(self) -> int:
+        return self.n_heads * self.d_kv
+
+    def to_hf_config(self) -> dict:
+        """config.json content HF's T5Config understands (used by tools/ and oracle/hf_path)."""
+        return {
+            "architectures": ["T5ForConditionalGeneration"],
+            "model_type": "t5",
+            "vocab_size": self.vocab,
+            "d_model": self.d_model,
+            "d_kv": self.d_kv,
+            "d_ff": self.d_ff,
+            "num_heads": self.n_heads,
+            "num_layers": self.n_enc,
+            "num_decoder_layers": self.n_dec,
+            "relative_attention_num_buckets": self.n_buckets,
+            "relative_attention_max_distance": self.max_distance,
+            "layer_norm_epsilon": self.eps,
+            "feed_forward_proj": "gated-gelu" if self.gated else "relu",
+            "tie_word_embeddings": bool(self.tied_head),
+            "dropout_rate": 0.0,
+            "initializer_factor": 1.0,
+            "is_encoder_decoder": True,
+            "use_cache": True,
+            "pad_token_id": 0,
+            "eos_token_id": 1,
+            "decoder_start_token_id": 0,
+        }
+
+    @staticmethod
+    def from_hf_config(cfg: dict) -> "T5Dims":
+        ffp = cfg.get("feed_forward_proj", "relu")
+        if ffp not in ("relu", "gated-gelu"):
+            raise NotImplementedError(f"feed_forward_proj={ffp!r} is not supported by the MI355X engine")
+        return T5Dims(
+            vocab=cfg["vocab_size"], d_model=cfg["d_model"], n_heads=cfg["num_heads"], d_kv=cfg["d_kv"],
+            d_ff=cfg["d_ff"], n_enc=cfg["num_layers"],
+            n_dec=cfg.get("num_decoder_layers") or cfg["num_layers"],
+            gated=ffp.startswith("gated"),
+            tied_head=bool(cfg.get("tie_word_embeddings", True)),
+            n_buckets=cfg.get("relative_attention_num_buckets", 32),
+            max_distance=cfg.get("relative_attention_max_distance", 128),
+            eps=cfg.get("layer_norm_epsilon", 1e-6),
+        )
+
+    def asdict(self) -> dict:
+        return asdict(self)
+
+
+# Public model-card dimensions.
+FLAN_T5_SMALL = T5Dims(vocab=32128, d_model=512, n_heads=6, d_kv=64, d_ff=1024, n_enc=8, n_dec=8)
+FLAN_T5_BASE = T5Dims(vocab=32128, d_model=768, n_heads=12, d_kv=64, d_ff=2048, n_enc=12, n_dec=12)
+FLAN_T5_LARGE = T5Dims(vocab=32128, d_model=1024, n_heads=16, d_kv=64, d_ff=2816, n_enc=24, n_dec=24)
+FLAN_T5_XL = T5Dims(vocab=32128, d_model=2048, n_heads=32, d_kv=64, d_ff=5120, n_enc=24, n_dec=24)
+# Toy models for fixtures: kernel-friendly (multiples of 64) but with inner != d_model.
+TOY_GATED_UNTIED = T5Dims(vocab=256, d_model=128, n_heads=3, d_kv=64, d_ff=256, n_enc=2, n_dec=2)
+TOY_RELU_TIED = T5Dims(vocab=256, d_model=128, n_heads=3, d_kv=64, d_ff=256, n_enc=2, n_dec=2,
+                       gated=False, tied_head=True)
+
+NAMED_DIMS = {
+    "flan-t5-small": FLAN_T5_SMALL, "flan-t5-base": FLAN_T5_BASE, "flan-t5-large": FLAN_T5_LARGE,
+    "flan-t5-xl": FLAN_T5_XL, "toy-gated-untied": TOY_GATED_UNTIED, "toy-relu-tied": TOY_RELU_TIED,
+}
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def counter_normal(n: int, stream: int, seed: int) -> np.ndarray:
+    """n standard normals, a pure function of (stream, seed, index). float64 Box-Muller."""
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.array([seed * 0x1000003 + stream], dtype=np.uint64))[0]
+        idx = np.arange(n, dtype=np.uint64)
+        a = _splitmix64(idx * np.uint64(2) + base)
+        b = _splitmix64(idx * np.uint64(2) + np.uint64(1) + base)
+    u1 = ((a >> np.uint64(11)).astype(np.float64) + 1.0) * (1.0 / 9007199254740993.0)  # (0,1)
+    u2 = (b >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)          # [0,1)
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def _fp16_round(x: np.ndarray) -> np.ndarray:
+    return x.astype(np.float16).astype(np.float32)
+
+
+def tensor_specs(d: T5Dims) -> Iterator[Tuple[str, Tuple[int, ...], float, bool]]:
+    """(hf_name, shape, std, is_norm_weight) for every tensor of the checkpoint, in a fixed order."""
+    yield "shared.weight", (d.vocab, d.d_model), 1.0, False
+    for stack, n_layers in (("encoder", d.n_enc), ("decoder", d.n_dec)):
+        for i in range(n_layers):
+            p = f"{stack}.block.{i}.layer"
+            attn_layers = [(0, "SelfAttention")] + ([(1, "EncDecAttention")] if stack == "decoder" else [])
+            for li, an in attn_layers:
+                yield f"{p}.{li}.{an}.q.weight", (d.inner, d.d_model), (d.d_model * d.d_kv) ** -0.5, False
+                yield f"{p}.{li}.{an}.k.weight", (d.inner, d.d_model), d.d_model ** -0.5, False
+                yield f"{p}.{li}.{an}.v.weight", (d.inner, d.d_model), d.d_model ** -0.5, False
+                yield f"{p}.{li}.{an}.o.weight", (d.d_model, d.inner), d.inner ** -0.5, False
+                if i == 0 and li == 0:
+                    yield (f"{p}.0.SelfAttention.relative_attention_bias.weight", (d.n_buckets, d.n_heads),
+                           0.5, False)   # HF uses d_model**-0.5; 0.5 makes the bias matter in tests
+                yield f"{p}.{li}.layer_norm.weight", (d.d_model,), 0.1, True
+            fl = 2 if stack == "decoder" else 1
+            if d.gated:
+                yield f"{p}.{fl}.DenseReluDense.wi_0.weight", (d.d_ff, d.d_model), d.d_model ** -0.5, False
+                yield f"{p}.{fl}.DenseReluDense.wi_1.weight", (d.d_ff, d.d_model), d.d_model ** -0.5, False
+            else:
+                yield f"{p}.{fl}.DenseReluDense.wi.weight", (d.d_ff, d.d_model), d.d_model ** -0.5, False
+            yield f"{p}.{fl}.DenseReluDense.wo.weight", (d.d_model, d.d_ff), d.d_ff ** -0.5, False
+            yield f"{p}.{fl}.layer_norm.weight", (d.d_model,), 0.1, True
+        yield f"{stack}.final_layer_norm.weight", (d.d_model,), 0.1, True
+    if not d.tied_head:
+        yield "lm_head.weight", (d.vocab, d.d_model), d.d_model ** -0.5, False
+
+
+def synth_tensors(d: T5Dims, seed: int = 929, gain: float = 1.0) -> Iterator[Tuple[str, np.ndarray]]:
+    """Yield (hf_name, fp32 array with fp16-representable values) one tensor at a time."""
+    for stream, (name, shape, std, is_norm) in enumerate(tensor_specs(d)):
+        n = int(np.prod(shape))
+        z = counter_normal(n, stream, seed)
+        w = (1.0 + std * z) if is_norm else (gain if std < 1.0 else 1.0) * std * z
+        yield name, _fp16_round(w.astype(np.float32).reshape(shape))
+
+
+def synth_state_dict(d: T5Dims, seed: int = 929, gain: float = 1.0) -> Dict[str, np.ndarray]:
+    return dict(synth_tensors(d, seed, gain))
+
+
+def synth_token_batch(n_seq: int, min_len: int, max_len: int, vocab: int, seed: int):
+    """Ragged synthetic prompts: ids ~ U{3..vocab-29}, last id = 1 (EOS). Returns list of int32 arrays."""
+    rs = np.random.RandomState(seed)   # MT19937: stable across numpy versions
+    hi = max(4, vocab - 28)
+    out = []
+    for _ in range(n_seq):
+        n = int(rs.randint(min_len, max_len + 1))
+        ids = rs.randint(3, hi, size=n).astype(np.int32)
+        ids[-1] = 1
+        out.append(ids)
+    return out
+
+
+def write_checkpoint(path: str, spec: dict, tokenizer_dir: str = None) -> None:
+    """Materialise a HF-layout checkpoint dir (config.json + model.safetensors [+ tokenizer files]) from a
+    regeneration recipe {dims, seed, gain[, boost_ids, boost]} — see tests/golden/ckpts.json."""
+    import json
+    import os
+    import shutil
+    from safetensors.numpy import save_file
+    dims = NAMED_DIMS[spec["dims"]]
+    os.makedirs(path, exist_ok=True)
+    sd = synth_state_dict(dims, seed=spec["seed"], gain=spec.get("gain", 1.0))
+    if spec.get("boost_ids"):
+        key = "shared.weight" if dims.tied_head else "lm_head.weight"
+        w = sd[key].copy()
+        ids = np.asarray(spec["boost_ids"], dtype=np.int64)
+        w[ids] = _fp16_round(w[ids] * np.float32(spec["boost"]))
+        sd[key] = w
+    save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(dims.to_hf_config(), f, indent=1)
+    if tokenizer_dir:
+        for fn in os.listdir(tokenizer_dir):
+            shutil.copy(os.path.join(tokenizer_dir, fn), os.path.join(path, fn))
+
+
+def checkpoint_sha256(path: str) -> str:
+    import hashlib
+    import os
+    from safetensors.numpy import load_file
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k]).tobytes())
+    return h.hexdigest()

@@ -1,0 +1,92 @@
+"""Pin the oracle (oracle/t5_numpy.py) to the HuggingFace/reference goldens (CPU, no GPU).
+
+Goldens come from tools/make_goldens.py: HF transformers 5.15.0 fp32 forward of padded batches — the
+arithmetic the reference executes at ref: llmrankers/pointwise.py:117-119 / setwise.py:93-95,184."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, load_state
+from oracle.t5_numpy import T5Oracle, relative_position_bucket
+
+TOL = 1e-4   # fp32 vs fp32: different summation order, ragged vs padded; logits reach |12|
+
+
+def test_rel_bucket_tables():
+    g = np.load(os.path.join(GOLD, "rel_buckets.npz"))
+    rel = g["rel"]
+    for key in g.files:
+        if key == "rel":
+            continue
+        b, nb, md = key[1:].split("_")
+        got = relative_position_bucket(rel, bidirectional=bool(int(b)), num_buckets=int(nb), max_distance=int(md))
+        np.testing.assert_array_equal(got, g[key], err_msg=key)
+
+
+@pytest.mark.parametrize("name", ["gated_untied", "relu_tied"])
+def test_forward_matches_hf(name, ckpt_dirs):
+    dims, state = load_state(ckpt_dirs["ckpt_" + name])
+    g = np.load(os.path.join(GOLD, f"model_{name}.npz"))
+    orc = T5Oracle(dims, state)
+    lens = g["lens"]
+    seqs = [g["input_ids"][b, :n] for b, n in enumerate(lens)]
+    for tag in ("d1", "d2", "d5"):
+        dec = g[f"{tag}.dec_ids"].tolist()
+        for b, ids in enumerate(seqs):
+            orc.capture = {}
+            logits = orc.decode(orc.encode(ids), dec)
+            np.testing.assert_allclose(logits, g[f"{tag}.logits"][b], atol=TOL, rtol=TOL)
+            if tag == "d2":
+                n = len(ids)
+                for k, v in orc.capture.items():
+                    gk = f"d2.{k}"
+                    if gk not in g.files:
+                        continue
+                    ref = g[gk][b]
+                    ref = ref[:n] if k.startswith("enc.") else ref
+                    np.testing.assert_allclose(v, ref, atol=TOL, rtol=TOL, err_msg=f"{k} seq {b}")
+        orc.capture = None
+
+
+@pytest.mark.parametrize("name", ["gated_untied", "relu_tied"])
+def test_qlm_and_greedy_match_hf(name, ckpt_dirs):
+    dims, state = load_state(ckpt_dirs["ckpt_" + name])
+    g = np.load(os.path.join(GOLD, f"model_{name}.npz"))
+    orc = T5Oracle(dims, state)
+    seqs = [g["input_ids"][b, :n] for b, n in enumerate(g["lens"])]
+    labels = g["qlm.labels"]
+    lg = g["qlm.logits"].astype(np.float64)
+    m = lg.max(-1, keepdims=True)
+    lse = (m + np.log(np.exp(lg - m).sum(-1, keepdims=True)))[..., 0]
+    want = -(lse - np.take_along_axis(lg, labels[None, :, None].repeat(len(seqs), 0), -1)[..., 0]).sum(-1)
+    np.testing.assert_allclose(orc.qlm(seqs, labels), want, atol=1e-4, rtol=1e-5)
+    prefix = g["gen.prefix"].tolist()
+    got = orc.greedy(seqs, prefix, max_new=2)
+    gen = g["gen.output_ids"]
+    assert gen.shape[1] <= len(prefix) + 2
+    want_new = np.zeros_like(got)
+    want_new[:, :gen.shape[1] - len(prefix)] = gen[:, len(prefix):]
+    np.testing.assert_array_equal(got, want_new)
+    singles = json.loads(bytes(g["gen.single_json"]).decode())
+    for b, s in enumerate(singles):       # the reference's own B=1 call shape stops at EOS
+        new = s[len(prefix):]
+        assert got[b, :len(new)].tolist() == new
+
+
+def test_config1_flan_t5_small_logits():
+    """BASELINE.json configs[0] plumbing case: flan-t5-small shape, 20 passages, HF fp32 CPU logits."""
+    from llmrankers import _synth
+    g = np.load(os.path.join(GOLD, "config1_flan_t5_small.npz"))
+    dims = _synth.FLAN_T5_SMALL
+    orc = T5Oracle(dims, _synth.synth_state_dict(dims, seed=int(g["seed"])))
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    seqs = [g["tokens"][off[i]:off[i + 1]] for i in range(len(g["lens"]))]
+    regen = _synth.synth_token_batch(20, 60, 184, dims.vocab, seed=int(g["token_seed"]))
+    assert all(np.array_equal(a, b) for a, b in zip(seqs, regen))
+    sub = [0, 7, 19]                              # 3 of 20 keeps the CPU suite quick; GPU test does all 20
+    got = orc.score_last([seqs[i] for i in sub], [0], g["yes_no_ids"])
+    np.testing.assert_allclose(got, g["logits"][sub], atol=5e-5, rtol=1e-5)
+    full = orc.score_last([seqs[0]], [0])[0]
+    np.testing.assert_allclose(full, g["full_logits_seq0"], atol=5e-5, rtol=1e-5)

@@ -1,0 +1,396 @@
+#!/usr/bin/env python
+"""Generate tests/golden/ — runs ONLY in the build container (needs /root/reference + transformers).
+
+Imports the real reference (ielab/llm-rankers @ /root/reference, read-only, never copied) against the
+installed HuggingFace transformers, on synthetic checkpoints + a synthetic tokenizer, and records
+inputs / activations / logits / rankings / counters as small data fixtures.  The reference ships no
+tests or golden vectors, so these are the parity pins for oracle/ and for the HIP
+engine.  Nothing Python from the reference travels to the GPU box; only the data written here does.
+
+Shims needed to import the reference under transformers 5.x:
+  * `openai`, `tiktoken` stub modules (only used by the OpenAI ranker classes),
+  * `T5Tokenizer.batch_encode_plus` (removed in 5.x; used at ref: llmrankers/setwise.py:55).
+
+Usage:  python tools/make_goldens.py            (rewrites tests/golden/)
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import random
+import shutil
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, os.path.join(REPO, "llm-rankers_amd"))
+sys.path.insert(0, REPO)
+
+from llmrankers import _synth  # noqa: E402  (the build's own generator; not the reference package)
+
+REF = "/root/reference"
+
+WORDS = (
+    "neural ranking model search engine index retrieval document answer question relevant topic "
+    "passage language large small fast slow memory compute kernel matrix vector token score sort heap "
+    "bubble list set point pair wise zero shot prompt label output input batch size length water river "
+    "mountain city country history science physics chemistry biology medicine doctor patient virus "
+    "vaccine covid treatment symptom economy market price trade bank money law court judge music art "
+    "film book author").split()
+PROMPT_WORDS = (
+    "Passage: Query: Does the passage answer query? Answer 'Yes' or 'No' Given a query which of "
+    "following passages is most relevant one to Output only label Please write question based on this "
+    "Document: Relevant: Passage Yes No").split()
+LABELS = [chr(ord("A") + i) for i in range(23)]
+
+
+def build_vocab():
+    pieces = [("<pad>", 0.0), ("</s>", 0.0), ("<unk>", 0.0), ("▁", -3.0)]
+    seen = {p for p, _ in pieces}
+
+    def add(p, s):
+        if p not in seen:
+            seen.add(p)
+            pieces.append((p, s))
+
+    for w in PROMPT_WORDS:
+        add("▁" + w, -2.0)
+    for c in LABELS:
+        add("▁" + c, -2.5)
+    for w in WORDS:
+        add("▁" + w, -2.0)
+    for c in "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789:?'\",.-":
+        add(c, -7.0)
+    assert len(pieces) <= 256, len(pieces)
+    return pieces
+
+
+def make_tokenizer(path):
+    from transformers import T5Tokenizer
+    tok = T5Tokenizer(vocab=build_vocab(), extra_ids=0)
+    tok.save_pretrained(path)
+    return T5Tokenizer.from_pretrained(path)
+
+
+def write_ckpt(path, spec, tok_dir):
+    """spec = the regeneration recipe committed to tests/golden/ckpts.json (weights themselves are not committed)."""
+    _synth.write_checkpoint(path, spec, tok_dir)
+    return _synth.checkpoint_sha256(path)
+
+
+def rand_text(rs, lo, hi):
+    return " ".join(rs.choice(WORDS, size=int(rs.randint(lo, hi + 1))))
+
+
+def import_reference():
+    for m in ("openai", "tiktoken"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    from transformers import T5Tokenizer
+    if not hasattr(T5Tokenizer, "batch_encode_plus"):
+        T5Tokenizer.batch_encode_plus = lambda self, texts, **kw: self(texts, **kw)
+    sys.path.insert(0, REF)
+    with contextlib.redirect_stdout(io.StringIO()):
+        # NB: `llmrankers` would resolve to the build's own package first on sys.path, so load the
+        # reference's package under its real name from its own directory explicitly.
+        for k in [k for k in sys.modules if k == "llmrankers" or k.startswith("llmrankers.")]:
+            del sys.modules[k]
+        sys.path.remove(os.path.join(REPO, "llm-rankers_amd"))
+        import llmrankers.rankers as ref_rankers
+        import llmrankers.pointwise as ref_pointwise
+        import llmrankers.setwise as ref_setwise
+    assert ref_rankers.__file__.startswith(REF), ref_rankers.__file__
+    return ref_rankers, ref_pointwise, ref_setwise
+
+
+def hf_model_goldens(ckpt_dir, name, tok):
+    """Padded HF batch forward with hooks -> activations + logits for oracle pinning."""
+    import torch
+    from transformers import T5ForConditionalGeneration
+    model = T5ForConditionalGeneration.from_pretrained(ckpt_dir, torch_dtype=torch.float32).eval()
+    cfg = model.config
+    rs = np.random.RandomState(4242)
+    lens = [7, 24, 13, 1, 19]
+    seqs = [rs.randint(3, cfg.vocab_size, size=n).astype(np.int64) for n in lens]
+    for s in seqs:
+        s[-1] = 1
+    L = max(lens)
+    ids = np.zeros((len(seqs), L), dtype=np.int64)
+    mask = np.zeros((len(seqs), L), dtype=np.int64)
+    for b, s in enumerate(seqs):
+        ids[b, :len(s)] = s
+        mask[b, :len(s)] = 1
+    passage_id = tok.encode("<pad> Passage", add_special_tokens=False)
+    out = {"lens": np.array(lens), "input_ids": ids, "attention_mask": mask}
+    caps = {}
+
+    def hook(key):
+        def fn(mod, args, output):
+            caps[key] = (output[0] if isinstance(output, tuple) else output).detach().numpy().copy()
+        return fn
+
+    hs = []
+    for i, blk in enumerate(model.encoder.block):
+        hs.append(blk.layer[0].register_forward_hook(hook(f"enc.{i}.attn")))
+        hs.append(blk.register_forward_hook(hook(f"enc.{i}.ffn")))
+    hs.append(model.encoder.embed_tokens.register_forward_hook(hook("enc.embed")))
+    hs.append(model.encoder.final_layer_norm.register_forward_hook(hook("enc.final")))
+    for i, blk in enumerate(model.decoder.block):
+        hs.append(blk.layer[0].register_forward_hook(hook(f"dec.{i}.self")))
+        hs.append(blk.layer[1].register_forward_hook(hook(f"dec.{i}.cross")))
+        hs.append(blk.register_forward_hook(hook(f"dec.{i}.ffn")))
+    hs.append(model.decoder.final_layer_norm.register_forward_hook(hook("dec.final_norm")))
+
+    for tag, dec in (("d1", [0]), ("d2", passage_id), ("d5", [0, 9, 17, 4, 30])):
+        caps.clear()
+        dec_ids = torch.tensor([dec] * len(seqs))
+        with torch.no_grad():
+            o = model(input_ids=torch.tensor(ids), attention_mask=torch.tensor(mask), decoder_input_ids=dec_ids)
+        out[f"{tag}.dec_ids"] = np.array(dec)
+        out[f"{tag}.logits"] = o.logits.numpy()
+        if tag == "d2":      # per-sublayer activations for one decoder shape only (keeps the fixture small)
+            for k, v in caps.items():
+                out[f"{tag}.{k}"] = v
+    for h in hs:
+        h.remove()
+    # qlm style labels path (HF shifts right internally)
+    labels = np.array([0, 12, 7, 99, 45, 3], dtype=np.int64)
+    with torch.no_grad():
+        o = model(input_ids=torch.tensor(ids), attention_mask=torch.tensor(mask),
+                  labels=torch.tensor(labels)[None].repeat(len(seqs), 1))
+    out["qlm.labels"] = labels
+    out["qlm.logits"] = o.logits.numpy()
+    # greedy generation (batched, prefix [0, Passage])
+    with torch.no_grad():
+        g = model.generate(torch.tensor(ids), attention_mask=torch.tensor(mask),
+                           decoder_input_ids=torch.tensor([passage_id] * len(seqs)), max_new_tokens=2,
+                           do_sample=False)
+    out["gen.prefix"] = np.array(passage_id)
+    out["gen.output_ids"] = g.numpy()
+    singles = []
+    for s in seqs:   # the reference's own call shape: one sequence, no mask (ref: setwise.py:93-95)
+        with torch.no_grad():
+            g1 = model.generate(torch.tensor(s)[None], decoder_input_ids=torch.tensor([passage_id]),
+                                max_new_tokens=2)
+        singles.append(g1[0].numpy().tolist())
+    out["gen.single_json"] = np.frombuffer(json.dumps(singles).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, f"model_{name}.npz"), **out)
+    print(f"[model_{name}] logits d1 range {out['d1.logits'].min():.3f}..{out['d1.logits'].max():.3f}")
+
+
+def bucket_goldens():
+    from transformers.models.t5.modeling_t5 import T5Attention
+    import torch
+    rel = torch.arange(-1024, 1025)
+    out = {"rel": rel.numpy()}
+    for bidir in (True, False):
+        for nb, md in ((32, 128), (32, 64), (16, 128)):
+            out[f"b{int(bidir)}_{nb}_{md}"] = T5Attention._relative_position_bucket(
+                rel, bidirectional=bidir, num_buckets=nb, max_distance=md).numpy()
+    np.savez_compressed(os.path.join(GOLD, "rel_buckets.npz"), **out)
+
+
+def sort_trace_goldens(ref_rankers, ref_setwise):
+    """Reference sort drivers with a deterministic fake comparator (SURVEY.md section 3.2 probe recipe)."""
+    traces = []
+    for (n, c, k) in ((100, 10, 10), (100, 3, 10), (100, 2, 10), (20, 3, 5), (7, 3, 10), (1, 3, 5), (24, 22, 3)):
+        for method in ("heapsort", "bubblesort"):
+            for mode in ("truth", "garbage"):
+                rk = ref_setwise.SetwiseLlmRanker.__new__(ref_setwise.SetwiseLlmRanker)
+                rk.num_child, rk.k, rk.method, rk.num_permutation = c, k, method, 1
+                rs = np.random.RandomState(n * 131 + c * 17 + k)
+                rel = rs.permutation(n).tolist()           # hidden relevance of doc i
+                calls = []
+
+                def fake_compare(query, docs, _rel=rel, _calls=calls, _mode=mode):
+                    rk.total_compare += 1
+                    idx = [int(d.docid[1:]) for d in docs]
+                    _calls.append(idx)
+                    if not idx:          # k > n in bubblesort: the reference really calls compare([])
+                        return "A"
+                    best = max(range(len(docs)), key=lambda j: _rel[idx[j]])
+                    if _mode == "garbage" and len(_calls) % 3 == 0:
+                        return ["?", "Z", "zz"][len(_calls) % 9 // 3]   # ValueError -> 0 fallback paths
+                    if _mode == "garbage" and len(_calls) % 7 == 0 and rk.method == "heapsort":
+                        return "W"     # IndexError -> keep parent (bubblesort has no such guard: it raises)
+                    return ref_setwise.SetwiseLlmRanker.CHARACTERS[best]
+
+                rk.compare = fake_compare
+                ranking = [ref_rankers.SearchResult(docid=f"d{i}", score=float(n - i), text=f"t{i}") for i in range(n)]
+                with contextlib.redirect_stdout(io.StringIO()):
+                    res = rk.rerank("q", ranking)
+                traces.append({"n": n, "c": c, "k": k, "method": method, "mode": mode, "rel": rel,
+                               "calls": calls, "total_compare": rk.total_compare,
+                               "result": [[r.docid, r.score] for r in res],
+                               "caller_list_after": [r.docid for r in ranking]})
+    with open(os.path.join(GOLD, "sort_traces.json"), "w") as f:
+        json.dump(traces, f)
+    print(f"[sort_traces] {len(traces)} traces")
+
+
+def rerank_goldens(ref_rankers, ref_pointwise, ref_setwise, ckpts):
+    rs = np.random.RandomState(77)
+    cases = []
+    queries = [rand_text(rs, 3, 8) for _ in range(3)]
+    doc_pool = [rand_text(rs, 8, 40) for _ in range(40)]
+
+    def make_ranking(n, off):
+        return [ref_rankers.SearchResult(docid=f"D{off + i}", score=float(100 - i), text=doc_pool[(off + i) % 40])
+                for i in range(n)]
+
+    sink = io.StringIO()
+    # pointwise (ref: pointwise.py:36-130); batch sizes chosen so the last batch is ragged
+    for ck in ("ckpt_gated_untied", "ckpt_relu_tied"):
+        for method, bs, n in (("yes_no", 4, 20), ("yes_no", 32, 13), ("qlm", 4, 10), ("qlm", 3, 7)):
+            with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+                rk = ref_pointwise.PointwiseLlmRanker(ckpts[ck], ckpts[ck], device="cpu", method=method, batch_size=bs)
+                for qi, q in enumerate(queries[:2]):
+                    ranking = make_ranking(n, 5 * qi)
+                    inp = [[r.docid, r.score, r.text] for r in ranking]
+                    res = rk.rerank(q, ranking)
+                    cases.append({"kind": "pointwise", "ckpt": ck, "method": method, "batch_size": bs, "query": q,
+                                  "input": inp, "result": [[r.docid, r.score] for r in res],
+                                  "counters": [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens]})
+    # monoT5 (ref: pointwise.py:136-186) — fixed token ids 6136/1176 exceed the toy vocab, so golden only
+    # the relu/tied forward via yes_no above; MonoT5 ids are exercised with a vocab-mapped variant in tests.
+
+    # setwise (ref: setwise.py:79-313)
+    for ck, scoring, method, c, k, nperm, n in (
+        ("ckpt_gated_untied", "likelihood", "heapsort", 3, 5, 1, 20),
+        ("ckpt_gated_untied", "likelihood", "bubblesort", 3, 5, 1, 20),
+        ("ckpt_gated_untied", "generation", "heapsort", 3, 5, 1, 20),
+        ("ckpt_labelboost", "generation", "heapsort", 3, 5, 1, 20),
+        ("ckpt_labelboost", "generation", "bubblesort", 4, 4, 1, 14),
+        ("ckpt_labelboost", "likelihood", "bubblesort", 4, 4, 1, 14),
+        ("ckpt_labelboost", "generation", "heapsort", 2, 3, 3, 12),
+        ("ckpt_labelboost", "likelihood", "heapsort", 10, 10, 1, 30),
+        ("ckpt_relu_tied", "likelihood", "heapsort", 3, 5, 1, 16),
+    ):
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            rk = ref_setwise.SetwiseLlmRanker(ckpts[ck], ckpts[ck], device="cpu", num_child=c, k=k, scoring=scoring,
+                                              method=method, num_permutation=nperm)
+            compare_log = []
+            orig_compare = rk.compare
+
+            def logged(query, docs, _o=orig_compare, _l=compare_log):
+                out = _o(query, docs)
+                _l.append([[d.docid for d in docs], out])
+                return out
+
+            rk.compare = logged
+            for qi, q in enumerate(queries[:2]):
+                ranking = make_ranking(n, 3 * qi)
+                inp = [[r.docid, r.score, r.text] for r in ranking]
+                random.seed(929)
+                del compare_log[:]
+                raises = None
+                try:
+                    res = rk.rerank(q, ranking)
+                except IndexError:     # the reference's bubblesort has no guard for an out-of-window label
+                    raises, res = "IndexError", []
+                cases.append({"kind": "setwise", "ckpt": ck, "scoring": scoring, "method": method, "num_child": c, "k": k,
+                              "num_permutation": nperm, "query": q, "input": inp, "raises": raises,
+                              "result": [[r.docid, r.score] for r in res], "compares": list(compare_log),
+                              "caller_list_after": [r.docid for r in ranking],
+                              "counters": [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens]})
+    # truncate() (ref: pointwise.py:132-133)
+    from transformers import T5Tokenizer
+    tok = T5Tokenizer.from_pretrained(ckpts["ckpt_gated_untied"])
+    trunc = []
+    for t in doc_pool[:6] + ["Hello World-42, unknown é chars?", ""]:
+        for n in (0, 1, 5, 128):
+            trunc.append([t, n, tok.convert_tokens_to_string(tok.tokenize(t)[:n])])
+    with open(os.path.join(GOLD, "rerank_cases.json"), "w") as f:
+        json.dump({"cases": cases, "truncate": trunc}, f)
+    n_unexp = sink.getvalue().count("Unexpected output")
+    print(f"[rerank_cases] {len(cases)} cases; reference printed 'Unexpected output' {n_unexp}x")
+
+
+def config1_golden(ref_rankers, ref_pointwise, tok_dir):
+    """BASELINE.json configs[0]: flan-t5-small shape, pointwise yes_no, hits=20, batch_size=4, CPU HF reference.
+    Weights come from the counter generator (regenerable on the GPU box); prompts are pre-tokenised ids."""
+    import torch
+    from transformers import T5ForConditionalGeneration, T5Config
+    dims = _synth.FLAN_T5_SMALL
+    cfg = T5Config(**{k: v for k, v in dims.to_hf_config().items() if k not in ("architectures", "model_type")})
+    model = T5ForConditionalGeneration(cfg).eval()
+    sd = _synth.synth_state_dict(dims, seed=929)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    tsd["encoder.embed_tokens.weight"] = tsd["shared.weight"]
+    tsd["decoder.embed_tokens.weight"] = tsd["shared.weight"]
+    model.lm_head.weight = torch.nn.Parameter(tsd["lm_head.weight"].clone())     # untie like flan (hf 5.x ties by default)
+    missing = model.load_state_dict(tsd, strict=False)
+    assert not missing.unexpected_keys, missing
+    model.config.scale_decoder_outputs = False
+    assert model.lm_head.weight.data_ptr() != model.shared.weight.data_ptr()
+    seqs = _synth.synth_token_batch(20, 60, 184, dims.vocab, seed=930)
+    yes_id, no_id = 2163, 465       # real flan-t5 ids quoted from memory; any two ids work for parity
+    logits = np.zeros((20, 2), dtype=np.float32)
+    full0 = None
+    for s0 in range(0, 20, 4):                     # batch_size 4, right padded like DataCollatorWithPadding
+        chunk = seqs[s0:s0 + 4]
+        L = max(len(s) for s in chunk)
+        ids = np.zeros((len(chunk), L), dtype=np.int64)
+        mask = np.zeros_like(ids)
+        for b, s in enumerate(chunk):
+            ids[b, :len(s)] = s
+            mask[b, :len(s)] = 1
+        with torch.no_grad():
+            lg = model(input_ids=torch.tensor(ids), attention_mask=torch.tensor(mask),
+                       decoder_input_ids=torch.zeros((len(chunk), 1), dtype=torch.long)).logits[:, 0]
+        logits[s0:s0 + len(chunk), 0] = lg[:, yes_id].numpy()
+        logits[s0:s0 + len(chunk), 1] = lg[:, no_id].numpy()
+        if full0 is None:
+            full0 = lg[0].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "config1_flan_t5_small.npz"),
+                        lens=np.array([len(s) for s in seqs]), tokens=np.concatenate(seqs),
+                        yes_no_ids=np.array([yes_id, no_id]), logits=logits, full_logits_seq0=full0,
+                        seed=np.array(929), token_seed=np.array(930))
+    print(f"[config1] yes/no logit diff range {np.ptp(logits[:, 0] - logits[:, 1]):.3f}")
+
+
+def main():
+    if os.path.isdir(GOLD):
+        shutil.rmtree(GOLD)
+    os.makedirs(GOLD)
+    tok_dir = os.path.join(GOLD, "tok")
+    tok = make_tokenizer(tok_dir)
+    label_ids = [tok.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1] for c in LABELS]
+    assert len(set(label_ids)) == 23 and all(i > 3 for i in label_ids), label_ids
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="rk_goldens_")
+    specs = {
+        "ckpt_gated_untied": {"dims": "toy-gated-untied", "seed": 11, "gain": 2.0},
+        "ckpt_relu_tied": {"dims": "toy-relu-tied", "seed": 12, "gain": 2.0},
+        "ckpt_labelboost": {"dims": "toy-gated-untied", "seed": 13, "gain": 2.0,
+                            "boost_ids": label_ids + [1], "boost": 6.0},
+    }
+    ckpts = {}
+    for name, spec in specs.items():
+        ckpts[name] = os.path.join(tmp, name)
+        spec["sha256"] = write_ckpt(ckpts[name], spec, tok_dir)
+    with open(os.path.join(GOLD, "ckpts.json"), "w") as f:
+        json.dump(specs, f, indent=1)
+    bucket_goldens()
+    hf_model_goldens(ckpts["ckpt_gated_untied"], "gated_untied", tok)
+    hf_model_goldens(ckpts["ckpt_relu_tied"], "relu_tied", tok)
+    ref_rankers, ref_pointwise, ref_setwise = import_reference()
+    sort_trace_goldens(ref_rankers, ref_setwise)
+    rerank_goldens(ref_rankers, ref_pointwise, ref_setwise, ckpts)
+    config1_golden(ref_rankers, ref_pointwise, tok_dir)
+    with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
+        import transformers, torch
+        json.dump({"generator": "tools/make_goldens.py", "reference": "ielab/llm-rankers @ /root/reference (2025-07-18)",
+                   "transformers": transformers.__version__, "torch": torch.__version__,
+                   "numpy": np.__version__}, f, indent=1)
+    shutil.rmtree(tmp)
+    total = sum(os.path.getsize(os.path.join(dp, fn)) for dp, _, fns in os.walk(GOLD) for fn in fns)
+    print(f"tests/golden: {total / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
