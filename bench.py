@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py — passages/sec of the pointwise yes_no hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): flan-t5-large dimensions, pointwise yes_no, batch_size=32, synthetic
+32-token-query / 128-token-passage prompts -> L_e = 184 encoder tokens per passage, decoder
+input [pad], scores = logits of two vocabulary rows.  Weights are the deterministic synthetic checkpoint
+(llmrankers._synth, HF init scales) — there are no real weights offline.  One "step" = one batch of 32
+passages through encoder + decoder + head with the token ids already resident in HBM (rk_t5_stage before the
+timed region; the host->device copy of 32x184 int32 = 23.5 KB is noted in DESIGN.md, never part of `value`).
+
+Multi-GPU: passages of a query are independent, so the candidate list shards across ranks (weak scaling: each
+rank scores its own batch of 32 per step) and the per-step scores are collected with ONE RCCL all_gather over
+xGMI (torch.distributed 'nccl' = RCCL).  value = passages all ranks scored / max-over-ranks time.
+
+Extra objects on the JSON line: `roofline` (the encoder GEMM kernel, MFMA-bound: algorithmic 2MNK flops per
+launch / average launch duration measured with HIP events on the engine's stream in a second, profiled pass)
+and `cpu_baseline` (the reference's CPU path — HF transformers fp32 — timed on this box's host cores, rank 0,
+N=1 only, on one batch of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "llm-rankers_amd"))
+sys.path.insert(0, REPO)
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
+YES_ID, NO_ID = 2163, 465     # flan-t5 "Yes"/"No" ids quoted from memory; any two rows cost the same
+
+
+def algorithmic_gflop_per_passage(d, L_e, L_d=1):
+    """SURVEY.md section 8(d) formula (2 FLOP per MAC), head excluded."""
+    dm, I, F = d.d_model, d.inner, d.d_ff
+    ffn = 6 if d.gated else 4
+    enc = d.n_enc * (L_e * (8 * dm * I + ffn * dm * F) + 4 * L_e * L_e * I)
+    dec = d.n_dec * (L_d * (8 * dm * I + 4 * dm * I + ffn * dm * F) + 4 * L_e * dm * I + 4 * L_d * L_e * I + 4 * L_d * L_d * I)
+    return (enc + dec) / 1e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="flan-t5-large")
+    ap.add_argument("--batch_size", type=int, default=32)
+    ap.add_argument("--seq_len", type=int, default=184)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_profile", action="store_true")
+    ap.add_argument("--glds", type=int, default=1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
+    import torch                        # first: its bundled HIP runtime must be the one in the process
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from llmrankers import _synth
+    from llmrankers._engine import RkEngine
+
+    dims = _synth.NAMED_DIMS[args.model]
+    B, L = args.batch_size, args.seq_len
+    t0 = time.time()
+    state = _synth.synth_state_dict(dims, seed=929, threads=min(32, os.cpu_count() or 8))
+    eng = RkEngine(dims, device=local_rank, max_tokens=max(8192, B * L), max_seqs=max(32, B), max_dec_len=4)
+    eng.load_state(state.items())
+    eng.set_option("gemm_glds", args.glds)
+    if rank == 0:
+        print(f"[bench] weights generated + engine finalized in {time.time() - t0:.1f}s", file=sys.stderr)
+    seqs = _synth.synth_token_batch(B, L, L, dims.vocab, seed=929 + rank)
+    eng.stage(seqs)                                        # inputs resident in HBM before the timed region
+    dec, out_ids = [0], [YES_ID, NO_ID]
+    gathered = torch.empty((world, B, 2), dtype=torch.float32, device="cuda") if world > 1 else None
+
+    def step():
+        eng.score_staged(dec, out_ids)
+        if world > 1:                                       # one RCCL gather of the step's [B,2] scores
+            eng.sync()
+            local = torch.from_numpy(eng.read_scores()).cuda(non_blocking=True)
+            dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t_start = time.perf_counter()
+    eng.timer_begin()
+    for _ in range(args.steps):
+        step()
+    ev_ms = eng.timer_end()                                # HIP events on the engine's own stream
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    scores = eng.read_scores()
+    assert np.isfinite(scores).all()
+
+    roofline = None
+    if not args.no_profile:
+        eng.profile(True)
+        eng.profile_reset()
+        for _ in range(min(args.steps, 5)):
+            eng.score_staged(dec, out_ids)
+        eng.sync()
+        rep = eng.profile_report()
+        eng.profile(False)
+        gemm_classes = ["enc_gemm_qkv", "enc_gemm_o", "enc_gemm_ffn_in", "enc_gemm_ffn_out", "gemm_cross_kv"]
+        g_ms = sum(rep[c]["ms"] for c in gemm_classes)
+        g_fl = sum(rep[c]["flops"] for c in gemm_classes)
+        g_n = sum(rep[c]["launches"] for c in gemm_classes)
+        achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        total_ms = sum(v["ms"] for v in rep.values())
+        roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "gemm_f16_kernel (all encoder-side launches: qkv, o, ffn_in+GEGLU, ffn_out, cross_kv)",
+                    "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches": int(g_n),
+                    "gemm_share_of_gpu_time": round(g_ms / total_ms, 3) if total_ms else None,
+                    "per_class": {k: {"ms_per_step": round(v["ms"] / min(args.steps, 5), 4),
+                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
+                                  for k, v in rep.items() if v["launches"]}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import hf_path
+            cpu = hf_path.time_cpu_baseline(dims, state, [list(s) for s in seqs], B, YES_ID, NO_ID, max_seconds=30.0)
+            ref_logits = cpu.pop("logits")
+            p_cpu = 1 / (1 + np.exp(-(ref_logits[:, 0] - ref_logits[:, 1])))
+            p_gpu = 1 / (1 + np.exp(-(scores[:len(p_cpu), 0] - scores[:len(p_cpu), 1])))
+            cpu["max_abs_score_diff_vs_gpu"] = float(np.abs(p_cpu - p_gpu).max())
+            cpu["value"] = round(cpu["value"], 3)
+        except Exception as exc:                      # the baseline must never take the GPU number down with it
+            cpu = {"value": None, "unit": "passages/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {exc!r}"}
+
+    if rank == 0:
+        passages = args.steps * B * world
+        gfl = algorithmic_gflop_per_passage(dims, L)
+        value = passages / elapsed
+        line = {
+            "metric": "passages/sec (pointwise yes_no reranking, flan-t5-large shape)", "value": round(value, 1),
+            "unit": "passages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 (MFMA inputs), f32 accumulate + residual stream", "data": "synthetic",
+            "config": {"workload": f"{args.model} pointwise yes_no, hits=100 batch_size={B} (one step = one batch), "
+                                   f"L_e={L} (128-token passage + 32-token query + template), L_d=1, 2 label rows",
+                       "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world} (candidate sharding + 1 RCCL all_gather/step)",
+                       "weights": "synthetic N(0, HF-init std), seed 929", "engine_stream_ms_per_step": round(ev_ms / args.steps, 3),
+                       "algorithmic_gflop_per_passage": round(gfl, 2),
+                       "whole_path_tflops_per_gpu": round(value / world * gfl / 1e3, 1),
+                       "whole_path_frac_of_mfma_peak": round(value / world * gfl / 1e3 / MFMA_PEAK_TFLOPS, 4)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+/* rk_engine.h — C ABI of the MI355X-native reranking engine (librk_engine.so, gfx950 only).
+ *
+ * This is the drop-in boundary for ONE hot path of ielab/llm-rankers: the batched T5 encoder-decoder forward
+ * behind PointwiseLlmRanker.rerank and SetwiseLlmRanker.compare.  The reference has no FFI of its own; the
+ * inner boundary these entry points replace is exactly three HuggingFace calls plus two attributes
+ * (SURVEY.md section 8b):
+ *
+ *   self.llm(input_ids, attention_mask, decoder_input_ids=...).logits   ref: llmrankers/pointwise.py:117-119,
+ *                                                                             llmrankers/setwise.py:184
+ *   self.llm(input_ids, attention_mask, labels=...).logits               ref: llmrankers/pointwise.py:73-75
+ *   self.llm.generate(input_ids, decoder_input_ids=..., max_new_tokens=2) ref: llmrankers/setwise.py:93-95,128-130
+ *   T5ForConditionalGeneration.from_pretrained(...)                       ref: llmrankers/pointwise.py:20-24
+ *
+ * Conventions: plain C, every function returns 0 on success or a negative rk_status; rk_last_error() gives the
+ * message of the last failure on that engine (or of the last failed rk_engine_create when engine == NULL).
+ * No exceptions, Python objects or torch types cross this boundary.  Inputs are RAGGED: the B token sequences
+ * of a batch are concatenated without padding, seq_offsets[B+1] gives the boundaries (the reference right-pads
+ * to the batch's longest sequence and masks; results are identical).  The caller owns all host
+ * buffers; the engine owns device memory and one HIP stream.  One engine per device; calls on one engine must
+ * be serialised by the caller; different engines may be driven from different threads.
+ * There is NO CPU fallback: with no usable gfx950 device rk_engine_create fails with RK_ERR_NO_DEVICE.
+ */
+#ifndef RK_ENGINE_H
+#define RK_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rk_engine rk_engine;
+
+typedef enum rk_status {
+  RK_OK = 0,
+  RK_ERR_INVALID = -1,    /* bad argument / unsupported model dimensions */
+  RK_ERR_NO_DEVICE = -2,  /* no gfx950 GPU visible — the engine never falls back to the CPU */
+  RK_ERR_HIP = -3,        /* a HIP runtime call failed */
+  RK_ERR_STATE = -4,      /* call order violated (e.g. score before finalize) */
+  RK_ERR_MISSING = -5,    /* finalize: a required tensor was never loaded */
+  RK_ERR_CAPACITY = -6    /* batch exceeds max_tokens / max_seqs / max_dec_len of the engine */
+} rk_status;
+
+typedef enum rk_dtype { RK_F32 = 0, RK_F16 = 1, RK_BF16 = 2 } rk_dtype;
+
+/* Mirrors the fields of HF's T5Config the path depends on (hf: models/t5/configuration_t5.py). */
+typedef struct rk_model_desc {
+  int32_t vocab, d_model, n_heads, d_kv, d_ff;
+  int32_t n_enc_layers, n_dec_layers;
+  int32_t n_buckets, max_distance;   /* relative_attention_num_buckets / _max_distance */
+  int32_t gated_gelu;                /* 1: feed_forward_proj = "gated-gelu" (T5 v1.1 / flan); 0: "relu" */
+  int32_t tied_head;                 /* 1: lm_head = shared and logits scaled by d_model^-0.5 (T5 v1.0, monoT5) */
+  float eps;                         /* layer_norm_epsilon */
+  int32_t max_tokens;                /* capacity: encoder tokens per call (sum over the batch) */
+  int32_t max_seqs;                  /* capacity: sequences per call */
+  int32_t max_dec_len;               /* capacity: decoder positions per sequence */
+} rk_model_desc;
+
+/* ---- lifetime & weights (replaces from_pretrained, ref: pointwise.py:20-24 / setwise.py:46-50) ---- */
+int rk_engine_create(const rk_model_desc* desc, int device_ordinal, rk_engine** out);
+void rk_engine_destroy(rk_engine* e);
+const char* rk_last_error(const rk_engine* e);
+/* One call per HF state-dict entry (names as in the checkpoint, e.g. "encoder.block.0.layer.0.SelfAttention.q.weight").
+ * Data is converted to fp16 (the reference's accelerator dtype).  Names the path does not need are ignored. */
+int rk_engine_load_tensor(rk_engine* e, const char* hf_name, const void* data, int dtype, const int64_t* shape, int ndim);
+/* Repack (fused QKV, interleaved wi_0|wi_1, stacked cross K/V, bias tables), upload, free host copies. */
+int rk_engine_finalize(rk_engine* e);
+
+/* ---- blocking calls on host buffers: what the Python rankers use ---- */
+/* logits of the LAST decoder position for out_token_ids (n_out > 0) -> out_logits[n_seq][n_out] fp32.
+ * dec_prefix is shared by all sequences ([0] for yes_no, [0, "Passage"] for setwise likelihood).
+ * replaces: self.llm(input_ids, attention_mask, decoder_input_ids).logits[:, -1, ids]  (pointwise.py:117-121, setwise.py:184-186) */
+int rk_t5_score(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq,
+                const int32_t* dec_prefix, int dec_len, const int32_t* out_token_ids, int n_out, float* out_logits);
+/* out_scores[b] = -sum_t CE(logits[b,t,:], labels[t]) with decoder input = shift_right(labels).
+ * replaces: self.llm(input_ids, attention_mask, labels=...).logits + CrossEntropyLoss(reduction="none") (pointwise.py:73-79) */
+int rk_t5_qlm(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq,
+              const int32_t* labels, int n_labels, float* out_scores);
+/* Greedy continuation of dec_prefix by up to max_new tokens -> out_tokens[n_seq][max_new] (pad_id after EOS;
+ * stops early when every row has finished, remaining columns = pad_id); *out_steps = decoder steps executed.
+ * replaces: self.llm.generate(input_ids, decoder_input_ids=..., max_new_tokens=2)  (setwise.py:93-95, 128-130) */
+int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq,
+                 const int32_t* dec_prefix, int dec_len, int max_new, int eos_id, int pad_id,
+                 int32_t* out_tokens, int32_t* out_steps);
+
+/* ---- staged / asynchronous form: inputs resident in HBM, used by bench.py and the multi-GPU driver ---- */
+int rk_t5_stage(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq);   /* H2D, synchronous */
+/* enqueue encoder + decoder + head on the engine stream for the staged batch; scores land in an engine-owned
+ * device buffer and are copied to pinned host memory asynchronously. Returns without synchronising. */
+int rk_t5_score_staged(rk_engine* e, const int32_t* dec_prefix, int dec_len, const int32_t* out_token_ids, int n_out);
+int rk_engine_sync(rk_engine* e);
+int rk_t5_read_scores(rk_engine* e, float* out_logits, int n_floats);   /* after rk_engine_sync */
+/* device address of the fp32 score buffer [n_seq][n_out] of the last rk_t5_score_staged (for RCCL gathers) */
+int rk_t5_scores_device_ptr(rk_engine* e, void** out_ptr);
+
+/* ---- measurement (HIP events on the engine's own stream) ---- */
+int rk_timer_begin(rk_engine* e);                 /* record start event on the engine stream */
+int rk_timer_end(rk_engine* e, float* out_ms);    /* record stop, synchronise, elapsed ms */
+/* per-kernel-class profiling: when enabled every launch is bracketed by an event pair (perturbs throughput;
+ * use in a separate pass).  Classes are listed by rk_profile_class_name. */
+int rk_profile_enable(rk_engine* e, int on);
+int rk_profile_reset(rk_engine* e);
+int rk_profile_num_classes(void);
+const char* rk_profile_class_name(int cls);
+int rk_profile_get(rk_engine* e, int cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
+/* kernel variant switches for A/B measurements: key "gemm_glds" (1 = direct-to-LDS DMA staging, 0 = registers) */
+int rk_engine_set_option(rk_engine* e, const char* key, int value);
+
+/* ---- host-only helpers (no device needed) ---- */
+int rk_abi_version(void);
+/* T5 relative-position bucket (hf: modeling_t5.py:216-262) as used to build the device bias tables */
+int rk_rel_bucket(int relative_position, int bidirectional, int num_buckets, int max_distance);
+/* debug: run one GEMM through the engine's kernel on host data (A[M,K] fp16, W[N,K] fp16 -> C[M,N] fp32) */
+int rk_debug_gemm(rk_engine* e, const uint16_t* A, const uint16_t* W, float* C, int M, int N, int K, int use_glds);
+/* debug: copy an internal activation buffer to the host as fp32. name: "enc_hidden" [T,d], "enc_out" [T,d],
+ * "qkv" [T,3I], "ctx" [T,I], "dec_hidden" [B*Ld,d]. Returns number of floats written or a negative status. */
+int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RK_ENGINE_H */

@@ -1,0 +1,213 @@
+// T5 attention kernels for gfx950 (d_kv = 64 only; every public T5 up to xl uses 64).
+//
+// Semantics restated from hf: models/t5/modeling_t5.py:144-173 with scaling = 1.0 (:196-197):
+//   P = softmax(Q K^T + bias[h, bucket(j - i)] + mask),  ctx = P V
+// bias comes from block 0's table, shared by all layers of a stack (:739-742); cross-attention has zero bias
+// (:337-342).  Ragged batches: every sequence only ever sees its own keys, which equals HF's additive
+// finfo.min padding mask (exp underflows to exactly 0).
+#pragma once
+#include "common.h"
+
+struct AttnEncArgs {
+  const half_t* qkv;     // [T, ld]: q at column 0, k at column I, v at column 2I (output of the fused QKV GEMM)
+  half_t* ctx;           // [T, ldctx]
+  const int* seq_off;    // [B+1] token offsets of the packed batch
+  const float* bias_lut; // [H][RK_LUT_N]
+  int ld, ldctx, I;
+};
+
+// Flash-style encoder self-attention.  grid = (ceil(maxL/128), H, B), 256 threads = 4 waves x 32 queries.
+// Per 64-key tile: K tile row-major and V tile TRANSPOSED are staged in LDS;  S^T = K Q^T by MFMA 32x32x16
+// (A = K rows, B = Q^T) so each lane owns ONE query column: the running max / sum / rescale are per-lane
+// scalars and the fp16 P values are already in MFMA B-operand position for O^T = V^T P^T (A = V^T rows).
+// The k-slot <-> key assignment is the same permutation for P (B operand) and V^T (A operand), so no
+// cross-lane data movement is needed anywhere except one xor-32 shuffle for the row max and row sum.
+#define ATT_KSTR 72   // sK row stride in halfs (144 B: 16-B aligned, conflict-free b128 reads)
+#define ATT_VSTR 68   // sVt row stride in halfs (136 B: 8-B aligned, conflict-free b64 reads)
+
+__global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
+  __shared__ __attribute__((aligned(16))) half_t sK[64 * ATT_KSTR];
+  __shared__ __attribute__((aligned(16))) half_t sVt[64 * ATT_VSTR];
+  __shared__ float sLut[RK_LUT_N + 3];
+  const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+  const int tok0 = p.seq_off[b];
+  const int L = p.seq_off[b + 1] - tok0;
+  if (qt * 128 >= L) return;   // uniform for the whole block
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int hh = lane >> 5, l31 = lane & 31;
+  for (int i = tid; i < RK_LUT_N; i += 256) sLut[i] = p.bias_lut[h * RK_LUT_N + i];
+  const int q0 = qt * 128 + wave * 32;
+  const bool wave_active = q0 < L;
+  const int qpos = q0 + l31;
+  const int qrow = qpos < L ? qpos : L - 1;
+  half8 qf[4];
+  {
+    const half_t* qptr = p.qkv + (size_t)(tok0 + qrow) * p.ld + h * 64 + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const half8*)(qptr + 16 * s);
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+  const int nkt = (L + 63) >> 6;
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();   // previous tile fully consumed (first iteration: sLut visible)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 3, cc = c & 7;
+      int key = kt * 64 + row;
+      key = key < L ? key : L - 1;   // clamp to valid memory; masked below
+      const half_t* src = p.qkv + (size_t)(tok0 + key) * p.ld + p.I + h * 64 + cc * 8;
+      const half8 kv = *(const half8*)src;
+      const half8 vv = *(const half8*)(src + p.I);
+      *(half8*)(sK + row * ATT_KSTR + cc * 8) = kv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sVt[(cc * 8 + j) * ATT_VSTR + row] = vv[j];
+    }
+    __syncthreads();
+    if (wave_active) {
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const half8 k0 = *(const half8*)(sK + l31 * ATT_KSTR + 16 * s + 8 * hh);
+        const half8 k1 = *(const half8*)(sK + (32 + l31) * ATT_KSTR + 16 * s + 8 * hh);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+      }
+      float tmax = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key0 = kt * 64 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int key1 = key0 + 32;
+        int rel0 = key0 - qpos, rel1 = key1 - qpos;
+        rel0 = rel0 < -RK_LUT_R ? -RK_LUT_R : (rel0 > RK_LUT_R ? RK_LUT_R : rel0);
+        rel1 = rel1 < -RK_LUT_R ? -RK_LUT_R : (rel1 > RK_LUT_R ? RK_LUT_R : rel1);
+        s0[r] = key0 < L ? s0[r] + sLut[rel0 + RK_LUT_R] : -1e30f;
+        s1[r] = key1 < L ? s1[r] + sLut[rel1 + RK_LUT_R] : -1e30f;
+        tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __expf(m_run - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __expf(s0[r] - m_new);
+        s1[r] = __expf(s1[r] - m_new);
+        psum += s0[r] + s1[r];
+      }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          half8 pf;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) pf[i] = (half_t)(sub == 0 ? s0[8 * sp + i] : s1[8 * sp + i]);
+          const int kb = sub * 32 + 16 * sp + 4 * hh;   // keys kb..kb+3 and kb+8..kb+11 <-> regs 8sp..8sp+7
+          {
+            const half_t* vr = sVt + l31 * ATT_VSTR + kb;
+            const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
+            const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o0, 0, 0, 0);
+          }
+          {
+            const half_t* vr = sVt + (32 + l31) * ATT_VSTR + kb;
+            const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
+            const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o1, 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (wave_active && qpos < L) {
+    const float inv = 1.0f / l_run;
+    half_t* out = p.ctx + (size_t)(tok0 + qpos) * p.ldctx + h * 64;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int d = 8 * q + 4 * hh;
+      half4 a, c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = f2h_sat(o0[4 * q + j] * inv); c[j] = f2h_sat(o1[4 * q + j] * inv); }
+      *(half4*)(out + d) = a;
+      *(half4*)(out + 32 + d) = c;
+    }
+  }
+}
+
+// Small-query attention for the decoder (self: causal + unidirectional bias; cross: no bias, keys = encoder
+// states of the same sequence).  One wave per query row: lanes parallel over keys for the scores (q in
+// registers, 64 MACs per key in-lane), wave reductions for max / sum, lanes parallel over d for P V.
+// grid = (ceil(Lq/4), H, B), 256 threads; dynamic LDS = 4 * (64 + max_keys) floats.
+struct AttnDecArgs {
+  const half_t* q;  int ldq;     // query rows b*Lq + i, head columns h*64..
+  const half_t* k;  const half_t* v;  int ldkv;   // key/value rows key_off + j
+  const int* key_off;            // [B+1] (cross) or nullptr (self: keys are rows b*Lq .. b*Lq+Lq-1)
+  half_t* ctx;      int ldctx;   // out rows b*Lq + i
+  const float* bias_lut;         // [H][RK_LUT_N] or nullptr
+  int Lq, causal, max_keys;
+};
+
+__global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float dec_smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int i = blockIdx.x * 4 + wave;             // query position
+  const bool active = i < p.Lq;
+  float* sQ = dec_smem + wave * (64 + p.max_keys);
+  float* sP = sQ + 64;
+  int koff, Lk;
+  if (p.key_off) { koff = p.key_off[b]; Lk = p.key_off[b + 1] - koff; }
+  else { koff = b * p.Lq; Lk = p.Lq; }
+  const int qi = active ? i : 0;
+  const int nk = p.causal ? (qi + 1 < Lk ? qi + 1 : Lk) : Lk;   // keys 0..nk-1 are visible
+  const size_t qrow = (size_t)(b * p.Lq + qi);
+  sQ[lane] = (float)p.q[qrow * p.ldq + h * 64 + lane];
+  __syncthreads();
+  float qv[64];
+#pragma unroll
+  for (int d = 0; d < 64; d += 4) {
+    const f32x4 t = *(const f32x4*)(sQ + d);
+    qv[d] = t[0]; qv[d + 1] = t[1]; qv[d + 2] = t[2]; qv[d + 3] = t[3];
+  }
+  float mx = -1e30f;
+  for (int j = lane; j < nk; j += 64) {
+    const half_t* kr = p.k + (size_t)(koff + j) * p.ldkv + h * 64;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const half8 kk = *(const half8*)(kr + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += qv[c * 8 + e] * (float)kk[e];
+    }
+    if (p.bias_lut) {
+      int rel = j - qi;
+      rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
+      s += p.bias_lut[h * RK_LUT_N + rel + RK_LUT_R];
+    }
+    sP[j] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < nk; j += 64) {
+    const float e = __expf(sP[j] - mx);
+    sP[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float acc = 0.f;
+  const half_t* vb = p.v + (size_t)koff * p.ldkv + h * 64 + lane;
+  for (int j = 0; j < nk; ++j) acc += sP[j] * (float)vb[(size_t)j * p.ldkv];
+  if (active) p.ctx[qrow * p.ldctx + h * 64 + lane] = f2h_sat(acc / sum);
+}

@@ -1,0 +1,34 @@
+// Shared device-side types for the gfx950 (CDNA4, wave64) kernels of the reranking engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define RK_WAVE 64
+// Relative-position bias is looked up through a per-head table indexed by clamp(key-query, -RK_LUT_R, RK_LUT_R).
+// Every distance >= max_distance falls in the last bucket (hf: modeling_t5.py:216-262), so the table is exact
+// as long as max_distance <= RK_LUT_R (checked at engine creation).
+#define RK_LUT_R 128
+#define RK_LUT_N (2 * RK_LUT_R + 1)
+
+__device__ __forceinline__ half_t f2h_sat(float x) {
+  // fp16 saturation instead of inf (the reference's fp16 path clamps to finfo.max, hf: modeling_t5.py:467-474)
+  return (half_t)fminf(fmaxf(x, -65504.f), 65504.f);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}

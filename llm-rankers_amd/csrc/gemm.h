@@ -1,0 +1,193 @@
+// fp16 MFMA GEMM for gfx950:  C[m][n] (+)= sum_k A[m][k] * W[n][k]     (y = x W^T, nn.Linear without bias)
+//
+// Replaces the q/k/v/o and wi/wo Linear calls of hf: models/t5/modeling_t5.py:206-209, 106-123 that the
+// reference reaches through self.llm(...) (ref: llmrankers/pointwise.py:117-119).
+//
+// Design (CDNA4): 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile as 2x2 MFMA 32x32x16 f16
+// fragments with fp32 accumulators.  The WEIGHT tile is the MFMA A operand and the ACTIVATION tile the B
+// operand, so a lane's 4 consecutive accumulator registers are 4 consecutive output columns n of one row m
+// (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) -> 8/16-byte epilogue stores.
+// Both tiles are K-contiguous in memory and are staged into LDS as [128 rows][64 halfs] (128-B rows) with the
+// 16-B chunk index XOR-swizzled by (row>>1)&7, which makes every ds_read_b128 fragment read conflict-free
+// (a 256-B bank row holds two tile rows; rows 2j,2j+1 share a swizzle value but sit in different halves).
+// Staging is either direct-to-LDS DMA (global_load_lds_dwordx4; LDS image is lane-linear so the swizzle is
+// applied to the per-lane SOURCE address) or through registers; double-buffered, one barrier per K step.
+//
+// Epilogues fuse what follows the Linear in T5: fp32 residual add (o / wo projections), GEGLU
+// (gelu_new(wi_0 x) * wi_1 x with wi_0/wi_1 rows interleaved in groups of 32 by the weight packer), ReLU.
+#pragma once
+#include "common.h"
+
+enum GemmEpi { EPI_STORE_F16 = 0, EPI_RESID_F32 = 1, EPI_GEGLU_F16 = 2, EPI_RELU_F16 = 3, EPI_STORE_F32 = 4 };
+
+struct GemmArgs {
+  const half_t* A;   // [M, K] activations, row stride lda (halfs)
+  const half_t* W;   // [N, K] weights, row stride ldw
+  void* C;           // output, row stride ldc (elements of the output type)
+  int lda, ldw, ldc;
+  int M, N, K;
+  int n_split;       // >0: output column n goes to block n / n_split at C + block*split_stride, column n % n_split
+  long split_stride; // in elements
+  float scale;       // multiplies the accumulator (1.0 normally)
+};
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 64
+#define GEMM_TILE_HALFS (128 * 64)
+#define GEMM_LDS_BYTES (2 * 2 * GEMM_TILE_HALFS * 2)   // 2 stages x {A,W} x 16 KiB = 64 KiB
+
+__device__ __forceinline__ float gelu_new_f(float x) {
+  // hf: activations.py:59-66
+  const float c = 0.7978845608028654f;
+  float u = c * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+
+template <bool GLDS>
+__device__ __forceinline__ void gemm_stage_tile(half_t* s_tile, const half_t* g, int ld, int row0, int rows_total,
+                                                int k0, int wave, int lane, half8 (&regs)[4]) {
+  // tile = 1024 16-byte slots; slot p = (row r = p>>3, chunk c = p&7).  Wave w owns slots [w*256, w*256+256).
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = (wave * 4 + i) * 64 + lane;
+    const int r = p >> 3, c = p & 7;
+    int grow = row0 + r;
+    grow = grow < rows_total ? grow : rows_total - 1;   // clamp: rows beyond the matrix are never stored
+    if (GLDS) {
+      // LDS slot p receives global chunk c ^ f(r): the DMA writes lane-linear, so permute the source.
+      const half_t* src = g + (size_t)grow * ld + k0 + ((c ^ ((r >> 1) & 7)) << 3);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(s_tile + (wave * 4 + i) * 512),
+                                       16, 0, 0);
+    } else {
+      regs[i] = *(const half8*)(g + (size_t)grow * ld + k0 + (c << 3));
+    }
+  }
+}
+
+__device__ __forceinline__ void gemm_write_tile(half_t* s_tile, int wave, int lane, const half8 (&regs)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = (wave * 4 + i) * 64 + lane;
+    const int r = p >> 3, c = p & 7;
+    *(half8*)(s_tile + r * 64 + ((c ^ ((r >> 1) & 7)) << 3)) = regs[i];
+  }
+}
+
+__device__ __forceinline__ half8 gemm_frag(const half_t* s_tile, int r, int cc) {
+  return *(const half8*)(s_tile + r * 64 + ((cc ^ ((r >> 1) & 7)) << 3));
+}
+
+template <int EPI, bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+  half_t* smem = (half_t*)gemm_smem;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM;
+  const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+  const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / GEMM_BK;
+  half8 ra[4], rw[4];
+  // prologue: stage k-tile 0 into stage 0
+  gemm_stage_tile<GLDS>(smem, p.A, p.lda, m0, p.M, 0, wave, lane, ra);
+  gemm_stage_tile<GLDS>(smem + GEMM_TILE_HALFS, p.W, p.ldw, n0, p.N, 0, wave, lane, rw);
+  if (!GLDS) {
+    gemm_write_tile(smem, wave, lane, ra);
+    gemm_write_tile(smem + GEMM_TILE_HALFS, wave, lane, rw);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    half_t* sA = smem + (kt & 1) * 2 * GEMM_TILE_HALFS;
+    half_t* sW = sA + GEMM_TILE_HALFS;
+    half_t* nA = smem + ((kt + 1) & 1) * 2 * GEMM_TILE_HALFS;
+    half_t* nW = nA + GEMM_TILE_HALFS;
+    __syncthreads();   // stage kt landed (glds drained by the barrier's vmcnt(0)); stage kt^1 free to overwrite
+    const bool more = kt + 1 < nk;
+    if (more) {
+      gemm_stage_tile<GLDS>(nA, p.A, p.lda, m0, p.M, (kt + 1) * GEMM_BK, wave, lane, ra);
+      gemm_stage_tile<GLDS>(nW, p.W, p.ldw, n0, p.N, (kt + 1) * GEMM_BK, wave, lane, rw);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cc = ks * 2 + hh;
+      half8 wf[2], af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        wf[i] = gemm_frag(sW, wn * 64 + i * 32 + l31, cc);
+        af[i] = gemm_frag(sA, wm * 64 + i * 32 + l31, cc);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+    }
+    if (!GLDS && more) {
+      gemm_write_tile(nA, wave, lane, ra);
+      gemm_write_tile(nW, wave, lane, rw);
+    }
+  }
+
+  // ---- epilogue: lane holds row m = ..+l31 and, per register group q, 4 consecutive columns n ----
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m0 + wm * 64 + mi * 32 + l31;
+    if (m >= p.M) continue;
+    if (EPI == EPI_GEGLU_F16) {
+      // acc[0] = gate rows, acc[1] = up rows of the same 32 output columns
+      half_t* C = (half_t*)p.C;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = (n0 >> 1) + wn * 32 + 8 * q + 4 * hh;
+        if (col >= (p.N >> 1)) continue;
+        half4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          o[j] = f2h_sat(gelu_new_f(acc[0][mi][4 * q + j] * p.scale) * (acc[1][mi][4 * q + j] * p.scale));
+        *(half4*)(C + (size_t)m * p.ldc + col) = o;
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int n = n0 + wn * 64 + ni * 32 + 8 * q + 4 * hh;
+          if (n >= p.N) continue;
+          size_t base = 0;
+          if (p.n_split > 0) {
+            base = (size_t)(n / p.n_split) * (size_t)p.split_stride;
+            n = n % p.n_split;
+          }
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * q + j] * p.scale;
+          if (EPI == EPI_STORE_F16 || EPI == EPI_RELU_F16) {
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f2h_sat(EPI == EPI_RELU_F16 ? fmaxf(v[j], 0.f) : v[j]);
+            *(half4*)((half_t*)p.C + base + (size_t)m * p.ldc + n) = o;
+          } else if (EPI == EPI_RESID_F32) {
+            float* c = (float*)p.C + base + (size_t)m * p.ldc + n;
+            f32x4 old = *(f32x4*)c;
+            f32x4 o = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+            *(f32x4*)c = o;
+          } else {  // EPI_STORE_F32
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *(f32x4*)((float*)p.C + base + (size_t)m * p.ldc + n) = o;
+          }
+        }
+      }
+    }
+  }
+}

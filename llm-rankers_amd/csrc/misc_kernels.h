@@ -1,0 +1,129 @@
+// HBM-bound helper kernels (embedding gather, RMSNorm, head rows, argmax, cross-entropy) for gfx950.
+// One wave (64 lanes) per row, 16-byte vector accesses, shuffle reductions.
+#pragma once
+#include "common.h"
+
+// hf: modeling_t5.py:644,678 (embed_tokens): hidden[t][:] = (fp32) E[ids[t]][:]; no scaling, dropout = identity.
+__global__ __launch_bounds__(256) void embed_gather_kernel(const int* __restrict__ ids, const half_t* __restrict__ table,
+                                                           float* __restrict__ out, int n_rows, int d, int vocab) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // host validates; clamp keeps a bad id from faulting
+  const half_t* src = table + (size_t)id * d;
+  float* dst = out + (size_t)row * d;
+  for (int c = lane * 8; c < d; c += 64 * 8) {
+    const half8 v = *(const half8*)(src + c);
+    f32x4 a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    f32x4 b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+    *(f32x4*)(dst + c) = a;
+    *(f32x4*)(dst + c + 4) = b;
+  }
+}
+
+// hf: modeling_t5.py:59-72 (T5LayerNorm): y = w * x * rsqrt(mean(x^2) + eps); fp32 statistics, fp16 result
+// (the GEMM input).  row_map (optional) gathers source rows: out row r reads x row row_map[r].
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      half_t* __restrict__ out, const int* __restrict__ row_map,
+                                                      int n_rows, int d, float eps, float out_scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const float* src = x + (size_t)(row_map ? row_map[row] : row) * d;
+  float ss = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const f32x4 v = *(const f32x4*)(src + c);
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)d + eps) * out_scale;
+  half_t* dst = out + (size_t)row * d;
+  for (int c = lane * 4; c < d; c += 256) {
+    const f32x4 v = *(const f32x4*)(src + c);
+    const f32x4 g = *(const f32x4*)(w + c);
+    half4 o = {f2h_sat(v[0] * rs * g[0]), f2h_sat(v[1] * rs * g[1]), f2h_sat(v[2] * rs * g[2]),
+               f2h_sat(v[3] * rs * g[3])};
+    *(half4*)(dst + c) = o;
+  }
+}
+
+// Final-token logit extraction for the label / yes-no rows only (hf: modeling_t5.py:1044-1047 lm_head, but
+// just the n_out vocabulary rows the rankers read: ref pointwise.py:120-121, setwise.py:186).
+// out[b][j] = dot(x[b], head[out_ids[j]]); one wave per (b, j).
+__global__ __launch_bounds__(256) void head_rows_kernel(const half_t* __restrict__ x, const half_t* __restrict__ head,
+                                                        const int* __restrict__ out_ids, float* __restrict__ out,
+                                                        int n_seq, int n_out, int d) {
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (idx >= n_seq * n_out) return;
+  const int b = idx / n_out, j = idx % n_out;
+  const half_t* xr = x + (size_t)b * d;
+  const half_t* hr = head + (size_t)out_ids[j] * d;
+  float s = 0.f;
+  for (int c = lane * 8; c < d; c += 512) {
+    const half8 a = *(const half8*)(xr + c);
+    const half8 w = *(const half8*)(hr + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)w[e];
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[idx] = s;
+}
+
+// Greedy decoding step: first index of the row maximum (torch.argmax tie rule; hf: generation/utils.py greedy).
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, int ld, int n_cols,
+                                                          int* __restrict__ out) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int row = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* src = logits + (size_t)row * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = tid; c < n_cols; c += 256) {
+    const float v = src[c];
+    if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    out[row] = bi;
+  }
+}
+
+// QLM score (ref: pointwise.py:77-79): out[b] = -sum_t ( logsumexp(logits[b,t,:]) - logits[b,t,label_t] ).
+// One block per sequence; positions are summed in order (deterministic).
+__global__ __launch_bounds__(256) void qlm_ce_kernel(const float* __restrict__ logits, int ld, int n_cols,
+                                                     const int* __restrict__ labels, int n_pos,
+                                                     float* __restrict__ out) {
+  __shared__ float sred[4];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float total = 0.f;
+  for (int t = 0; t < n_pos; ++t) {
+    const float* src = logits + (size_t)(b * n_pos + t) * ld;
+    float mx = -INFINITY;
+    for (int c = tid; c < n_cols; c += 256) mx = fmaxf(mx, src[c]);
+    mx = wave_max(mx);
+    if (lane == 0) sred[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+    __syncthreads();
+    float se = 0.f;
+    for (int c = tid; c < n_cols; c += 256) se += expf(src[c] - mx);
+    se = wave_sum(se);
+    if (lane == 0) sred[wave] = se;
+    __syncthreads();
+    se = sred[0] + sred[1] + sred[2] + sred[3];
+    __syncthreads();
+    total += (mx + logf(se)) - src[labels[t]];
+  }
+  if (tid == 0) out[b] = -total;
+}

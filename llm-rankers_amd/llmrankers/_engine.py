@@ -1,0 +1,266 @@
+"""ctypes binding of librk_engine.so (C ABI: include/rk_engine.h).
+
+north_star asks for a "thin C-ABI cffi layer"; cffi is not installed in this image,
+so the same extern "C" surface is bound with the stdlib's ctypes.  There is no fallback: if the shared
+library is missing or no gfx950 device is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "librk_engine.so")
+
+RK_F32, RK_F16, RK_BF16 = 0, 1, 2
+
+
+class RkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rk_engine error {code}: {msg}")
+        self.code = code
+
+
+class RkModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab", "d_model", "n_heads", "d_kv", "d_ff", "n_enc_layers",
+                                         "n_dec_layers", "n_buckets", "max_distance", "gated_gelu", "tied_head")] + \
+               [("eps", C.c_float)] + [(n, C.c_int32) for n in ("max_tokens", "max_seqs", "max_dec_len")]
+
+
+# name -> (restype, argtypes); this table is also what tests check against include/rk_engine.h
+_P = C.POINTER
+_i32p, _f32p = _P(C.c_int32), _P(C.c_float)
+ABI = {
+    "rk_engine_create": (C.c_int, [_P(RkModelDesc), C.c_int, _P(C.c_void_p)]),
+    "rk_engine_destroy": (None, [C.c_void_p]),
+    "rk_last_error": (C.c_char_p, [C.c_void_p]),
+    "rk_engine_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, _P(C.c_int64), C.c_int]),
+    "rk_engine_finalize": (C.c_int, [C.c_void_p]),
+    "rk_t5_score": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _f32p]),
+    "rk_t5_qlm": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, _i32p, C.c_int, _f32p]),
+    "rk_t5_greedy": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
+    "rk_t5_stage": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int]),
+    "rk_t5_score_staged": (C.c_int, [C.c_void_p, _i32p, C.c_int, _i32p, C.c_int]),
+    "rk_engine_sync": (C.c_int, [C.c_void_p]),
+    "rk_t5_read_scores": (C.c_int, [C.c_void_p, _f32p, C.c_int]),
+    "rk_t5_scores_device_ptr": (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
+    "rk_timer_begin": (C.c_int, [C.c_void_p]),
+    "rk_timer_end": (C.c_int, [C.c_void_p, _f32p]),
+    "rk_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "rk_profile_reset": (C.c_int, [C.c_void_p]),
+    "rk_profile_num_classes": (C.c_int, []),
+    "rk_profile_class_name": (C.c_char_p, [C.c_int]),
+    "rk_profile_get": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_double), _P(C.c_int64), _P(C.c_double), _P(C.c_double)]),
+    "rk_engine_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "rk_abi_version": (C.c_int, []),
+    "rk_rel_bucket": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rk_debug_gemm": (C.c_int, [C.c_void_p, _P(C.c_uint16), _P(C.c_uint16), _f32p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rk_debug_read": (C.c_int64, [C.c_void_p, C.c_char_p, _f32p, C.c_int64]),
+}
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen librk_engine.so and attach prototypes. Raises if the in-tree build is missing (no fallback)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("RK_ENGINE_LIB", LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  If torch gets imported AFTER this library (e.g. via
+    # transformers' tokenizer), the process would hold two HIP runtimes; importing torch first lets the loader
+    # resolve our DT_NEEDED libamdhip64.so.7 to the copy already mapped.  Plumbing only — nothing here uses torch.
+    if os.environ.get("RK_IMPORT_TORCH_FIRST", "1") == "1":
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
+    if not os.path.exists(p):
+        raise FileNotFoundError(
+            f"{p} not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU/PyTorch fallback for the hot path.")
+    lib = C.CDLL(p)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)     # AttributeError here = the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def pack_ragged(seqs: Sequence[Sequence[int]]) -> Tuple[np.ndarray, np.ndarray]:
+    """list of token-id sequences -> (tokens[T] int32, seq_offsets[B+1] int32): the engine's input boundary."""
+    lens = [len(s) for s in seqs]
+    off = np.zeros(len(seqs) + 1, dtype=np.int32)
+    np.cumsum(lens, out=off[1:])
+    tok = np.concatenate([np.asarray(s, dtype=np.int32) for s in seqs]) if seqs else np.zeros(0, np.int32)
+    return np.ascontiguousarray(tok, dtype=np.int32), off
+
+
+class RkEngine:
+    """One engine = one MI355X.  Thin object wrapper; all compute happens in the HIP library."""
+
+    def __init__(self, dims, device: int = 0, max_tokens: int = 16384, max_seqs: int = 128, max_dec_len: int = 136):
+        self.lib = load_library()
+        self.dims = dims
+        self.desc = RkModelDesc(vocab=dims.vocab, d_model=dims.d_model, n_heads=dims.n_heads, d_kv=dims.d_kv,
+                                d_ff=dims.d_ff, n_enc_layers=dims.n_enc, n_dec_layers=dims.n_dec,
+                                n_buckets=dims.n_buckets, max_distance=dims.max_distance,
+                                gated_gelu=int(dims.gated), tied_head=int(dims.tied_head), eps=dims.eps,
+                                max_tokens=max_tokens, max_seqs=max_seqs, max_dec_len=max_dec_len)
+        h = C.c_void_p()
+        rc = self.lib.rk_engine_create(C.byref(self.desc), device, C.byref(h))
+        if rc != 0:
+            raise RkError(rc, (self.lib.rk_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+
+    # -- plumbing ------------------------------------------------------------------------------------
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise RkError(rc, (self.lib.rk_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rk_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights -------------------------------------------------------------------------------------
+    def load_tensor(self, name: str, arr: np.ndarray):
+        if arr.dtype == np.float16:
+            dt = RK_F16
+        elif arr.dtype == np.float32:
+            dt = RK_F32
+        elif arr.dtype == np.uint16:      # raw bf16 bits (safetensors bf16 viewed as uint16)
+            dt = RK_BF16
+        else:
+            arr, dt = arr.astype(np.float32), RK_F32
+        arr = np.ascontiguousarray(arr)
+        shape = (C.c_int64 * arr.ndim)(*arr.shape)
+        self._chk(self.lib.rk_engine_load_tensor(self.h, name.encode(), arr.ctypes.data_as(C.c_void_p), dt, shape, arr.ndim))
+
+    def load_state(self, tensors: Iterable[Tuple[str, np.ndarray]]):
+        for name, arr in tensors:
+            self.load_tensor(name, arr)
+        self._chk(self.lib.rk_engine_finalize(self.h))
+        return self
+
+    # -- the three call shapes of the hot path ----------------------------------------------------------
+    def score(self, seqs: Sequence[Sequence[int]], dec_prefix: Sequence[int], out_ids: Sequence[int]) -> np.ndarray:
+        tok, off = pack_ragged(seqs)
+        dp, oi = _i32(dec_prefix), _i32(out_ids)
+        out = np.empty((len(seqs), len(oi)), dtype=np.float32)
+        self._chk(self.lib.rk_t5_score(self.h, tok.ctypes.data_as(_i32p), off.ctypes.data_as(_i32p), len(seqs),
+                                       dp.ctypes.data_as(_i32p), len(dp), oi.ctypes.data_as(_i32p), len(oi),
+                                       out.ctypes.data_as(_f32p)))
+        return out
+
+    def qlm(self, seqs: Sequence[Sequence[int]], labels: Sequence[int]) -> np.ndarray:
+        tok, off = pack_ragged(seqs)
+        lab = _i32(labels)
+        out = np.empty(len(seqs), dtype=np.float32)
+        self._chk(self.lib.rk_t5_qlm(self.h, tok.ctypes.data_as(_i32p), off.ctypes.data_as(_i32p), len(seqs),
+                                     lab.ctypes.data_as(_i32p), len(lab), out.ctypes.data_as(_f32p)))
+        return out
+
+    def greedy(self, seqs: Sequence[Sequence[int]], dec_prefix: Sequence[int], max_new: int, eos_id: int = 1,
+               pad_id: int = 0) -> Tuple[np.ndarray, int]:
+        tok, off = pack_ragged(seqs)
+        dp = _i32(dec_prefix)
+        out = np.empty((len(seqs), max_new), dtype=np.int32)
+        steps = C.c_int32(0)
+        self._chk(self.lib.rk_t5_greedy(self.h, tok.ctypes.data_as(_i32p), off.ctypes.data_as(_i32p), len(seqs),
+                                        dp.ctypes.data_as(_i32p), len(dp), max_new, eos_id, pad_id,
+                                        out.ctypes.data_as(_i32p), C.byref(steps)))
+        return out, int(steps.value)
+
+    # -- staged / async form (bench, multi-GPU) --------------------------------------------------------
+    def stage(self, seqs: Sequence[Sequence[int]]):
+        tok, off = pack_ragged(seqs)
+        self._chk(self.lib.rk_t5_stage(self.h, tok.ctypes.data_as(_i32p), off.ctypes.data_as(_i32p), len(seqs)))
+        self._staged_n = len(seqs)
+
+    def score_staged(self, dec_prefix: Sequence[int], out_ids: Sequence[int]):
+        dp, oi = _i32(dec_prefix), _i32(out_ids)
+        self._last_n_out = len(oi)
+        self._chk(self.lib.rk_t5_score_staged(self.h, dp.ctypes.data_as(_i32p), len(dp), oi.ctypes.data_as(_i32p), len(oi)))
+
+    def sync(self):
+        self._chk(self.lib.rk_engine_sync(self.h))
+
+    def read_scores(self) -> np.ndarray:
+        out = np.empty((self._staged_n, self._last_n_out), dtype=np.float32)
+        self._chk(self.lib.rk_t5_read_scores(self.h, out.ctypes.data_as(_f32p), out.size))
+        return out
+
+    def scores_device_ptr(self) -> int:
+        p = C.c_void_p()
+        self._chk(self.lib.rk_t5_scores_device_ptr(self.h, C.byref(p)))
+        return int(p.value)
+
+    # -- measurement -------------------------------------------------------------------------------------
+    def timer_begin(self):
+        self._chk(self.lib.rk_timer_begin(self.h))
+
+    def timer_end(self) -> float:
+        ms = C.c_float(0)
+        self._chk(self.lib.rk_timer_end(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    def profile(self, on: bool):
+        self._chk(self.lib.rk_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._chk(self.lib.rk_profile_reset(self.h))
+
+    def profile_report(self) -> dict:
+        rep = {}
+        for c in range(self.lib.rk_profile_num_classes()):
+            ms, n, fl, by = C.c_double(0), C.c_int64(0), C.c_double(0), C.c_double(0)
+            self._chk(self.lib.rk_profile_get(self.h, c, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+            rep[self.lib.rk_profile_class_name(c).decode()] = {"ms": ms.value, "launches": n.value, "flops": fl.value,
+                                                              "bytes": by.value}
+        return rep
+
+    def set_option(self, key: str, value: int):
+        self._chk(self.lib.rk_engine_set_option(self.h, key.encode(), int(value)))
+
+    # -- debug ---------------------------------------------------------------------------------------------
+    def debug_gemm(self, a16: np.ndarray, w16: np.ndarray, use_glds: bool = True) -> np.ndarray:
+        a16 = np.ascontiguousarray(a16, dtype=np.float16)
+        w16 = np.ascontiguousarray(w16, dtype=np.float16)
+        m, k = a16.shape
+        n = w16.shape[0]
+        out = np.empty((m, n), dtype=np.float32)
+        self._chk(self.lib.rk_debug_gemm(self.h, a16.view(np.uint16).ctypes.data_as(_P(C.c_uint16)),
+                                         w16.view(np.uint16).ctypes.data_as(_P(C.c_uint16)),
+                                         out.ctypes.data_as(_f32p), m, n, k, int(use_glds)))
+        return out
+
+    def debug_read(self, name: str, n_floats: int) -> np.ndarray:
+        out = np.empty(n_floats, dtype=np.float32)
+        got = self.lib.rk_debug_read(self.h, name.encode(), out.ctypes.data_as(_f32p), n_floats)
+        if got < 0:
+            self._chk(int(got))
+        return out[:got]
+
+
+def rel_bucket(rel: int, bidirectional: bool, num_buckets: int = 32, max_distance: int = 128) -> int:
+    """The C++ restatement of hf: modeling_t5.py:216-262 that builds the device bias tables (host-only call)."""
+    return load_library().rk_rel_bucket(int(rel), int(bidirectional), num_buckets, max_distance)

@@ -155,17 +155,44 @@ def tensor_specs(d: T5Dims) -> Iterator[Tuple[str, Tuple[int, ...], float, bool]
         yield "lm_head.weight", (d.vocab, d.d_model), d.d_model ** -0.5, False
 
 
-def synth_tensors(d: T5Dims, seed: int = 929, gain: float = 1.0) -> Iterator[Tuple[str, np.ndarray]]:
-    """Yield (hf_name, fp32 array with fp16-representable values) one tensor at a time."""
-    for stream, (name, shape, std, is_norm) in enumerate(tensor_specs(d)):
-        n = int(np.prod(shape))
-        z = counter_normal(n, stream, seed)
+def _make_tensor(args):
+    stream, name, shape, std, is_norm, seed, gain = args
+    n = int(np.prod(shape))
+    out = np.empty(n, dtype=np.float32)
+    step = 1 << 22                      # chunked so peak memory stays small and threads interleave well
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.array([seed * 0x1000003 + stream], dtype=np.uint64))[0]
+    for s0 in range(0, n, step):
+        s1 = min(n, s0 + step)
+        with np.errstate(over="ignore"):
+            idx = np.arange(s0, s1, dtype=np.uint64)
+            a = _splitmix64(idx * np.uint64(2) + base)
+            b = _splitmix64(idx * np.uint64(2) + np.uint64(1) + base)
+        u1 = ((a >> np.uint64(11)).astype(np.float64) + 1.0) * (1.0 / 9007199254740993.0)
+        u2 = (b >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
         w = (1.0 + std * z) if is_norm else (gain if std < 1.0 else 1.0) * std * z
-        yield name, _fp16_round(w.astype(np.float32).reshape(shape))
+        out[s0:s1] = w.astype(np.float32)
+    return name, _fp16_round(out.reshape(shape))
 
 
-def synth_state_dict(d: T5Dims, seed: int = 929, gain: float = 1.0) -> Dict[str, np.ndarray]:
-    return dict(synth_tensors(d, seed, gain))
+def synth_tensors(d: T5Dims, seed: int = 929, gain: float = 1.0, threads: int = 0) -> Iterator[Tuple[str, np.ndarray]]:
+    """Yield (hf_name, fp32 array with fp16-representable values).  A pure function of (dims, seed, gain):
+    value i of tensor #s is Box-Muller(splitmix64 counters) — identical on every machine and thread count."""
+    jobs = [(stream, name, shape, std, is_norm, seed, gain)
+            for stream, (name, shape, std, is_norm) in enumerate(tensor_specs(d))]
+    if threads <= 1:
+        for j in jobs:
+            yield _make_tensor(j)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as ex:       # numpy ufuncs release the GIL
+        for res in ex.map(_make_tensor, jobs):
+            yield res
+
+
+def synth_state_dict(d: T5Dims, seed: int = 929, gain: float = 1.0, threads: int = 0) -> Dict[str, np.ndarray]:
+    return dict(synth_tensors(d, seed, gain, threads))
 
 
 def synth_token_batch(n_seq: int, min_len: int, max_len: int, vocab: int, seed: int):

@@ -1,0 +1,223 @@
+"""Setwise ranker on the MI355X engine: c-ary heapsort / bubblesort over an LLM "which passage is most relevant" call.
+
+Drop-in for ref: llmrankers/setwise.py:21-316 (SetwiseLlmRanker) — same constructor, `compare()` contract,
+counters, fallbacks for malformed model output and result assembly.  Each compare is one encoder pass over a
+single long prompt plus either two greedy decoder steps (`scoring='generation'`, engine call rk_t5_greedy) or
+one label-row read at decoder position 1 (`scoring='likelihood'`, rk_t5_score with the 23 label ids).
+Llama-family models (ref: setwise.py:60-69,159-177) are not built yet: NotImplementedError, as the reference
+raises for unknown model types.
+"""
+import copy
+import random
+from collections import Counter
+from typing import List
+
+import numpy as np
+
+from ._batching import tokenize_prompts
+from .rankers import LlmRanker, SearchResult
+
+random.seed(929)   # same import-time seeding as the reference (ref: setwise.py:18): permutation voting depends on it
+
+QUESTION = 'Given a query "{query}", which of the following passages is the most relevant one to the query?\n\n'
+INSTRUCTION = '\n\nOutput only the passage label of the most relevant passage:'
+
+
+class SetwiseLlmRanker(LlmRanker):
+    # "Passage X" / "Passage Y" tokenize into 3 tokens with the T5 vocabulary, hence 23 labels (ref: setwise.py:22-23)
+    CHARACTERS = ["A", "B", "C", "D", "E", "F", "G", "H", "I", "J", "K", "L",
+                  "M", "N", "O", "P", "Q", "R", "S", "T", "U", "V", "W"]
+
+    def __init__(self, model_name_or_path, tokenizer_name_or_path, device, num_child=3, k=10, scoring='generation',
+                 method="heapsort", num_permutation=1, cache_dir=None, _runtime=None, _tokenizer=None):
+        self.device = device
+        self.num_child = num_child
+        self.num_permutation = num_permutation
+        self.k = k
+        if _runtime is None:
+            from ._runtime import T5Runtime
+            try:
+                _runtime = T5Runtime(model_name_or_path, device)
+            except NotImplementedError as exc:   # same message shape as ref: setwise.py:71
+                raise NotImplementedError(f"{exc} (setwise)") from None
+        self.llm = _runtime
+        self.config = getattr(_runtime, "config", None)
+        if _tokenizer is None:
+            from transformers import T5Tokenizer
+            _tokenizer = T5Tokenizer.from_pretrained(
+                tokenizer_name_or_path if tokenizer_name_or_path is not None else model_name_or_path,
+                cache_dir=cache_dir)
+        self.tokenizer = _tokenizer
+        # decoder prompt "<pad> Passage" and the last token of "<pad> Passage {label}" (ref: setwise.py:51-59)
+        self.decoder_input_ids = self.tokenizer.encode("<pad> Passage", add_special_tokens=False)
+        self.target_token_ids = [self.tokenizer.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1]
+                                 for c in self.CHARACTERS]
+        self.scoring = scoring
+        self.method = method
+        self.total_compare = 0
+        self.total_completion_tokens = 0
+        self.total_prompt_tokens = 0
+
+    # ------------------------------------------------------------------------------------------------------
+    def _prompt(self, query: str, labels: List[str], texts: List[str]) -> str:
+        passages = "\n\n".join(f'Passage {lab}: "{txt}"' for lab, txt in zip(labels, texts))
+        return QUESTION.format(query=query) + passages + INSTRUCTION
+
+    def _generate(self, token_lists: List[List[int]]) -> List[List[int]]:
+        """Greedy, max_new_tokens=2, continuing "<pad> Passage".  Returns full output id rows the way
+        HF generate does: prefix + new tokens, all rows cut at the step where every row had finished."""
+        eos, pad = self.tokenizer.eos_token_id, self.tokenizer.pad_token_id
+        new = self.llm.greedy(token_lists, self.decoder_input_ids, 2, eos, pad)
+        out = []
+        for row in np.asarray(new):
+            out.append(list(self.decoder_input_ids) + [int(t) for t in row if t >= 0])
+        return out
+
+    def compare(self, query: str, docs: List):
+        # ref: setwise.py:79-198
+        self.total_compare += 1 if self.num_permutation == 1 else self.num_permutation
+        n = len(docs)
+        if self.scoring == 'generation':
+            if self.num_permutation == 1:
+                text = self._prompt(query, self.CHARACTERS[:n], [d.text for d in docs])
+                ids = tokenize_prompts(self.tokenizer, [text])
+                self.total_prompt_tokens += len(ids[0])
+                output_ids = self._generate(ids)[0]
+                self.total_completion_tokens += len(output_ids)
+                output = self.tokenizer.decode(output_ids, skip_special_tokens=True).strip()
+                output = output[-1]
+            else:
+                id_passage = [(i, p) for i, p in enumerate(docs)]
+                labels = [self.CHARACTERS[i] for i in range(n)]
+                perms = []
+                for _ in range(self.num_permutation):   # two draws per permutation, in this order (ref :107-109)
+                    perms.append([random.sample(id_passage, len(id_passage)), random.sample(labels, len(labels))])
+                refs, texts = [], []
+                for shuffled, chars in perms:
+                    refs.append(([p[0] for p in shuffled], list(chars)))
+                    texts.append(self._prompt(query, list(chars), [p[1].text for p in shuffled]))
+                ids = tokenize_prompts(self.tokenizer, texts)
+                # return_tensors="pt" without padding requires equal lengths; permuting passages keeps them equal
+                self.total_prompt_tokens += len(ids[0]) * len(ids)
+                rows = self._generate(ids)
+                plen = len(self.decoder_input_ids)
+                decoded = self.tokenizer.batch_decode([r[plen:] for r in rows], skip_special_tokens=True)
+                candidates = []
+                for (docids, chars), result in zip(refs, decoded):
+                    result = result.strip().upper()
+                    if len(result) != 1 or result not in chars:
+                        print(f"Unexpected output: {result}")
+                        continue
+                    candidates.append(docids[chars.index(result)])
+                if len(candidates) == 0:
+                    print(f"Unexpected voting: {decoded}")
+                    output = "Unexpected voting."
+                else:
+                    counts = Counter(candidates)
+                    top = max(counts.values())
+                    winners = [c for c, v in counts.items() if v == top]
+                    output = self.CHARACTERS[winners[0] if len(winners) == 1 else random.choice(winners)]
+        elif self.scoring == 'likelihood':
+            text = self._prompt(query, self.CHARACTERS[:n], [d.text for d in docs])
+            ids = tokenize_prompts(self.tokenizer, [text])
+            self.total_prompt_tokens += len(ids[0])
+            # softmax over the vocabulary is monotone, so the best label is the arg-max of the label logits;
+            # stable descending sort = first maximum wins (ref: setwise.py:184-188)
+            if n == 0:
+                raise IndexError("list index out of range")   # ranked[0] on an empty list in the reference (:188)
+            lg = self.llm.score(ids, self.decoder_input_ids, self.target_token_ids[:n])[0]
+            output = self.CHARACTERS[int(np.argmax(lg))]
+        else:
+            raise UnboundLocalError("local variable 'output' referenced before assignment")  # what the reference does
+
+        if not (len(output) == 1 and output in self.CHARACTERS):
+            print(f"Unexpected output: {output}")
+        return output
+
+    # ---- sort drivers: pure index logic, must reproduce the reference's comparisons exactly ---------------
+    def _pick(self, output: str) -> int:
+        try:
+            return self.CHARACTERS.index(output)
+        except ValueError:
+            return 0                              # malformed output -> first document wins (ref :206-209)
+
+    def heapify(self, arr, n, i, query):
+        # ref: setwise.py:200-217, written as a loop instead of tail recursion
+        c = self.num_child
+        while c * i + 1 < n:
+            hi = min(c * (i + 1) + 1, n)
+            inds = [i] + list(range(c * i + 1, hi))
+            best = self._pick(self.compare(query, [arr[j] for j in inds]))
+            largest = inds[best] if best < len(inds) else i   # label beyond the window keeps the parent (ref :210-213)
+            if largest == i:
+                return
+            arr[i], arr[largest] = arr[largest], arr[i]
+            i = largest
+
+    def heapSort(self, arr, query, k):
+        # ref: setwise.py:219-232
+        n = len(arr)
+        for i in range(n // self.num_child, -1, -1):
+            self.heapify(arr, n, i, query)
+        ranked = 0
+        for i in range(n - 1, 0, -1):
+            arr[i], arr[0] = arr[0], arr[i]
+            ranked += 1
+            if ranked == k:
+                break
+            self.heapify(arr, i, 0, query)
+
+    def _bubblesort(self, ranking, query):
+        # ref: setwise.py:243-273 — sliding window of num_child+1 bubbling the best document to position i,
+        # with the reference's `last_start` shortcut that skips windows already known to be in order.
+        c = self.num_child
+        full = len(ranking) - (c + 1)
+        last_start = full
+        for i in range(self.k):
+            start, end = last_start, last_start + (c + 1)
+            changed = False
+            while True:
+                if start < i:
+                    start = i
+                window = ranking[start:end]
+                best = self._pick(self.compare(query, window))
+                if best != 0:
+                    # no guard here in the reference either: an out-of-window label raises IndexError
+                    ranking[start], ranking[start + best] = ranking[start + best], ranking[start]
+                    if not changed:
+                        changed = True
+                        if last_start != full and best == len(window) - 1:
+                            last_start += len(window) - 1
+                if start == i:
+                    break
+                if not changed:
+                    last_start -= c
+                start -= c
+                end -= c
+
+    def rerank(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
+        # ref: setwise.py:234-313.  NB: like the reference, the caller's list is re-ordered in place.
+        original_ranking = copy.deepcopy(ranking)
+        self.total_compare = 0
+        self.total_completion_tokens = 0
+        self.total_prompt_tokens = 0
+        if self.method == "heapsort":
+            self.heapSort(ranking, query, self.k)
+            ranking = list(reversed(ranking))
+        elif self.method == "bubblesort":
+            self._bubblesort(ranking, query)
+        else:
+            raise NotImplementedError(f'Method {self.method} is not implemented.')
+        results, top_doc_ids, rank = [], set(), 1
+        for doc in ranking[:self.k]:
+            top_doc_ids.add(doc.docid)
+            results.append(SearchResult(docid=doc.docid, score=-rank, text=None))
+            rank += 1
+        for doc in original_ranking:
+            if doc.docid not in top_doc_ids:
+                results.append(SearchResult(docid=doc.docid, score=-rank, text=None))
+                rank += 1
+        return results
+
+    def truncate(self, text, length):
+        return self.tokenizer.convert_tokens_to_string(self.tokenizer.tokenize(text)[:length])

@@ -1,0 +1,194 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP kernels + C ABI vs the oracle and the HF goldens.
+
+Tolerances: the engine computes with fp16 MFMA inputs / fp32 accumulation / fp32 residual stream, the oracle in
+fp32.  north_star: logit scores within 1e-3 (fp16 tolerance) for pointwise -> asserted on the yes/no
+probability; raw logits of magnitude ~10 are allowed LOGIT_TOL."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, load_state
+
+pytestmark = pytest.mark.gpu
+SCORE_TOL = 1e-3
+LOGIT_TOL = 2e-2
+
+
+def _engine(dims, state, **kw):
+    from llmrankers._engine import RkEngine
+    kw.setdefault("max_tokens", 4096)
+    kw.setdefault("max_seqs", 64)
+    kw.setdefault("max_dec_len", 40)
+    return RkEngine(dims, device=0, **kw).load_state(state.items())
+
+
+def _sigm(d):
+    return 1.0 / (1.0 + np.exp(-d))
+
+
+@pytest.fixture(scope="module")
+def toy(ckpt_dirs):
+    out = {}
+    for name in ("ckpt_gated_untied", "ckpt_relu_tied"):
+        dims, state = load_state(ckpt_dirs[name])
+        out[name] = (dims, state, _engine(dims, state))
+    yield out
+    for _, _, e in out.values():
+        e.close()
+
+
+@pytest.mark.parametrize("glds", [True, False])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 192, 128), (70, 576, 192), (1, 4, 64), (333, 260, 1024),
+                                    (5888, 1024, 2816)])
+def test_gemm_vs_numpy(toy, shape, glds):
+    """C = A W^T with fp16 inputs, fp32 accumulate: exact products, only summation order differs."""
+    m, n, k = shape
+    rs = np.random.RandomState(m + n + k)
+    a = rs.standard_normal((m, k)).astype(np.float16)
+    w = rs.standard_normal((n, k)).astype(np.float16)
+    eng = toy["ckpt_gated_untied"][2]
+    got = eng.debug_gemm(a, w, use_glds=glds)
+    want = a.astype(np.float32) @ w.astype(np.float32).T
+    err = np.abs(got - want)
+    assert err.max() < 2e-3 * np.sqrt(k), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}; " \
+        f"bad rows {np.unique(np.where(err > 1e-2 * np.sqrt(k))[0])[:16]} bad cols {np.unique(np.where(err > 1e-2 * np.sqrt(k))[1])[:16]}"
+
+
+def test_encoder_stages_one_layer():
+    """1-layer model: every intermediate buffer vs the oracle (localises a wrong kernel)."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle, rmsnorm
+    dims = _synth.T5Dims(vocab=256, d_model=128, n_heads=3, d_kv=64, d_ff=256, n_enc=1, n_dec=1)
+    state = _synth.synth_state_dict(dims, seed=21, gain=2.0)
+    eng = _engine(dims, state)
+    orc = T5Oracle(dims, state)
+    seqs = _synth.synth_token_batch(5, 3, 200, dims.vocab, seed=3) + [np.array([7], dtype=np.int32)]
+    eng.score(seqs, [0], [5, 6])
+    T = sum(len(s) for s in seqs)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+    I, dm = dims.inner, dims.d_model
+    qkv = eng.debug_read("qkv", T * 3 * I).reshape(T, 3 * I)
+    ctx = eng.debug_read("ctx", T * I).reshape(T, I)
+    hid = eng.debug_read("enc_hidden", T * dm).reshape(T, dm)
+    enc_out = eng.debug_read("enc_out", T * dm).reshape(T, dm)
+    for b, ids in enumerate(seqs):
+        orc.capture = {}
+        orc.encode(ids)
+        h0 = orc.capture["enc.embed"]
+        x = rmsnorm(h0, state["encoder.block.0.layer.0.layer_norm.weight"], dims.eps)
+        p = "encoder.block.0.layer.0.SelfAttention."
+        want_qkv = np.concatenate([x @ state[p + m + ".weight"].T for m in "qkv"], axis=1)
+        sl = slice(off[b], off[b + 1])
+        np.testing.assert_allclose(qkv[sl], want_qkv, atol=3e-2, rtol=2e-3, err_msg=f"qkv seq {b}")
+        L = len(ids)
+        q, k, v = (want_qkv[:, i * I:(i + 1) * I].reshape(L, dims.n_heads, 64).transpose(1, 0, 2) for i in range(3))
+        s = q @ k.transpose(0, 2, 1) + orc.capture["enc.bias"]
+        pr = np.exp(s - s.max(-1, keepdims=True))
+        pr /= pr.sum(-1, keepdims=True)
+        want_ctx = (pr @ v).transpose(1, 0, 2).reshape(L, I)
+        np.testing.assert_allclose(ctx[sl], want_ctx, atol=3e-2, rtol=5e-3, err_msg=f"ctx seq {b} (len {L})")
+        np.testing.assert_allclose(hid[sl], orc.capture["enc.0.ffn"], atol=6e-2, rtol=5e-3, err_msg=f"hidden seq {b}")
+        np.testing.assert_allclose(enc_out[sl], orc.capture["enc.final"], atol=3e-2, rtol=5e-3, err_msg=f"enc_out seq {b}")
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["gated_untied", "relu_tied"])
+def test_toy_logits_vs_hf_goldens(toy, name):
+    dims, state, eng = toy["ckpt_" + name]
+    g = np.load(os.path.join(GOLD, f"model_{name}.npz"))
+    seqs = [g["input_ids"][b, :n].astype(np.int32) for b, n in enumerate(g["lens"])]
+    for tag in ("d1", "d2", "d5"):
+        dec = g[f"{tag}.dec_ids"].tolist()
+        want = g[f"{tag}.logits"][:, -1, :]
+        got = np.concatenate([eng.score(seqs, dec, list(range(c, c + 64))) for c in range(0, dims.vocab, 64)], axis=1)
+        err = np.abs(got - want)
+        assert err.max() < LOGIT_TOL, f"{tag}: max logit err {err.max():.4f} (mean {err.mean():.5f})"
+        # pointwise-style probability between two arbitrary vocabulary rows
+        assert np.abs(_sigm(got[:, 10] - got[:, 20]) - _sigm(want[:, 10] - want[:, 20])).max() < SCORE_TOL
+
+
+@pytest.mark.parametrize("name", ["gated_untied", "relu_tied"])
+def test_toy_qlm_and_greedy_vs_hf_goldens(toy, name):
+    dims, state, eng = toy["ckpt_" + name]
+    g = np.load(os.path.join(GOLD, f"model_{name}.npz"))
+    seqs = [g["input_ids"][b, :n].astype(np.int32) for b, n in enumerate(g["lens"])]
+    labels = g["qlm.labels"]
+    lg = g["qlm.logits"].astype(np.float64)
+    m = lg.max(-1, keepdims=True)
+    lse = (m + np.log(np.exp(lg - m).sum(-1, keepdims=True)))[..., 0]
+    want = -(lse - np.take_along_axis(lg, labels[None, :, None].repeat(len(seqs), 0), -1)[..., 0]).sum(-1)
+    got = eng.qlm(seqs, labels.tolist())
+    assert np.abs(got - want).max() < 5e-2, (got, want)          # sum of 6 log-probs of magnitude ~5 each
+    prefix = g["gen.prefix"].tolist()
+    toks, steps = eng.greedy(seqs, prefix, 2)
+    gen = g["gen.output_ids"]
+    assert steps == gen.shape[1] - len(prefix)
+    np.testing.assert_array_equal(toks[:, :steps], gen[:, len(prefix):])
+    for b, s in enumerate(json.loads(bytes(g["gen.single_json"]).decode())):   # the reference's B=1 call shape
+        t1, st1 = eng.greedy([seqs[b]], prefix, 2)
+        assert t1[0, :st1].tolist() == s[len(prefix):]
+
+
+def test_config1_flan_t5_small_vs_hf_golden():
+    """BASELINE.json configs[0]: flan-t5-small shape, pointwise yes_no, hits=20, batch_size=4 — HF CPU logits."""
+    from llmrankers import _synth
+    g = np.load(os.path.join(GOLD, "config1_flan_t5_small.npz"))
+    dims = _synth.FLAN_T5_SMALL
+    eng = _engine(dims, _synth.synth_state_dict(dims, seed=int(g["seed"]), threads=8), max_tokens=2048, max_seqs=8, max_dec_len=4)
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    seqs = [g["tokens"][off[i]:off[i + 1]].astype(np.int32) for i in range(len(g["lens"]))]
+    ids = g["yes_no_ids"].tolist()
+    got = np.concatenate([eng.score(seqs[s:s + 4], [0], ids) for s in range(0, 20, 4)], axis=0)
+    want = g["logits"]
+    assert np.abs(got - want).max() < LOGIT_TOL, np.abs(got - want).max()
+    p_got, p_want = _sigm(got[:, 0] - got[:, 1]), _sigm(want[:, 0] - want[:, 1])
+    assert np.abs(p_got - p_want).max() < SCORE_TOL, np.abs(p_got - p_want).max()
+    assert np.array_equal(np.argsort(-p_got, kind="stable"), np.argsort(-p_want, kind="stable")) or \
+        np.abs(np.sort(p_want)[1:] - np.sort(p_want)[:-1]).min() < 2 * SCORE_TOL
+    # one whole call of 20 ragged passages == five calls of 4 (batch composition cannot matter)
+    np.testing.assert_array_equal(eng.score(seqs, [0], ids), got)
+    eng.close()
+
+
+def test_flan_t5_large_dims_vs_oracle_and_properties():
+    """BASELINE.json configs[1] model shape: a few sequences vs the fp32 oracle, then size-independent
+    properties on the full B=32 x L=184 batch (batch independence, permutation equivariance)."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle
+    dims = _synth.FLAN_T5_LARGE
+    state = _synth.synth_state_dict(dims, seed=929, threads=16)
+    eng = _engine(dims, state, max_tokens=8192, max_seqs=32, max_dec_len=4)
+    batch = _synth.synth_token_batch(32, 184, 184, dims.vocab, seed=929)
+    ragged = _synth.synth_token_batch(3, 20, 184, dims.vocab, seed=930)
+    ids = [2163, 465]
+    got_r = eng.score(ragged, [0], ids)
+    want_r = T5Oracle(dims, state).score_last(ragged, [0], ids)
+    p_got, p_want = _sigm(got_r[:, 0] - got_r[:, 1]), _sigm(want_r[:, 0] - want_r[:, 1])
+    assert np.abs(p_got - p_want).max() < SCORE_TOL, (got_r, want_r)
+    full = eng.score(batch, [0], ids)
+    assert np.isfinite(full).all()
+    perm = np.random.RandomState(1).permutation(32)
+    np.testing.assert_array_equal(eng.score([batch[i] for i in perm], [0], ids), full[perm])
+    np.testing.assert_array_equal(eng.score(batch[5:9], [0], ids), full[5:9])
+    glds_off = None
+    eng.set_option("gemm_glds", 0)
+    glds_off = eng.score(batch, [0], ids)
+    eng.set_option("gemm_glds", 1)
+    np.testing.assert_array_equal(glds_off, full)        # both staging variants run the same arithmetic
+    eng.close()
+
+
+def test_capacity_and_argument_errors(toy):
+    from llmrankers._engine import RkError
+    dims, state, eng = toy["ckpt_gated_untied"]
+    with pytest.raises(RkError):
+        eng.score([[5, 1]] * 100, [0], [3])                 # > max_seqs
+    with pytest.raises(RkError):
+        eng.score([[5, 999, 1]], [0], [3])                  # token id out of range
+    with pytest.raises(RkError):
+        eng.score([[5, 1], []], [0], [3])                   # empty sequence
+    with pytest.raises(RkError):
+        eng.score([[5, 1]], [0] * 100, [3])                 # decoder prefix beyond max_dec_len
+    assert np.isfinite(eng.score([[5, 1]], [0], [3])).all()   # engine still usable after errors

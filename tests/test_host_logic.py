@@ -1,0 +1,142 @@
+"""Host logic of the drop-in rankers vs goldens recorded from the REAL reference (tools/make_goldens.py).
+
+CPU only: the model is the oracle-backed stub (tests/_stub.py) so what is under test here is prompting,
+tokenise-then-batch, counters, score extraction, sort drivers, fallbacks and result assembly
+(ref: llmrankers/pointwise.py:36-133, llmrankers/setwise.py:79-316).  The same cases run against the HIP
+engine in tests/test_gpu_rerank.py."""
+import contextlib
+import io
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, load_state
+from _stub import OracleRuntime
+from llmrankers.rankers import SearchResult, LlmRanker
+from llmrankers.pointwise import PointwiseLlmRanker, MonoT5LlmRanker
+from llmrankers.setwise import SetwiseLlmRanker
+
+
+@pytest.fixture(scope="module")
+def cases():
+    with open(os.path.join(GOLD, "rerank_cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def runtimes(ckpt_dirs):
+    from transformers import T5Tokenizer
+    out = {}
+    for name, path in ckpt_dirs.items():
+        dims, state = load_state(path)
+        out[name] = (OracleRuntime(dims, state), T5Tokenizer.from_pretrained(path))
+    return out
+
+
+def build_ranker(case, rt, tok):
+    if case["kind"] == "pointwise":
+        return PointwiseLlmRanker(None, None, "cuda", method=case["method"], batch_size=case["batch_size"],
+                                  _runtime=rt, _tokenizer=tok)
+    return SetwiseLlmRanker(None, None, "cuda", num_child=case["num_child"], k=case["k"], scoring=case["scoring"],
+                            method=case["method"], num_permutation=case["num_permutation"], _runtime=rt, _tokenizer=tok)
+
+
+def check_case(case, ranker, score_tol):
+    ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+    random.seed(929)
+    sink = io.StringIO()
+    if case.get("raises"):
+        with pytest.raises(IndexError), contextlib.redirect_stdout(sink):
+            ranker.rerank(case["query"], ranking)
+        return
+    with contextlib.redirect_stdout(sink):
+        res = ranker.rerank(case["query"], ranking)
+    want = case["result"]
+    assert [r.docid for r in res] == [d for d, _ in want]
+    if case["kind"] == "pointwise":
+        np.testing.assert_allclose([r.score for r in res], [s for _, s in want], atol=score_tol, rtol=score_tol)
+        assert all(a is b for a, b in zip(sorted(res, key=id), sorted(ranking, key=id)))   # same objects, mutated in place
+    else:
+        assert [r.score for r in res] == [s for _, s in want]
+        assert all(r.text is None for r in res)
+        assert [r.docid for r in ranking] == case["caller_list_after"]
+    assert [ranker.total_compare, ranker.total_prompt_tokens, ranker.total_completion_tokens] == case["counters"]
+
+
+def test_all_reference_cases_cpu(cases, runtimes):
+    assert len(cases["cases"]) >= 30
+    for case in cases["cases"]:
+        rt, tok = runtimes[case["ckpt"]]
+        check_case(case, build_ranker(case, rt, tok), score_tol=2e-5)
+
+
+def test_truncate(cases, runtimes):
+    rt, tok = runtimes["ckpt_gated_untied"]
+    pw = PointwiseLlmRanker(None, None, "cuda", method="yes_no", batch_size=2, _runtime=rt, _tokenizer=tok)
+    sw = SetwiseLlmRanker(None, None, "cuda", _runtime=rt, _tokenizer=tok)
+    for text, n, want in cases["truncate"]:
+        assert pw.truncate(text, n) == want
+        assert sw.truncate(text, n) == want
+
+
+def test_sort_drivers_match_reference_traces():
+    """Reference heapsort/bubblesort (incl. malformed-output fallbacks) replayed with the recorded comparator."""
+    with open(os.path.join(GOLD, "sort_traces.json")) as f:
+        traces = json.load(f)
+    assert len(traces) == 28
+    for tr in traces:
+        rk = SetwiseLlmRanker.__new__(SetwiseLlmRanker)
+        rk.num_child, rk.k, rk.method, rk.num_permutation = tr["c"], tr["k"], tr["method"], 1
+        rel, calls = tr["rel"], []
+
+        def fake(query, docs, _rel=rel, _calls=calls, _mode=tr["mode"], _rk=rk):
+            _rk.total_compare += 1
+            idx = [int(d.docid[1:]) for d in docs]
+            _calls.append(idx)
+            if not idx:
+                return "A"
+            best = max(range(len(docs)), key=lambda j: _rel[idx[j]])
+            if _mode == "garbage" and len(_calls) % 3 == 0:
+                return ["?", "Z", "zz"][len(_calls) % 9 // 3]
+            if _mode == "garbage" and len(_calls) % 7 == 0 and _rk.method == "heapsort":
+                return "W"
+            return SetwiseLlmRanker.CHARACTERS[best]
+
+        rk.compare = fake
+        n = tr["n"]
+        ranking = [SearchResult(docid=f"d{i}", score=float(n - i), text=f"t{i}") for i in range(n)]
+        res = rk.rerank("q", ranking)
+        assert calls == tr["calls"], (tr["n"], tr["c"], tr["k"], tr["method"], tr["mode"])
+        assert [[r.docid, r.score] for r in res] == tr["result"]
+        assert [r.docid for r in ranking] == tr["caller_list_after"]
+        assert rk.total_compare == tr["total_compare"]
+
+
+def test_api_surface():
+    import dataclasses
+    import inspect
+    assert [f.name for f in dataclasses.fields(SearchResult)] == ["docid", "score", "text"]
+    assert list(inspect.signature(PointwiseLlmRanker.__init__).parameters)[:7] == [
+        "self", "model_name_or_path", "tokenizer_name_or_path", "device", "method", "batch_size", "cache_dir"]
+    sig = inspect.signature(SetwiseLlmRanker.__init__)
+    assert list(sig.parameters)[:10] == ["self", "model_name_or_path", "tokenizer_name_or_path", "device", "num_child",
+                                         "k", "scoring", "method", "num_permutation", "cache_dir"]
+    assert (sig.parameters["num_child"].default, sig.parameters["k"].default, sig.parameters["scoring"].default,
+            sig.parameters["method"].default, sig.parameters["num_permutation"].default) == (3, 10, "generation", "heapsort", 1)
+    assert len(SetwiseLlmRanker.CHARACTERS) == 23
+    assert issubclass(MonoT5LlmRanker, PointwiseLlmRanker) and issubclass(SetwiseLlmRanker, LlmRanker)
+    with pytest.raises(NotImplementedError):
+        LlmRanker().rerank("q", [])
+
+
+def test_unknown_sort_method_and_cpu_device(runtimes, ckpt_dirs):
+    rt, tok = runtimes["ckpt_gated_untied"]
+    sw = SetwiseLlmRanker(None, None, "cuda", method="quicksort", _runtime=rt, _tokenizer=tok)
+    with pytest.raises(NotImplementedError):
+        sw.rerank("q", [SearchResult("a", 1.0, "x"), SearchResult("b", 0.5, "y")])
+    # no silent CPU fallback in the product path: device='cpu' must fail loudly
+    with pytest.raises((RuntimeError, FileNotFoundError)):
+        PointwiseLlmRanker(ckpt_dirs["ckpt_gated_untied"], None, "cpu", method="yes_no", batch_size=2)
