@@ -144,10 +144,11 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
   }
 }
 
-// Small-query attention for the decoder (self: causal + unidirectional bias; cross: no bias, keys = encoder
-// states of the same sequence).  One wave per query row: lanes parallel over keys for the scores (q in
-// registers, 64 MACs per key in-lane), wave reductions for max / sum, lanes parallel over d for P V.
-// grid = (ceil(Lq/4), H, B), 256 threads; dynamic LDS = 4 * (64 + max_keys) floats.
+// Decoder attention (self: causal + unidirectional bias; cross: zero bias, keys = encoder states of the same
+// sequence).  One 256-thread workgroup per (query position, head, sequence): threads parallel over keys for the
+// scores (q broadcast from LDS, 64 MACs per key in-lane), block reductions for max / sum, then the 4 waves split the
+// keys for P V with lanes parallel over d, combined through LDS in a fixed order (bitwise reproducible).
+// grid = (Lq, H, B); dynamic LDS = (64 + 4*64 + 8 + max_keys) floats.
 struct AttnDecArgs {
   const half_t* q;  int ldq;     // query rows b*Lq + i, head columns h*64..
   const half_t* k;  const half_t* v;  int ldkv;   // key/value rows key_off + j
@@ -159,38 +160,32 @@ struct AttnDecArgs {
 
 __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
   extern __shared__ __attribute__((aligned(16))) float dec_smem[];
+  float* sQ = dec_smem;            // [64]
+  float* sPart = sQ + 64;          // [4][64]
+  float* sRed = sPart + 256;       // [8]
+  float* sP = sRed + 8;            // [max_keys]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int i = blockIdx.x * 4 + wave;             // query position
-  const bool active = i < p.Lq;
-  float* sQ = dec_smem + wave * (64 + p.max_keys);
-  float* sP = sQ + 64;
+  const int b = blockIdx.z, h = blockIdx.y, i = blockIdx.x;
   int koff, Lk;
   if (p.key_off) { koff = p.key_off[b]; Lk = p.key_off[b + 1] - koff; }
   else { koff = b * p.Lq; Lk = p.Lq; }
-  const int qi = active ? i : 0;
-  const int nk = p.causal ? (qi + 1 < Lk ? qi + 1 : Lk) : Lk;   // keys 0..nk-1 are visible
-  const size_t qrow = (size_t)(b * p.Lq + qi);
-  sQ[lane] = (float)p.q[qrow * p.ldq + h * 64 + lane];
+  const int nk = p.causal ? (i + 1 < Lk ? i + 1 : Lk) : Lk;   // keys 0..nk-1 are visible
+  const size_t qrow = (size_t)(b * p.Lq + i);
+  if (tid < 64) sQ[tid] = (float)p.q[qrow * p.ldq + h * 64 + tid];
   __syncthreads();
-  float qv[64];
-#pragma unroll
-  for (int d = 0; d < 64; d += 4) {
-    const f32x4 t = *(const f32x4*)(sQ + d);
-    qv[d] = t[0]; qv[d + 1] = t[1]; qv[d + 2] = t[2]; qv[d + 3] = t[3];
-  }
   float mx = -1e30f;
-  for (int j = lane; j < nk; j += 64) {
+  for (int j = tid; j < nk; j += 256) {
     const half_t* kr = p.k + (size_t)(koff + j) * p.ldkv + h * 64;
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const half8 kk = *(const half8*)(kr + c * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += qv[c * 8 + e] * (float)kk[e];
+      const f32x4 q0 = *(const f32x4*)(sQ + c * 8), q1 = *(const f32x4*)(sQ + c * 8 + 4);
+      s += q0[0] * (float)kk[0] + q0[1] * (float)kk[1] + q0[2] * (float)kk[2] + q0[3] * (float)kk[3] +
+           q1[0] * (float)kk[4] + q1[1] * (float)kk[5] + q1[2] * (float)kk[6] + q1[3] * (float)kk[7];
     }
     if (p.bias_lut) {
-      int rel = j - qi;
+      int rel = j - i;
       rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
       s += p.bias_lut[h * RK_LUT_N + rel + RK_LUT_R];
     }
@@ -198,16 +193,34 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
     mx = fmaxf(mx, s);
   }
   mx = wave_max(mx);
+  if (lane == 0) sRed[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
   float sum = 0.f;
-  for (int j = lane; j < nk; j += 64) {
+  for (int j = tid; j < nk; j += 256) {
     const float e = __expf(sP[j] - mx);
     sP[j] = e;
     sum += e;
   }
   sum = wave_sum(sum);
+  if (lane == 0) sRed[4 + wave] = sum;
   __syncthreads();
-  float acc = 0.f;
+  sum = (sRed[4] + sRed[5]) + (sRed[6] + sRed[7]);
+  // P V: wave w takes keys w, w+4, ...; lane = d
   const half_t* vb = p.v + (size_t)koff * p.ldkv + h * 64 + lane;
-  for (int j = 0; j < nk; ++j) acc += sP[j] * (float)vb[(size_t)j * p.ldkv];
-  if (active) p.ctx[qrow * p.ldctx + h * 64 + lane] = f2h_sat(acc / sum);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int j = wave;
+  for (; j + 12 < nk; j += 16) {
+    a0 += sP[j] * (float)vb[(size_t)j * p.ldkv];
+    a1 += sP[j + 4] * (float)vb[(size_t)(j + 4) * p.ldkv];
+    a2 += sP[j + 8] * (float)vb[(size_t)(j + 8) * p.ldkv];
+    a3 += sP[j + 12] * (float)vb[(size_t)(j + 12) * p.ldkv];
+  }
+  for (; j < nk; j += 4) a0 += sP[j] * (float)vb[(size_t)j * p.ldkv];
+  sPart[wave * 64 + lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wave == 0) {
+    const float acc = (sPart[lane] + sPart[64 + lane]) + (sPart[128 + lane] + sPart[192 + lane]);
+    p.ctx[qrow * p.ldctx + h * 64 + lane] = f2h_sat(acc / sum);
+  }
 }

@@ -79,6 +79,63 @@ __device__ __forceinline__ half8 gemm_frag(const half_t* s_tile, int r, int cc) 
   return *(const half8*)(s_tile + r * 64 + ((cc ^ ((r >> 1) & 7)) << 3));
 }
 
+// Epilogue shared by the tiled and the skinny kernel.  acc[ni][mi] are 32x32 MFMA C fragments of a 64(n) x 64(m)
+// wave tile at (mbase, nbase); valid_mi/valid_ni limit the fragments a caller actually computed.
+// The lane holds row m = mbase + mi*32 + l31 and, per register group q, 4 consecutive columns n.
+template <int EPI, int NI = 2, int MI = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase, int l31, int hh) {
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = mbase + mi * 32 + l31;
+    if (m >= p.M) continue;
+    if (EPI == EPI_GEGLU_F16) {
+      // acc[0] = gate rows, acc[1] = up rows of the same 32 output columns
+      half_t* C = (half_t*)p.C;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = (nbase >> 1) + 8 * q + 4 * hh;
+        if (col >= (p.N >> 1)) continue;
+        half4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          o[j] = f2h_sat(gelu_new_f(acc[0][mi][4 * q + j] * p.scale) * (acc[NI - 1][mi][4 * q + j] * p.scale));
+        *(half4*)(C + (size_t)m * p.ldc + col) = o;
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int n = nbase + ni * 32 + 8 * q + 4 * hh;
+          if (n >= p.N) continue;
+          size_t base = 0;
+          if (p.n_split > 0) {
+            base = (size_t)(n / p.n_split) * (size_t)p.split_stride;
+            n = n % p.n_split;
+          }
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * q + j] * p.scale;
+          if (EPI == EPI_STORE_F16 || EPI == EPI_RELU_F16) {
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f2h_sat(EPI == EPI_RELU_F16 ? fmaxf(v[j], 0.f) : v[j]);
+            *(half4*)((half_t*)p.C + base + (size_t)m * p.ldc + n) = o;
+          } else if (EPI == EPI_RESID_F32) {
+            float* c = (float*)p.C + base + (size_t)m * p.ldc + n;
+            f32x4 old = *(f32x4*)c;
+            f32x4 o = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+            *(f32x4*)c = o;
+          } else {  // EPI_STORE_F32
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *(f32x4*)((float*)p.C + base + (size_t)m * p.ldc + n) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
@@ -139,55 +196,60 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
     }
   }
 
-  // ---- epilogue: lane holds row m = ..+l31 and, per register group q, 4 consecutive columns n ----
+  gemm_epilogue<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, l31, hh);
+}
+
+// ---- skinny GEMM: M <= 32 rows (the single-step decoder: M = sequences in the batch) ----------------------------
+// Weight-streaming regime: every weight element is used once, so there is no LDS staging of W at all.  One workgroup
+// owns NT consecutive 32-row weight tiles (NT = 2 for GEGLU: gate + up); its 4 waves split K four ways, each wave
+// streams its weight rows straight from HBM into MFMA A fragments (16 B per lane) and reads the tiny activation
+// matrix (L2-resident) as the B fragment; partial accumulators are combined through LDS in a FIXED order (bitwise
+// reproducible, unlike an atomic split-K).  grid = ceil(N / (32*NT)).
+template <int EPI, int NT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
+  __shared__ float red[3 * NT * 1024];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int n0 = blockIdx.x * 32 * NT;
+  const int kq = p.K >> 2;               // K % 64 == 0 -> kq % 16 == 0
+  const int kb = wave * kq;
+  int m = l31 < p.M ? l31 : p.M - 1;
+  const half_t* arow = p.A + (size_t)m * p.lda + kb + 8 * hh;
+  const half_t* wrow[NT];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = m0 + wm * 64 + mi * 32 + l31;
-    if (m >= p.M) continue;
-    if (EPI == EPI_GEGLU_F16) {
-      // acc[0] = gate rows, acc[1] = up rows of the same 32 output columns
-      half_t* C = (half_t*)p.C;
+  for (int t = 0; t < NT; ++t) {
+    int n = n0 + t * 32 + l31;
+    n = n < p.N ? n : p.N - 1;
+    wrow[t] = p.W + (size_t)n * p.ldw + kb + 8 * hh;
+  }
+  f32x16 acc[NT][1];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = (n0 >> 1) + wn * 32 + 8 * q + 4 * hh;
-        if (col >= (p.N >> 1)) continue;
-        half4 o;
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          o[j] = f2h_sat(gelu_new_f(acc[0][mi][4 * q + j] * p.scale) * (acc[1][mi][4 * q + j] * p.scale));
-        *(half4*)(C + (size_t)m * p.ldc + col) = o;
-      }
-    } else {
+    for (int r = 0; r < 16; ++r) acc[t][0][r] = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < kq; k += 16) {
+    const half8 bf = *(const half8*)(arow + k);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int n = n0 + wn * 64 + ni * 32 + 8 * q + 4 * hh;
-          if (n >= p.N) continue;
-          size_t base = 0;
-          if (p.n_split > 0) {
-            base = (size_t)(n / p.n_split) * (size_t)p.split_stride;
-            n = n % p.n_split;
-          }
-          float v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * q + j] * p.scale;
-          if (EPI == EPI_STORE_F16 || EPI == EPI_RELU_F16) {
-            half4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = f2h_sat(EPI == EPI_RELU_F16 ? fmaxf(v[j], 0.f) : v[j]);
-            *(half4*)((half_t*)p.C + base + (size_t)m * p.ldc + n) = o;
-          } else if (EPI == EPI_RESID_F32) {
-            float* c = (float*)p.C + base + (size_t)m * p.ldc + n;
-            f32x4 old = *(f32x4*)c;
-            f32x4 o = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
-            *(f32x4*)c = o;
-          } else {  // EPI_STORE_F32
-            f32x4 o = {v[0], v[1], v[2], v[3]};
-            *(f32x4*)((float*)p.C + base + (size_t)m * p.ldc + n) = o;
-          }
-        }
-      }
+    for (int t = 0; t < NT; ++t) {
+      const half8 wf = *(const half8*)(wrow[t] + k);
+      acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, bf, acc[t][0], 0, 0, 0);
     }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave - 1) * NT + t) * 1024 + r * 64 + lane] = acc[t][0][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][0][r] += red[(w * NT + t) * 1024 + r * 64 + lane];
+    gemm_epilogue<EPI, NT, 1>(p, acc, 0, n0, l31, hh);
   }
 }

@@ -24,6 +24,8 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int* __restrict
 
 // hf: modeling_t5.py:59-72 (T5LayerNorm): y = w * x * rsqrt(mean(x^2) + eps); fp32 statistics, fp16 result
 // (the GEMM input).  row_map (optional) gathers source rows: out row r reads x row row_map[r].
+// One wave per row; the row (d <= 64*4*NV floats) stays in registers so HBM is read exactly once.
+template <int NV>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       half_t* __restrict__ out, const int* __restrict__ row_map,
                                                       int n_rows, int d, float eps, float out_scale) {
@@ -31,20 +33,28 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
   const int lane = threadIdx.x & 63;
   if (row >= n_rows) return;
   const float* src = x + (size_t)(row_map ? row_map[row] : row) * d;
+  f32x4 v[NV];
   float ss = 0.f;
-  for (int c = lane * 4; c < d; c += 256) {
-    const f32x4 v = *(const f32x4*)(src + c);
-    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < d) {
+      v[i] = *(const f32x4*)(src + c);
+      ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+    }
   }
   ss = wave_sum(ss);
   const float rs = rsqrtf(ss / (float)d + eps) * out_scale;
   half_t* dst = out + (size_t)row * d;
-  for (int c = lane * 4; c < d; c += 256) {
-    const f32x4 v = *(const f32x4*)(src + c);
-    const f32x4 g = *(const f32x4*)(w + c);
-    half4 o = {f2h_sat(v[0] * rs * g[0]), f2h_sat(v[1] * rs * g[1]), f2h_sat(v[2] * rs * g[2]),
-               f2h_sat(v[3] * rs * g[3])};
-    *(half4*)(dst + c) = o;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < d) {
+      const f32x4 g = *(const f32x4*)(w + c);
+      half4 o = {f2h_sat(v[i][0] * rs * g[0]), f2h_sat(v[i][1] * rs * g[1]), f2h_sat(v[i][2] * rs * g[2]),
+                 f2h_sat(v[i][3] * rs * g[3])};
+      *(half4*)(dst + c) = o;
+    }
   }
 }
 

@@ -76,7 +76,7 @@ struct rk_engine {
   // staged batch
   int n_seq = 0, T = 0, maxL = 0; bool staged = false; int last_n_out = 0;
   // options / measurement
-  int opt_glds = 1;
+  int opt_glds = 1, opt_skinny = 1;
   hipEvent_t t0 = nullptr, t1 = nullptr;
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
@@ -155,6 +155,17 @@ void gemm(rk_engine* e, int cls, int epi, const half_t* A, int lda, const half_t
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
                        out_elems * (epi == EPI_RESID_F32 ? 8.0 : (epi == EPI_STORE_F32 ? 4.0 : 2.0));
   Bracket br(e, cls, flops, bytes);
+  if (M <= 32 && e->opt_skinny && n_split == 0) {   // weight-streaming regime (single-step decoder, head)
+    const dim3 b(256);
+    switch (epi) {
+      case EPI_STORE_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F16, 1>), dim3((N + 31) / 32), b, 0, e->stream, a); break;
+      case EPI_RESID_F32: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RESID_F32, 1>), dim3((N + 31) / 32), b, 0, e->stream, a); break;
+      case EPI_GEGLU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_GEGLU_F16, 2>), dim3((N + 63) / 64), b, 0, e->stream, a); break;
+      case EPI_RELU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RELU_F16, 1>), dim3((N + 31) / 32), b, 0, e->stream, a); break;
+      default: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F32, 1>), dim3((N + 31) / 32), b, 0, e->stream, a); break;
+    }
+    return;
+  }
   switch (epi) {
     case EPI_STORE_F16: launch_gemm_epi<EPI_STORE_F16>(e, a); break;
     case EPI_RESID_F32: launch_gemm_epi<EPI_RESID_F32>(e, a); break;
@@ -167,8 +178,11 @@ void gemm(rk_engine* e, int cls, int epi, const half_t* A, int lda, const half_t
 void rmsnorm(rk_engine* e, const float* x, const float* w, half_t* out, const int* row_map, int rows, float scale = 1.f) {
   if (rows <= 0) return;
   Bracket br(e, PC_NORM, 3.0 * rows * e->d.d_model, (double)rows * e->d.d_model * 6.0);
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, e->stream, x, w, out, row_map, rows,
-                     e->d.d_model, e->d.eps, scale);
+  const int dm = e->d.d_model;
+  const dim3 g((rows + 3) / 4), b(256);
+  if (dm <= 1024) hipLaunchKernelGGL(rmsnorm_kernel<4>, g, b, 0, e->stream, x, w, out, row_map, rows, dm, e->d.eps, scale);
+  else if (dm <= 2048) hipLaunchKernelGGL(rmsnorm_kernel<8>, g, b, 0, e->stream, x, w, out, row_map, rows, dm, e->d.eps, scale);
+  else hipLaunchKernelGGL(rmsnorm_kernel<16>, g, b, 0, e->stream, x, w, out, row_map, rows, dm, e->d.eps, scale);
 }
 
 void embed(rk_engine* e, const int* ids, float* out, int rows) {
@@ -262,16 +276,20 @@ int run_decoder(rk_engine* e, int Ld) {
   const rk_model_desc& d = e->d;
   const int B = e->n_seq, M = B * Ld, I = e->inner, dm = d.d_model, F = d.d_ff;
   embed(e, e->d_dec_ids, e->dhidden, M);
-  const size_t smem_self = 4 * (64 + (size_t)Ld) * sizeof(float);
-  const size_t smem_cross = 4 * (64 + (size_t)e->maxL) * sizeof(float);
+  const size_t smem_self = (64 + 256 + 8 + (size_t)Ld) * sizeof(float);
+  const size_t smem_cross = (64 + 256 + 8 + (size_t)e->maxL) * sizeof(float);
   for (int l = 0; l < d.n_dec_layers; ++l) {
     const DecLayerW& w = e->dec[l];
     rmsnorm(e, e->dhidden, w.ln0, e->dxn, nullptr, M);
-    gemm(e, PC_DEC_GEMM, EPI_STORE_F16, e->dxn, dm, w.qkv, dm, e->dqkv, 3 * I, M, 3 * I, dm);
-    {
+    if (Ld == 1) {
+      // one decoder position: softmax over a single key is 1, so self-attention is exactly o(v(x)) — the q/k
+      // projections, scores and bias are dead (hf: modeling_t5.py:448-509 at L_d = 1)
+      gemm(e, PC_DEC_GEMM, EPI_STORE_F16, e->dxn, dm, w.qkv + (size_t)2 * I * dm, dm, e->dctx, I, M, I, dm);
+    } else {
+      gemm(e, PC_DEC_GEMM, EPI_STORE_F16, e->dxn, dm, w.qkv, dm, e->dqkv, 3 * I, M, 3 * I, dm);
       AttnDecArgs a{e->dqkv, 3 * I, e->dqkv + I, e->dqkv + 2 * I, 3 * I, nullptr, e->dctx, I, e->lut_dec, Ld, 1, Ld};
       Bracket br(e, PC_DEC_ATTN, 4.0 * M * Ld * I, 0);
-      hipLaunchKernelGGL(attn_dec_kernel, dim3((Ld + 3) / 4, d.n_heads, B), dim3(256), smem_self, e->stream, a);
+      hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_self, e->stream, a);
     }
     gemm(e, PC_DEC_GEMM, EPI_RESID_F32, e->dctx, I, w.o, I, e->dhidden, dm, M, dm, I);
     rmsnorm(e, e->dhidden, w.ln1, e->dxn, nullptr, M);
@@ -280,7 +298,7 @@ int run_decoder(rk_engine* e, int Ld) {
       const half_t* kv = e->cross_kv + (size_t)l * d.max_tokens * 2 * I;
       AttnDecArgs a{e->dq, I, kv, kv + I, 2 * I, e->d_seq_off, e->dctx, I, nullptr, Ld, 0, e->maxL};
       Bracket br(e, PC_DEC_ATTN, 4.0 * Ld * (double)e->T * I, (double)e->T * 2 * I * 2.0);
-      hipLaunchKernelGGL(attn_dec_kernel, dim3((Ld + 3) / 4, d.n_heads, B), dim3(256), smem_cross, e->stream, a);
+      hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_cross, e->stream, a);
     }
     gemm(e, PC_DEC_GEMM, EPI_RESID_F32, e->dctx, I, w.co, I, e->dhidden, dm, M, dm, I);
     rmsnorm(e, e->dhidden, w.ln2, e->dxn, nullptr, M);
@@ -564,7 +582,7 @@ int rk_engine_finalize(rk_engine* e) {
   HIPCHK(e, hipHostMalloc((void**)&e->h_small, 4 * 8192 * sizeof(int), hipHostMallocDefault));
 #undef RC
   // dynamic-LDS opt-in for the kernels that may exceed the 64 KiB default
-  const int dec_smem_max = (int)(4 * (64 + (size_t)std::max(d.max_tokens, d.max_dec_len)) * sizeof(float));
+  const int dec_smem_max = (int)((64 + 256 + 8 + (size_t)std::max(d.max_tokens, d.max_dec_len)) * sizeof(float));
   if (dec_smem_max > 160 * 1024) { /* checked per call against maxL */ }
   // best effort: only kernels asking for more than the default dynamic-LDS window need the opt-in
   (void)hipFuncSetAttribute((const void*)attn_dec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -587,7 +605,7 @@ int rk_t5_stage(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets,
   e->staged = false;
   rc = check_batch(e, tokens, seq_offsets, n_seq);
   if (rc) return rc;
-  if (4 * (64 + (size_t)e->maxL) * sizeof(float) > 160 * 1024)
+  if ((64 + 256 + 8 + (size_t)e->maxL) * sizeof(float) > 160 * 1024)
     return fail(e, RK_ERR_CAPACITY, "sequence of %d tokens exceeds the cross-attention LDS budget", e->maxL);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   HIPCHK(e, hipMemcpy(e->d_tokens, tokens, (size_t)e->T * sizeof(int), hipMemcpyHostToDevice));
@@ -781,6 +799,7 @@ int rk_profile_get(rk_engine* e, int cls, double* total_ms, int64_t* launches, d
 int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!e || !key) return RK_ERR_INVALID;
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
+  if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value != 0; return RK_OK; }
   return fail(e, RK_ERR_INVALID, "unknown option %s", key);
 }
 

@@ -136,7 +136,7 @@ def test_config1_flan_t5_small_vs_hf_golden():
     from llmrankers import _synth
     g = np.load(os.path.join(GOLD, "config1_flan_t5_small.npz"))
     dims = _synth.FLAN_T5_SMALL
-    eng = _engine(dims, _synth.synth_state_dict(dims, seed=int(g["seed"]), threads=8), max_tokens=2048, max_seqs=8, max_dec_len=4)
+    eng = _engine(dims, _synth.synth_state_dict(dims, seed=int(g["seed"]), threads=8), max_tokens=4096, max_seqs=32, max_dec_len=4)
     off = np.concatenate([[0], np.cumsum(g["lens"])])
     seqs = [g["tokens"][off[i]:off[i + 1]].astype(np.int32) for i in range(len(g["lens"]))]
     ids = g["yes_no_ids"].tolist()

@@ -364,9 +364,9 @@ def main():
     import tempfile
     tmp = tempfile.mkdtemp(prefix="rk_goldens_")
     specs = {
-        "ckpt_gated_untied": {"dims": "toy-gated-untied", "seed": 11, "gain": 2.0},
-        "ckpt_relu_tied": {"dims": "toy-relu-tied", "seed": 12, "gain": 2.0},
-        "ckpt_labelboost": {"dims": "toy-gated-untied", "seed": 13, "gain": 2.0,
+        "ckpt_gated_untied": {"dims": "toy-gated-untied", "seed": 11, "gain": 1.0},
+        "ckpt_relu_tied": {"dims": "toy-relu-tied", "seed": 12, "gain": 1.0},
+        "ckpt_labelboost": {"dims": "toy-gated-untied", "seed": 13, "gain": 1.0,
                             "boost_ids": label_ids + [1], "boost": 6.0},
     }
     ckpts = {}
