@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
     ap.add_argument("--glds", type=int, default=1)
+    ap.add_argument("--overlap", type=int, default=1, help="1: decoder chain of step i overlaps encoder of step i+1 (two HIP streams)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -82,19 +83,30 @@ def main():
     eng = RkEngine(dims, device=local_rank, max_tokens=max(8192, B * L), max_seqs=max(32, B), max_dec_len=4)
     eng.load_state(state.items())
     eng.set_option("gemm_glds", args.glds)
+    eng.set_option("overlap", args.overlap)
     if rank == 0:
         print(f"[bench] weights generated + engine finalized in {time.time() - t0:.1f}s", file=sys.stderr)
-    seqs = _synth.synth_token_batch(B, L, L, dims.vocab, seed=929 + rank)
-    eng.stage(seqs)                                        # inputs resident in HBM before the timed region
+    n_slots = eng.num_slots
+    slot_seqs = [_synth.synth_token_batch(B, L, L, dims.vocab, seed=929 + rank * 16 + s) for s in range(n_slots)]
+    seqs = slot_seqs[0]
+    for s in range(n_slots):
+        eng.stage(slot_seqs[s], slot=s)                    # inputs resident in HBM before the timed region
     dec, out_ids = [0], [YES_ID, NO_ID]
     gathered = torch.empty((world, B, 2), dtype=torch.float32, device="cuda") if world > 1 else None
+    state_i = {"i": 0}
+
+    def gather(slot):                                      # one RCCL all_gather of a finished step's [B,2] scores
+        local = torch.from_numpy(eng.read_scores(slot)).cuda(non_blocking=True)
+        dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
 
     def step():
-        eng.score_staged(dec, out_ids)
-        if world > 1:                                       # one RCCL gather of the step's [B,2] scores
-            eng.sync()
-            local = torch.from_numpy(eng.read_scores()).cuda(non_blocking=True)
-            dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
+        # steps are independent batches (a query's candidate list is 4 such batches): batch i runs in slot i%2, so
+        # its decoder chain (own stream) overlaps the encoder of batch i+1
+        i = state_i["i"]
+        state_i["i"] = i + 1
+        eng.score_staged(dec, out_ids, slot=i % n_slots)
+        if world > 1 and i > 0:
+            gather((i - 1) % n_slots)                      # lags one step behind so the pipeline stays full
 
     def fence():
         eng.sync()
@@ -110,22 +122,25 @@ def main():
     eng.timer_begin()
     for _ in range(args.steps):
         step()
-    ev_ms = eng.timer_end()                                # HIP events on the engine's own stream
+    if world > 1:
+        gather((state_i["i"] - 1) % n_slots)               # flush the last step's scores
+    ev_ms = eng.timer_end()                                # HIP events on the engine's own streams
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    scores = eng.read_scores()
-    assert np.isfinite(scores).all()
+    scores = eng.read_scores(0)
+    assert all(np.isfinite(eng.read_scores(s)).all() for s in range(n_slots))
 
     roofline = None
     if not args.no_profile:
         eng.profile(True)
         eng.profile_reset()
+        eng.set_option("overlap", 0)                        # per-kernel events need a serial timeline
         for _ in range(min(args.steps, 5)):
-            eng.score_staged(dec, out_ids)
+            eng.score_staged(dec, out_ids, slot=0)
         eng.sync()
         rep = eng.profile_report()
         eng.profile(False)

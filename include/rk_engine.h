@@ -89,7 +89,14 @@ int rk_t5_stage(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets,
  * device buffer and are copied to pinned host memory asynchronously. Returns without synchronising. */
 int rk_t5_score_staged(rk_engine* e, const int32_t* dec_prefix, int dec_len, const int32_t* out_token_ids, int n_out);
 int rk_engine_sync(rk_engine* e);
-int rk_t5_read_scores(rk_engine* e, float* out_logits, int n_floats);   /* after rk_engine_sync */
+int rk_t5_read_scores(rk_engine* e, float* out_logits, int n_floats);   /* waits for the batch's decoder, then copies */
+/* The same three calls for batch slot `slot` in [0, rk_engine_num_slots()).  Slots are independent batches in flight:
+ * the latency-bound decoder chain of one slot runs on its own high-priority HIP stream while the MFMA-bound encoder
+ * of the next slot occupies the chip (events order encoder -> decoder per slot).  The un-suffixed calls use slot 0. */
+int rk_engine_num_slots(void);
+int rk_t5_stage_slot(rk_engine* e, int slot, const int32_t* tokens, const int32_t* seq_offsets, int n_seq);
+int rk_t5_score_slot(rk_engine* e, int slot, const int32_t* dec_prefix, int dec_len, const int32_t* out_token_ids, int n_out);
+int rk_t5_read_scores_slot(rk_engine* e, int slot, float* out_logits, int n_floats);
 /* device address of the fp32 score buffer [n_seq][n_out] of the last rk_t5_score_staged (for RCCL gathers) */
 int rk_t5_scores_device_ptr(rk_engine* e, void** out_ptr);
 
@@ -103,7 +110,8 @@ int rk_profile_reset(rk_engine* e);
 int rk_profile_num_classes(void);
 const char* rk_profile_class_name(int cls);
 int rk_profile_get(rk_engine* e, int cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
-/* kernel variant switches for A/B measurements: key "gemm_glds" (1 = direct-to-LDS DMA staging, 0 = registers) */
+/* variant switches for A/B measurements: "gemm_glds" (1 = direct-to-LDS DMA staging, 0 = registers),
+ * "gemm_skinny" (1 = weight-streaming kernel for M <= 32), "overlap" (1 = decoder chain on its own stream) */
 int rk_engine_set_option(rk_engine* e, const char* key, int value);
 
 /* ---- host-only helpers (no device needed) ---- */

@@ -200,35 +200,51 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
 }
 
 // ---- skinny GEMM: M <= 32 rows (the single-step decoder: M = sequences in the batch) ----------------------------
-// Weight-streaming regime: every weight element is used once, so there is no LDS staging of W at all.  One workgroup
-// owns NT consecutive 32-row weight tiles (NT = 2 for GEGLU: gate + up); its 4 waves split K four ways, each wave
-// streams its weight rows straight from HBM into MFMA A fragments (16 B per lane) and reads the tiny activation
-// matrix (L2-resident) as the B fragment; partial accumulators are combined through LDS in a FIXED order (bitwise
-// reproducible, unlike an atomic split-K).  grid = ceil(N / (32*NT)).
+// Weight-streaming regime: every weight element is used once, so W is never staged in LDS.  One 512-thread workgroup
+// owns NT consecutive 32-row weight tiles (NT = 2 for GEGLU: gate + up); its 8 waves take the K dimension in
+// interleaved 16-wide steps, each wave streams its weight rows straight from HBM into MFMA A fragments (16 B per
+// lane, 4 steps in flight) and reads the tiny activation matrix (L2-resident) as the B fragment.  Partial
+// accumulators are combined through LDS by a FIXED binary tree (bitwise reproducible, unlike an atomic split-K)
+// that needs only 16*NT KiB, so these workgroups still fit on a CU next to two resident encoder GEMM workgroups.
+#define SKINNY_THREADS 512
 template <int EPI, int NT>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
-  __shared__ float red[3 * NT * 1024];
+__global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p) {
+  __shared__ float red[4 * NT * 1024];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, hh = lane >> 5;
   const int n0 = blockIdx.x * 32 * NT;
-  const int kq = p.K >> 2;               // K % 64 == 0 -> kq % 16 == 0
-  const int kb = wave * kq;
-  int m = l31 < p.M ? l31 : p.M - 1;
-  const half_t* arow = p.A + (size_t)m * p.lda + kb + 8 * hh;
+  const int nsteps = p.K >> 4;
+  const int m = l31 < p.M ? l31 : p.M - 1;
+  const half_t* arow = p.A + (size_t)m * p.lda + 8 * hh;
   const half_t* wrow[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     int n = n0 + t * 32 + l31;
     n = n < p.N ? n : p.N - 1;
-    wrow[t] = p.W + (size_t)n * p.ldw + kb + 8 * hh;
+    wrow[t] = p.W + (size_t)n * p.ldw + 8 * hh;
   }
   f32x16 acc[NT][1];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][0][r] = 0.f;
-#pragma unroll 8
-  for (int k = 0; k < kq; k += 16) {
+  int s = wave;
+  for (; s + 24 < nsteps; s += 32) {
+    half8 bf[4], wf[4][NT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = (s + 8 * u) << 4;
+      bf[u] = *(const half8*)(arow + k);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wf[u][t] = *(const half8*)(wrow[t] + k);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[u][t], bf[u], acc[t][0], 0, 0, 0);
+  }
+  for (; s < nsteps; s += 8) {
+    const int k = s << 4;
     const half8 bf = *(const half8*)(arow + k);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -236,20 +252,23 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
       acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, bf, acc[t][0], 0, 0, 0);
     }
   }
-  if (wave > 0) {
+  // fixed reduction tree: (w, w+4) -> w ; (w, w+2) -> w ; (0, 1) -> 0
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[((wave - 1) * NT + t) * 1024 + r * 64 + lane] = acc[t][0][r];
-  }
-  __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int w = 0; w < 3; ++w)
+  for (int half_n = 4; half_n >= 1; half_n >>= 1) {
+    if (wave >= half_n && wave < 2 * half_n) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][0][r] += red[(w * NT + t) * 1024 + r * 64 + lane];
-    gemm_epilogue<EPI, NT, 1>(p, acc, 0, n0, l31, hh);
+        for (int r = 0; r < 16; ++r) red[((wave - half_n) * NT + t) * 1024 + r * 64 + lane] = acc[t][0][r];
+    }
+    __syncthreads();
+    if (wave < half_n) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][0][r] += red[(wave * NT + t) * 1024 + r * 64 + lane];
+    }
+    __syncthreads();
   }
+  if (wave == 0) gemm_epilogue<EPI, NT, 1>(p, acc, 0, n0, l31, hh);
 }

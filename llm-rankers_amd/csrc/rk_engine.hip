@@ -49,10 +49,26 @@ struct ProfRec { hipEvent_t a, b; int cls; };
 
 }  // namespace
 
+#define RK_SLOTS 2
+
+// Everything that belongs to ONE batch in flight.  The encoder workspace is shared (encoders run back to back on
+// the encoder stream); what the decoder of batch i needs while the encoder of batch i+1 already runs lives here.
+struct Slot {
+  int* d_tokens = nullptr; int* d_seq_off = nullptr;
+  int n_seq = 0, T = 0, maxL = 0; bool staged = false; int last_n_out = 0;
+  half_t* cross_kv = nullptr;                                  // [n_dec][max_tokens][2I] encoder -> decoder hand-off
+  int *d_dec_ids = nullptr, *d_last_rows = nullptr, *d_out_ids = nullptr, *d_labels = nullptr, *d_argmax = nullptr;
+  float* dhidden = nullptr; half_t *dxn = nullptr, *dqkv = nullptr, *dctx = nullptr, *dq = nullptr, *dffh = nullptr, *dlast = nullptr;
+  float* d_scores = nullptr; float* h_scores = nullptr;
+  int* h_small = nullptr;                                      // pinned staging for small int uploads
+  std::vector<int> cache_dec, cache_out, cache_rows;
+  hipEvent_t ev_enc = nullptr, ev_dec = nullptr; bool dec_pending = false;
+};
+
 struct rk_engine {
   rk_model_desc d{};
   int dev = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t s_enc = nullptr, s_dec = nullptr;   // MFMA-bound encoder chain | latency-bound decoder chain
   std::string err;
   bool finalized = false;
   int inner = 0;
@@ -63,21 +79,14 @@ struct rk_engine {
   std::vector<EncLayerW> enc;
   std::vector<DecLayerW> dec;
   float *enc_final_ln = nullptr, *dec_final_ln = nullptr, *lut_enc = nullptr, *lut_dec = nullptr;
-  // workspace (encoder side)
-  int* d_tokens = nullptr; int* d_seq_off = nullptr;
-  float* hidden = nullptr; half_t *xn = nullptr, *qkv = nullptr, *ctx = nullptr, *ffh = nullptr, *enc_out = nullptr, *cross_kv = nullptr;
-  // workspace (decoder side)
-  int *d_dec_ids = nullptr, *d_last_rows = nullptr, *d_out_ids = nullptr, *d_labels = nullptr, *d_argmax = nullptr;
-  float* dhidden = nullptr; half_t *dxn = nullptr, *dqkv = nullptr, *dctx = nullptr, *dq = nullptr, *dffh = nullptr, *dlast = nullptr;
-  float* logits = nullptr; size_t logits_cap = 0;
-  float* d_scores = nullptr; float* h_scores = nullptr; size_t scores_cap = 0;
-  int* h_small = nullptr;   // pinned staging for small int uploads
-  std::vector<int> cache_dec, cache_out, cache_lab;
-  // staged batch
-  int n_seq = 0, T = 0, maxL = 0; bool staged = false; int last_n_out = 0;
+  // shared encoder workspace
+  float* hidden = nullptr; half_t *xn = nullptr, *qkv = nullptr, *ctx = nullptr, *ffh = nullptr, *enc_out = nullptr;
+  float* logits = nullptr; size_t logits_cap = 0;              // full-vocabulary paths (qlm, greedy); slot 0 only
+  size_t scores_cap = 0;
+  Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 1;
-  hipEvent_t t0 = nullptr, t1 = nullptr;
+  int opt_glds = 1, opt_skinny = 1, opt_overlap = 1;
+  hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
   double prof_flops[PC_COUNT] = {0}, prof_bytes[PC_COUNT] = {0}; int64_t prof_n[PC_COUNT] = {0};
@@ -120,8 +129,8 @@ int upload(rk_engine* e, T** p, const T* src, size_t n) {
 
 // ---- profiling-aware launch bracket ---------------------------------------------------------------------
 struct Bracket {
-  rk_engine* e; int idx = -1;
-  Bracket(rk_engine* e_, int cls, double flops, double bytes) : e(e_) {
+  rk_engine* e; hipStream_t st; int idx = -1;
+  Bracket(rk_engine* e_, hipStream_t st_, int cls, double flops, double bytes) : e(e_), st(st_) {
     if (!e->prof_on) return;
     if (e->prof_used == e->prof_recs.size()) {
       ProfRec r{};
@@ -131,64 +140,66 @@ struct Bracket {
     idx = (int)e->prof_used++;
     e->prof_recs[idx].cls = cls;
     e->prof_flops[cls] += flops; e->prof_bytes[cls] += bytes; e->prof_n[cls]++;
-    hipEventRecord(e->prof_recs[idx].a, e->stream);
+    hipEventRecord(e->prof_recs[idx].a, st);
   }
-  ~Bracket() { if (idx >= 0) hipEventRecord(e->prof_recs[idx].b, e->stream); }
+  ~Bracket() { if (idx >= 0) hipEventRecord(e->prof_recs[idx].b, st); }
 };
+
+hipStream_t dec_stream(rk_engine* e) { return e->opt_overlap ? e->s_dec : e->s_enc; }
 
 // ---- kernel launch helpers ------------------------------------------------------------------------------
 template <int EPI>
-void launch_gemm_epi(rk_engine* e, const GemmArgs& a) {
+void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
   const int tiles = ((a.M + GEMM_BM - 1) / GEMM_BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
   if (e->opt_glds)
-    hipLaunchKernelGGL((gemm_f16_kernel<EPI, true>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, e->stream, a);
+    hipLaunchKernelGGL((gemm_f16_kernel<EPI, true>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);
   else
-    hipLaunchKernelGGL((gemm_f16_kernel<EPI, false>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, e->stream, a);
+    hipLaunchKernelGGL((gemm_f16_kernel<EPI, false>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);
 }
 
-void gemm(rk_engine* e, int cls, int epi, const half_t* A, int lda, const half_t* W, int ldw, void* C, int ldc,
-          int M, int N, int K, int n_split = 0, long split_stride = 0, float scale = 1.f) {
+void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int lda, const half_t* W, int ldw, void* C,
+          int ldc, int M, int N, int K, int n_split = 0, long split_stride = 0, float scale = 1.f) {
   if (M <= 0) return;
   GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale};
   const double flops = 2.0 * M * (double)N * K;
   const double out_elems = (epi == EPI_GEGLU_F16) ? (double)M * N / 2 : (double)M * N;
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
                        out_elems * (epi == EPI_RESID_F32 ? 8.0 : (epi == EPI_STORE_F32 ? 4.0 : 2.0));
-  Bracket br(e, cls, flops, bytes);
+  Bracket br(e, st, cls, flops, bytes);
   if (M <= 32 && e->opt_skinny && n_split == 0) {   // weight-streaming regime (single-step decoder, head)
-    const dim3 b(256);
+    const dim3 b(SKINNY_THREADS);
     switch (epi) {
-      case EPI_STORE_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F16, 1>), dim3((N + 31) / 32), b, 0, e->stream, a); break;
-      case EPI_RESID_F32: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RESID_F32, 1>), dim3((N + 31) / 32), b, 0, e->stream, a); break;
-      case EPI_GEGLU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_GEGLU_F16, 2>), dim3((N + 63) / 64), b, 0, e->stream, a); break;
-      case EPI_RELU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RELU_F16, 1>), dim3((N + 31) / 32), b, 0, e->stream, a); break;
-      default: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F32, 1>), dim3((N + 31) / 32), b, 0, e->stream, a); break;
+      case EPI_STORE_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F16, 1>), dim3((N + 31) / 32), b, 0, st, a); break;
+      case EPI_RESID_F32: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RESID_F32, 1>), dim3((N + 31) / 32), b, 0, st, a); break;
+      case EPI_GEGLU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_GEGLU_F16, 2>), dim3((N + 63) / 64), b, 0, st, a); break;
+      case EPI_RELU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RELU_F16, 1>), dim3((N + 31) / 32), b, 0, st, a); break;
+      default: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F32, 1>), dim3((N + 31) / 32), b, 0, st, a); break;
     }
     return;
   }
   switch (epi) {
-    case EPI_STORE_F16: launch_gemm_epi<EPI_STORE_F16>(e, a); break;
-    case EPI_RESID_F32: launch_gemm_epi<EPI_RESID_F32>(e, a); break;
-    case EPI_GEGLU_F16: launch_gemm_epi<EPI_GEGLU_F16>(e, a); break;
-    case EPI_RELU_F16: launch_gemm_epi<EPI_RELU_F16>(e, a); break;
-    default: launch_gemm_epi<EPI_STORE_F32>(e, a); break;
+    case EPI_STORE_F16: launch_gemm_epi<EPI_STORE_F16>(e, st, a); break;
+    case EPI_RESID_F32: launch_gemm_epi<EPI_RESID_F32>(e, st, a); break;
+    case EPI_GEGLU_F16: launch_gemm_epi<EPI_GEGLU_F16>(e, st, a); break;
+    case EPI_RELU_F16: launch_gemm_epi<EPI_RELU_F16>(e, st, a); break;
+    default: launch_gemm_epi<EPI_STORE_F32>(e, st, a); break;
   }
 }
 
-void rmsnorm(rk_engine* e, const float* x, const float* w, half_t* out, const int* row_map, int rows, float scale = 1.f) {
+void rmsnorm(rk_engine* e, hipStream_t st, const float* x, const float* w, half_t* out, const int* row_map, int rows, float scale = 1.f) {
   if (rows <= 0) return;
-  Bracket br(e, PC_NORM, 3.0 * rows * e->d.d_model, (double)rows * e->d.d_model * 6.0);
+  Bracket br(e, st, PC_NORM, 3.0 * rows * e->d.d_model, (double)rows * e->d.d_model * 6.0);
   const int dm = e->d.d_model;
   const dim3 g((rows + 3) / 4), b(256);
-  if (dm <= 1024) hipLaunchKernelGGL(rmsnorm_kernel<4>, g, b, 0, e->stream, x, w, out, row_map, rows, dm, e->d.eps, scale);
-  else if (dm <= 2048) hipLaunchKernelGGL(rmsnorm_kernel<8>, g, b, 0, e->stream, x, w, out, row_map, rows, dm, e->d.eps, scale);
-  else hipLaunchKernelGGL(rmsnorm_kernel<16>, g, b, 0, e->stream, x, w, out, row_map, rows, dm, e->d.eps, scale);
+  if (dm <= 1024) hipLaunchKernelGGL(rmsnorm_kernel<4>, g, b, 0, st, x, w, out, row_map, rows, dm, e->d.eps, scale);
+  else if (dm <= 2048) hipLaunchKernelGGL(rmsnorm_kernel<8>, g, b, 0, st, x, w, out, row_map, rows, dm, e->d.eps, scale);
+  else hipLaunchKernelGGL(rmsnorm_kernel<16>, g, b, 0, st, x, w, out, row_map, rows, dm, e->d.eps, scale);
 }
 
-void embed(rk_engine* e, const int* ids, float* out, int rows) {
+void embed(rk_engine* e, hipStream_t st, const int* ids, float* out, int rows) {
   if (rows <= 0) return;
-  Bracket br(e, PC_EMBED, 0, (double)rows * e->d.d_model * 6.0);
-  hipLaunchKernelGGL(embed_gather_kernel, dim3((rows + 3) / 4), dim3(256), 0, e->stream, ids, e->emb, out, rows,
+  Bracket br(e, st, PC_EMBED, 0, (double)rows * e->d.d_model * 6.0);
+  hipLaunchKernelGGL(embed_gather_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, ids, e->emb, out, rows,
                      e->d.d_model, e->d.vocab);
 }
 
@@ -227,95 +238,122 @@ int set_device(rk_engine* e) {
 }
 
 // Upload a small int array through pinned memory unless it equals what is already on the device.
-int upload_small(rk_engine* e, std::vector<int>* cache, int* dptr, int slot, const int* src, int n) {
+int upload_small(rk_engine* e, Slot& sl, hipStream_t st, std::vector<int>* cache, int* dptr, int pin_slot, const int* src, int n) {
   if ((int)cache->size() == n && (n == 0 || memcmp(cache->data(), src, n * sizeof(int)) == 0)) return RK_OK;
-  HIPCHK(e, hipStreamSynchronize(e->stream));   // pinned slot may still be in flight
-  int* pin = e->h_small + slot * 8192;
+  HIPCHK(e, hipStreamSynchronize(st));   // the pinned slot may still be in flight
+  int* pin = sl.h_small + pin_slot * 8192;
   memcpy(pin, src, n * sizeof(int));
-  HIPCHK(e, hipMemcpyAsync(dptr, pin, n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(dptr, pin, n * sizeof(int), hipMemcpyHostToDevice, st));
   cache->assign(src, src + n);
   return RK_OK;
 }
 
 // ---- forward passes -----------------------------------------------------------------------------------------
-// hf: modeling_t5.py:663-750 (T5Stack.forward, encoder) over the staged ragged batch, then the stacked
+// hf: modeling_t5.py:663-750 (T5Stack.forward, encoder) over the slot's staged ragged batch, then the stacked
 // cross-attention K/V projections of all decoder layers (:325-326 with key_value_states = encoder output).
-int run_encoder(rk_engine* e) {
+int run_encoder(rk_engine* e, Slot& sl) {
   const rk_model_desc& d = e->d;
-  const int T = e->T, I = e->inner, dm = d.d_model, F = d.d_ff;
-  embed(e, e->d_tokens, e->hidden, T);
+  hipStream_t st = e->s_enc;
+  const int T = sl.T, I = e->inner, dm = d.d_model, F = d.d_ff;
+  embed(e, st, sl.d_tokens, e->hidden, T);
   for (int l = 0; l < d.n_enc_layers; ++l) {
     const EncLayerW& w = e->enc[l];
-    rmsnorm(e, e->hidden, w.ln0, e->xn, nullptr, T);
-    gemm(e, PC_ENC_GEMM_QKV, EPI_STORE_F16, e->xn, dm, w.qkv, dm, e->qkv, 3 * I, T, 3 * I, dm);
+    rmsnorm(e, st, e->hidden, w.ln0, e->xn, nullptr, T);
+    gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, e->xn, dm, w.qkv, dm, e->qkv, 3 * I, T, 3 * I, dm);
     {
-      AttnEncArgs a{e->qkv, e->ctx, e->d_seq_off, e->lut_enc, 3 * I, I, I};
-      double att_flops = 0;   // 4 * L^2 * I per sequence, filled by caller-independent estimate below
-      att_flops = 4.0 * (double)e->maxL * T * I;   // upper bound for ragged batches; exact when uniform
-      Bracket br(e, PC_ENC_ATTN, att_flops, (double)T * 4 * I * 2.0);
-      hipLaunchKernelGGL(attn_enc_kernel, dim3((e->maxL + 127) / 128, d.n_heads, e->n_seq), dim3(256), 0, e->stream, a);
+      AttnEncArgs a{e->qkv, e->ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I};
+      const double att_flops = 4.0 * (double)sl.maxL * T * I;   // exact for uniform lengths, upper bound if ragged
+      Bracket br(e, st, PC_ENC_ATTN, att_flops, (double)T * 4 * I * 2.0);
+      hipLaunchKernelGGL(attn_enc_kernel, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
     }
-    gemm(e, PC_ENC_GEMM_O, EPI_RESID_F32, e->ctx, I, w.o, I, e->hidden, dm, T, dm, I);
-    rmsnorm(e, e->hidden, w.ln1, e->xn, nullptr, T);
+    gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, e->ctx, I, w.o, I, e->hidden, dm, T, dm, I);
+    rmsnorm(e, st, e->hidden, w.ln1, e->xn, nullptr, T);
     if (d.gated_gelu)
-      gemm(e, PC_ENC_GEMM_FFN_IN, EPI_GEGLU_F16, e->xn, dm, w.ffn_in, dm, e->ffh, F, T, 2 * F, dm);
+      gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_GEGLU_F16, e->xn, dm, w.ffn_in, dm, e->ffh, F, T, 2 * F, dm);
     else
-      gemm(e, PC_ENC_GEMM_FFN_IN, EPI_RELU_F16, e->xn, dm, w.ffn_in, dm, e->ffh, F, T, F, dm);
-    gemm(e, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, e->ffh, F, w.ffn_out, F, e->hidden, dm, T, dm, F);
+      gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_RELU_F16, e->xn, dm, w.ffn_in, dm, e->ffh, F, T, F, dm);
+    gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, e->ffh, F, w.ffn_out, F, e->hidden, dm, T, dm, F);
   }
-  rmsnorm(e, e->hidden, e->enc_final_ln, e->enc_out, nullptr, T);
-  gemm(e, PC_GEMM_CROSS_KV, EPI_STORE_F16, e->enc_out, dm, e->cross_kv_w, dm, e->cross_kv, 2 * I, T,
+  rmsnorm(e, st, e->hidden, e->enc_final_ln, e->enc_out, nullptr, T);
+  gemm(e, st, PC_GEMM_CROSS_KV, EPI_STORE_F16, e->enc_out, dm, e->cross_kv_w, dm, sl.cross_kv, 2 * I, T,
        d.n_dec_layers * 2 * I, dm, 2 * I, (long)d.max_tokens * 2 * I);
   HIPCHK(e, hipGetLastError());
   return RK_OK;
 }
 
 // hf: modeling_t5.py:663-750 (decoder stack) for Ld teacher-forced positions per sequence (ids already on the
-// device in d_dec_ids, row = b*Ld + t).  Leaves the residual stream in dhidden.
-int run_decoder(rk_engine* e, int Ld) {
+// device in sl.d_dec_ids, row = b*Ld + t).  Leaves the residual stream in sl.dhidden.
+int run_decoder(rk_engine* e, Slot& sl, int Ld) {
   const rk_model_desc& d = e->d;
-  const int B = e->n_seq, M = B * Ld, I = e->inner, dm = d.d_model, F = d.d_ff;
-  embed(e, e->d_dec_ids, e->dhidden, M);
+  hipStream_t st = dec_stream(e);
+  const int B = sl.n_seq, M = B * Ld, I = e->inner, dm = d.d_model, F = d.d_ff;
+  embed(e, st, sl.d_dec_ids, sl.dhidden, M);
   const size_t smem_self = (64 + 256 + 8 + (size_t)Ld) * sizeof(float);
-  const size_t smem_cross = (64 + 256 + 8 + (size_t)e->maxL) * sizeof(float);
+  const size_t smem_cross = (64 + 256 + 8 + (size_t)sl.maxL) * sizeof(float);
   for (int l = 0; l < d.n_dec_layers; ++l) {
     const DecLayerW& w = e->dec[l];
-    rmsnorm(e, e->dhidden, w.ln0, e->dxn, nullptr, M);
+    rmsnorm(e, st, sl.dhidden, w.ln0, sl.dxn, nullptr, M);
     if (Ld == 1) {
       // one decoder position: softmax over a single key is 1, so self-attention is exactly o(v(x)) — the q/k
       // projections, scores and bias are dead (hf: modeling_t5.py:448-509 at L_d = 1)
-      gemm(e, PC_DEC_GEMM, EPI_STORE_F16, e->dxn, dm, w.qkv + (size_t)2 * I * dm, dm, e->dctx, I, M, I, dm);
+      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.qkv + (size_t)2 * I * dm, dm, sl.dctx, I, M, I, dm);
     } else {
-      gemm(e, PC_DEC_GEMM, EPI_STORE_F16, e->dxn, dm, w.qkv, dm, e->dqkv, 3 * I, M, 3 * I, dm);
-      AttnDecArgs a{e->dqkv, 3 * I, e->dqkv + I, e->dqkv + 2 * I, 3 * I, nullptr, e->dctx, I, e->lut_dec, Ld, 1, Ld};
-      Bracket br(e, PC_DEC_ATTN, 4.0 * M * Ld * I, 0);
-      hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_self, e->stream, a);
+      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.qkv, dm, sl.dqkv, 3 * I, M, 3 * I, dm);
+      AttnDecArgs a{sl.dqkv, 3 * I, sl.dqkv + I, sl.dqkv + 2 * I, 3 * I, nullptr, sl.dctx, I, e->lut_dec, Ld, 1, Ld};
+      Bracket br(e, st, PC_DEC_ATTN, 4.0 * M * Ld * I, 0);
+      hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_self, st, a);
     }
-    gemm(e, PC_DEC_GEMM, EPI_RESID_F32, e->dctx, I, w.o, I, e->dhidden, dm, M, dm, I);
-    rmsnorm(e, e->dhidden, w.ln1, e->dxn, nullptr, M);
-    gemm(e, PC_DEC_GEMM, EPI_STORE_F16, e->dxn, dm, w.cq, dm, e->dq, I, M, I, dm);
+    gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.o, I, sl.dhidden, dm, M, dm, I);
+    rmsnorm(e, st, sl.dhidden, w.ln1, sl.dxn, nullptr, M);
+    gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.cq, dm, sl.dq, I, M, I, dm);
     {
-      const half_t* kv = e->cross_kv + (size_t)l * d.max_tokens * 2 * I;
-      AttnDecArgs a{e->dq, I, kv, kv + I, 2 * I, e->d_seq_off, e->dctx, I, nullptr, Ld, 0, e->maxL};
-      Bracket br(e, PC_DEC_ATTN, 4.0 * Ld * (double)e->T * I, (double)e->T * 2 * I * 2.0);
-      hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_cross, e->stream, a);
+      const half_t* kv = sl.cross_kv + (size_t)l * d.max_tokens * 2 * I;
+      AttnDecArgs a{sl.dq, I, kv, kv + I, 2 * I, sl.d_seq_off, sl.dctx, I, nullptr, Ld, 0, sl.maxL};
+      Bracket br(e, st, PC_DEC_ATTN, 4.0 * Ld * (double)sl.T * I, (double)sl.T * 2 * I * 2.0);
+      hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_cross, st, a);
     }
-    gemm(e, PC_DEC_GEMM, EPI_RESID_F32, e->dctx, I, w.co, I, e->dhidden, dm, M, dm, I);
-    rmsnorm(e, e->dhidden, w.ln2, e->dxn, nullptr, M);
+    gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.co, I, sl.dhidden, dm, M, dm, I);
+    rmsnorm(e, st, sl.dhidden, w.ln2, sl.dxn, nullptr, M);
     if (d.gated_gelu)
-      gemm(e, PC_DEC_GEMM, EPI_GEGLU_F16, e->dxn, dm, w.ffn_in, dm, e->dffh, F, M, 2 * F, dm);
+      gemm(e, st, PC_DEC_GEMM, EPI_GEGLU_F16, sl.dxn, dm, w.ffn_in, dm, sl.dffh, F, M, 2 * F, dm);
     else
-      gemm(e, PC_DEC_GEMM, EPI_RELU_F16, e->dxn, dm, w.ffn_in, dm, e->dffh, F, M, F, dm);
-    gemm(e, PC_DEC_GEMM, EPI_RESID_F32, e->dffh, F, w.ffn_out, F, e->dhidden, dm, M, dm, F);
+      gemm(e, st, PC_DEC_GEMM, EPI_RELU_F16, sl.dxn, dm, w.ffn_in, dm, sl.dffh, F, M, F, dm);
+    gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dffh, F, w.ffn_out, F, sl.dhidden, dm, M, dm, F);
   }
   HIPCHK(e, hipGetLastError());
+  return RK_OK;
+}
+
+// Encoder on s_enc, decoder on s_dec, ordered by events; the decoder of this slot's PREVIOUS batch must have
+// finished reading cross_kv before the encoder overwrites it.
+int encoder_then_handoff(rk_engine* e, Slot& sl) {
+  if (sl.dec_pending && dec_stream(e) != e->s_enc) HIPCHK(e, hipStreamWaitEvent(e->s_enc, sl.ev_dec, 0));
+  int rc = run_encoder(e, sl);
+  if (rc) return rc;
+  if (dec_stream(e) != e->s_enc) {
+    HIPCHK(e, hipEventRecord(sl.ev_enc, e->s_enc));
+    HIPCHK(e, hipStreamWaitEvent(dec_stream(e), sl.ev_enc, 0));
+  }
+  return RK_OK;
+}
+
+int mark_decoder_done(rk_engine* e, Slot& sl) {
+  HIPCHK(e, hipEventRecord(sl.ev_dec, dec_stream(e)));
+  sl.dec_pending = true;
+  return RK_OK;
+}
+
+int sync_all(rk_engine* e) {
+  HIPCHK(e, hipStreamSynchronize(e->s_enc));
+  HIPCHK(e, hipStreamSynchronize(e->s_dec));
   return RK_OK;
 }
 
 int ensure_logits(rk_engine* e, size_t rows) {
   const size_t need_elems = rows * (size_t)e->d.vocab;
   if (need_elems <= e->logits_cap) return RK_OK;
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  int rc = sync_all(e);
+  if (rc) return rc;
   if (e->logits) HIPCHK(e, hipFree(e->logits));
   e->logits = nullptr; e->logits_cap = 0;
   HIPCHK(e, hipMalloc((void**)&e->logits, need_elems * sizeof(float)));
@@ -327,7 +365,7 @@ float head_scale(const rk_engine* e) {   // hf: modeling_t5.py:1044-1045 (scale_
   return e->d.tied_head ? 1.0f / std::sqrt((float)e->d.d_model) : 1.0f;
 }
 
-int check_batch(rk_engine* e, const int32_t* tokens, const int32_t* off, int n_seq) {
+int check_batch(rk_engine* e, Slot& sl, const int32_t* tokens, const int32_t* off, int n_seq) {
   if (!e->finalized) return fail(e, RK_ERR_STATE, "engine not finalized");
   if (!tokens || !off || n_seq <= 0) return fail(e, RK_ERR_INVALID, "empty batch (n_seq=%d)", n_seq);
   if (n_seq > e->d.max_seqs) return fail(e, RK_ERR_CAPACITY, "n_seq %d > max_seqs %d", n_seq, e->d.max_seqs);
@@ -342,7 +380,9 @@ int check_batch(rk_engine* e, const int32_t* tokens, const int32_t* off, int n_s
   if (T > e->d.max_tokens) return fail(e, RK_ERR_CAPACITY, "%d tokens > max_tokens %d", T, e->d.max_tokens);
   for (int t = 0; t < T; ++t)
     if (tokens[t] < 0 || tokens[t] >= e->d.vocab) return fail(e, RK_ERR_INVALID, "token id %d out of range at %d", tokens[t], t);
-  e->maxL = maxL; e->T = T; e->n_seq = n_seq;
+  if ((64 + 256 + 8 + (size_t)maxL) * sizeof(float) > 160 * 1024)
+    return fail(e, RK_ERR_CAPACITY, "sequence of %d tokens exceeds the cross-attention LDS budget", maxL);
+  sl.maxL = maxL; sl.T = T; sl.n_seq = n_seq;
   return RK_OK;
 }
 
@@ -352,16 +392,62 @@ int check_ids(rk_engine* e, const int32_t* ids, int n, const char* what) {
   return RK_OK;
 }
 
-int upload_dec_ids_shared(rk_engine* e, const int32_t* prefix, int Ld) {
-  std::vector<int> ids((size_t)e->n_seq * Ld);
-  for (int b = 0; b < e->n_seq; ++b) memcpy(&ids[(size_t)b * Ld], prefix, Ld * sizeof(int));
+int upload_dec_ids_shared(rk_engine* e, Slot& sl, const int32_t* prefix, int Ld) {
+  std::vector<int> ids((size_t)sl.n_seq * Ld);
+  for (int b = 0; b < sl.n_seq; ++b) memcpy(&ids[(size_t)b * Ld], prefix, Ld * sizeof(int));
+  hipStream_t st = dec_stream(e);
   if (ids.size() > 8192) {   // larger than a pinned slot: plain synchronous copy
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    HIPCHK(e, hipMemcpy(e->d_dec_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
-    e->cache_dec.clear();
+    HIPCHK(e, hipStreamSynchronize(st));
+    HIPCHK(e, hipMemcpy(sl.d_dec_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
+    sl.cache_dec.clear();
     return RK_OK;
   }
-  return upload_small(e, &e->cache_dec, e->d_dec_ids, 0, ids.data(), (int)ids.size());
+  return upload_small(e, sl, st, &sl.cache_dec, sl.d_dec_ids, 0, ids.data(), (int)ids.size());
+}
+
+int stage_slot(rk_engine* e, int slot, const int32_t* tokens, const int32_t* seq_offsets, int n_seq) {
+  if (slot < 0 || slot >= RK_SLOTS) return fail(e, RK_ERR_INVALID, "slot %d out of range", slot);
+  int rc = set_device(e);
+  if (rc) return rc;
+  Slot& sl = e->slots[slot];
+  sl.staged = false;
+  if ((rc = check_batch(e, sl, tokens, seq_offsets, n_seq))) return rc;
+  // the slot's previous batch (encoder reads tokens, decoder reads seq_off) must be done before overwriting
+  if (sl.dec_pending) { HIPCHK(e, hipEventSynchronize(sl.ev_dec)); sl.dec_pending = false; }
+  HIPCHK(e, hipStreamSynchronize(e->s_enc));
+  HIPCHK(e, hipMemcpy(sl.d_tokens, tokens, (size_t)sl.T * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(sl.d_seq_off, seq_offsets, (size_t)(n_seq + 1) * sizeof(int), hipMemcpyHostToDevice));
+  sl.staged = true;
+  return RK_OK;
+}
+
+int score_slot(rk_engine* e, int slot, const int32_t* dec_prefix, int dec_len, const int32_t* out_token_ids, int n_out) {
+  if (slot < 0 || slot >= RK_SLOTS) return fail(e, RK_ERR_INVALID, "slot %d out of range", slot);
+  int rc = set_device(e);
+  if (rc) return rc;
+  Slot& sl = e->slots[slot];
+  if (!sl.staged) return fail(e, RK_ERR_STATE, "no staged batch in slot %d", slot);
+  if (!dec_prefix || dec_len <= 0 || dec_len > e->d.max_dec_len) return fail(e, RK_ERR_CAPACITY, "dec_len %d out of range (max %d)", dec_len, e->d.max_dec_len);
+  if (!out_token_ids || n_out <= 0 || n_out > 64) return fail(e, RK_ERR_INVALID, "n_out must be in 1..64 (got %d)", n_out);
+  if ((rc = check_ids(e, dec_prefix, dec_len, "decoder")) || (rc = check_ids(e, out_token_ids, n_out, "output"))) return rc;
+  hipStream_t sd = dec_stream(e);
+  if ((rc = upload_dec_ids_shared(e, sl, dec_prefix, dec_len))) return rc;
+  if ((rc = upload_small(e, sl, sd, &sl.cache_out, sl.d_out_ids, 1, out_token_ids, n_out))) return rc;
+  std::vector<int> rows(sl.n_seq);
+  for (int b = 0; b < sl.n_seq; ++b) rows[b] = b * dec_len + dec_len - 1;
+  if ((rc = upload_small(e, sl, sd, &sl.cache_rows, sl.d_last_rows, 2, rows.data(), sl.n_seq))) return rc;
+  if ((rc = encoder_then_handoff(e, sl))) return rc;
+  if ((rc = run_decoder(e, sl, dec_len))) return rc;
+  rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, sl.n_seq, head_scale(e));
+  {
+    Bracket br(e, sd, PC_HEAD, 2.0 * sl.n_seq * n_out * e->d.d_model, 0);
+    hipLaunchKernelGGL(head_rows_kernel, dim3((sl.n_seq * n_out + 3) / 4), dim3(256), 0, sd, sl.dlast, e->lm_head,
+                       sl.d_out_ids, sl.d_scores, sl.n_seq, n_out, e->d.d_model);
+  }
+  HIPCHK(e, hipMemcpyAsync(sl.h_scores, sl.d_scores, (size_t)sl.n_seq * n_out * sizeof(float), hipMemcpyDeviceToHost, sd));
+  HIPCHK(e, hipGetLastError());
+  sl.last_n_out = n_out;
+  return mark_decoder_done(e, sl);
 }
 
 }  // namespace
@@ -404,8 +490,19 @@ int rk_engine_create(const rk_model_desc* desc, int device_ordinal, rk_engine** 
     return fail(nullptr, RK_ERR_NO_DEVICE, "device %d is %s; kernels are built for gfx950 (MI355X) only", device_ordinal, prop.gcnArchName);
   rk_engine* e = new rk_engine();
   e->d = d; e->dev = device_ordinal; e->inner = d.n_heads * d.d_kv;
-  if (hipSetDevice(device_ordinal) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&e->t0) != hipSuccess || hipEventCreate(&e->t1) != hipSuccess) {
+  int prio_lo = 0, prio_hi = 0;
+  bool ok = hipSetDevice(device_ordinal) == hipSuccess;
+  ok = ok && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess;
+  // the decoder chain is a long sequence of tiny dependent kernels: give it dispatch priority over the encoder's
+  // chip-filling GEMM grids so it progresses while they run
+  ok = ok && hipStreamCreateWithPriority(&e->s_enc, hipStreamNonBlocking, prio_lo) == hipSuccess;
+  ok = ok && hipStreamCreateWithPriority(&e->s_dec, hipStreamNonBlocking, prio_hi) == hipSuccess;
+  ok = ok && hipEventCreate(&e->t0) == hipSuccess && hipEventCreate(&e->t1) == hipSuccess &&
+       hipEventCreateWithFlags(&e->t_tmp, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < RK_SLOTS; ++i)
+    ok = hipEventCreateWithFlags(&e->slots[i].ev_enc, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&e->slots[i].ev_dec, hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
     delete e;
     return fail(nullptr, RK_ERR_HIP, "stream/event creation failed");
   }
@@ -416,15 +513,22 @@ int rk_engine_create(const rk_model_desc* desc, int device_ordinal, rk_engine** 
 void rk_engine_destroy(rk_engine* e) {
   if (!e) return;
   hipSetDevice(e->dev);
-  if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->s_enc) hipStreamSynchronize(e->s_enc);
+  if (e->s_dec) hipStreamSynchronize(e->s_dec);
   for (void* p : e->allocs) hipFree(p);
   if (e->logits) hipFree(e->logits);
-  if (e->h_scores) hipHostFree(e->h_scores);
-  if (e->h_small) hipHostFree(e->h_small);
+  for (auto& sl : e->slots) {
+    if (sl.h_scores) hipHostFree(sl.h_scores);
+    if (sl.h_small) hipHostFree(sl.h_small);
+    if (sl.ev_enc) hipEventDestroy(sl.ev_enc);
+    if (sl.ev_dec) hipEventDestroy(sl.ev_dec);
+  }
   for (auto& r : e->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   if (e->t0) hipEventDestroy(e->t0);
   if (e->t1) hipEventDestroy(e->t1);
-  if (e->stream) hipStreamDestroy(e->stream);
+  if (e->t_tmp) hipEventDestroy(e->t_tmp);
+  if (e->s_enc) hipStreamDestroy(e->s_enc);
+  if (e->s_dec) hipStreamDestroy(e->s_dec);
   delete e;
 }
 
@@ -567,19 +671,21 @@ int rk_engine_finalize(rk_engine* e) {
 
   // workspaces, sized once for the 288 GB part: nothing is allocated on the hot path afterwards
   const size_t Tc = d.max_tokens, Bc = d.max_seqs, Mc = (size_t)d.max_seqs * d.max_dec_len;
-  RC(dalloc(e, &e->d_tokens, Tc)); RC(dalloc(e, &e->d_seq_off, Bc + 1));
   RC(dalloc(e, &e->hidden, Tc * dm)); RC(dalloc(e, &e->xn, Tc * dm)); RC(dalloc(e, &e->qkv, Tc * 3 * I));
   RC(dalloc(e, &e->ctx, Tc * I)); RC(dalloc(e, &e->ffh, Tc * F)); RC(dalloc(e, &e->enc_out, Tc * dm));
-  RC(dalloc(e, &e->cross_kv, (size_t)d.n_dec_layers * Tc * 2 * I));
-  RC(dalloc(e, &e->d_dec_ids, Mc)); RC(dalloc(e, &e->d_last_rows, Bc)); RC(dalloc(e, &e->d_out_ids, 8192));
-  RC(dalloc(e, &e->d_labels, (size_t)d.max_dec_len)); RC(dalloc(e, &e->d_argmax, Bc));
-  RC(dalloc(e, &e->dhidden, Mc * dm)); RC(dalloc(e, &e->dxn, Mc * dm)); RC(dalloc(e, &e->dqkv, Mc * 3 * I));
-  RC(dalloc(e, &e->dctx, Mc * I)); RC(dalloc(e, &e->dq, Mc * I)); RC(dalloc(e, &e->dffh, Mc * F));
-  RC(dalloc(e, &e->dlast, Bc * dm));
   e->scores_cap = Bc * 64;
-  RC(dalloc(e, &e->d_scores, e->scores_cap));
-  HIPCHK(e, hipHostMalloc((void**)&e->h_scores, e->scores_cap * sizeof(float), hipHostMallocDefault));
-  HIPCHK(e, hipHostMalloc((void**)&e->h_small, 4 * 8192 * sizeof(int), hipHostMallocDefault));
+  for (Slot& sl : e->slots) {
+    RC(dalloc(e, &sl.d_tokens, Tc)); RC(dalloc(e, &sl.d_seq_off, Bc + 1));
+    RC(dalloc(e, &sl.cross_kv, (size_t)d.n_dec_layers * Tc * 2 * I));
+    RC(dalloc(e, &sl.d_dec_ids, Mc)); RC(dalloc(e, &sl.d_last_rows, Bc)); RC(dalloc(e, &sl.d_out_ids, 8192));
+    RC(dalloc(e, &sl.d_labels, (size_t)d.max_dec_len)); RC(dalloc(e, &sl.d_argmax, Bc));
+    RC(dalloc(e, &sl.dhidden, Mc * dm)); RC(dalloc(e, &sl.dxn, Mc * dm)); RC(dalloc(e, &sl.dqkv, Mc * 3 * I));
+    RC(dalloc(e, &sl.dctx, Mc * I)); RC(dalloc(e, &sl.dq, Mc * I)); RC(dalloc(e, &sl.dffh, Mc * F));
+    RC(dalloc(e, &sl.dlast, Bc * dm));
+    RC(dalloc(e, &sl.d_scores, e->scores_cap));
+    HIPCHK(e, hipHostMalloc((void**)&sl.h_scores, e->scores_cap * sizeof(float), hipHostMallocDefault));
+    HIPCHK(e, hipHostMalloc((void**)&sl.h_small, 4 * 8192 * sizeof(int), hipHostMallocDefault));
+  }
 #undef RC
   // dynamic-LDS opt-in for the kernels that may exceed the 64 KiB default
   const int dec_smem_max = (int)((64 + 256 + 8 + (size_t)std::max(d.max_tokens, d.max_dec_len)) * sizeof(float));
@@ -598,77 +704,52 @@ int rk_engine_finalize(rk_engine* e) {
   return RK_OK;
 }
 
-int rk_t5_stage(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq) {
+int rk_t5_stage_slot(rk_engine* e, int slot, const int32_t* tokens, const int32_t* seq_offsets, int n_seq) {
   if (!e) return RK_ERR_INVALID;
-  int rc = set_device(e);
-  if (rc) return rc;
-  e->staged = false;
-  rc = check_batch(e, tokens, seq_offsets, n_seq);
-  if (rc) return rc;
-  if ((64 + 256 + 8 + (size_t)e->maxL) * sizeof(float) > 160 * 1024)
-    return fail(e, RK_ERR_CAPACITY, "sequence of %d tokens exceeds the cross-attention LDS budget", e->maxL);
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  HIPCHK(e, hipMemcpy(e->d_tokens, tokens, (size_t)e->T * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(e, hipMemcpy(e->d_seq_off, seq_offsets, (size_t)(n_seq + 1) * sizeof(int), hipMemcpyHostToDevice));
-  e->staged = true;
-  return RK_OK;
+  return stage_slot(e, slot, tokens, seq_offsets, n_seq);
+}
+int rk_t5_stage(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq) {
+  return rk_t5_stage_slot(e, 0, tokens, seq_offsets, n_seq);
 }
 
-int rk_t5_score_staged(rk_engine* e, const int32_t* dec_prefix, int dec_len, const int32_t* out_token_ids, int n_out) {
+int rk_t5_score_slot(rk_engine* e, int slot, const int32_t* dec_prefix, int dec_len, const int32_t* out_token_ids, int n_out) {
   if (!e) return RK_ERR_INVALID;
-  int rc = set_device(e);
-  if (rc) return rc;
-  if (!e->staged) return fail(e, RK_ERR_STATE, "no staged batch");
-  if (!dec_prefix || dec_len <= 0 || dec_len > e->d.max_dec_len) return fail(e, RK_ERR_CAPACITY, "dec_len %d out of range (max %d)", dec_len, e->d.max_dec_len);
-  if (!out_token_ids || n_out <= 0 || n_out > 64) return fail(e, RK_ERR_INVALID, "n_out must be in 1..64 (got %d)", n_out);
-  if ((rc = check_ids(e, dec_prefix, dec_len, "decoder")) || (rc = check_ids(e, out_token_ids, n_out, "output"))) return rc;
-  if ((rc = upload_dec_ids_shared(e, dec_prefix, dec_len))) return rc;
-  if ((rc = upload_small(e, &e->cache_out, e->d_out_ids, 1, out_token_ids, n_out))) return rc;
-  if ((rc = run_encoder(e))) return rc;
-  if ((rc = run_decoder(e, dec_len))) return rc;
-  {
-    // last-row map is a pure function of (n_seq, dec_len): upload through the cached small-int path
-    std::vector<int> rows(e->n_seq);
-    for (int b = 0; b < e->n_seq; ++b) rows[b] = b * dec_len + dec_len - 1;
-    if ((rc = upload_small(e, &e->cache_lab, e->d_last_rows, 2, rows.data(), e->n_seq))) return rc;
-    rmsnorm(e, e->dhidden, e->dec_final_ln, e->dlast, e->d_last_rows, e->n_seq, head_scale(e));
-    Bracket br(e, PC_HEAD, 2.0 * e->n_seq * n_out * e->d.d_model, 0);
-    hipLaunchKernelGGL(head_rows_kernel, dim3((e->n_seq * n_out + 3) / 4), dim3(256), 0, e->stream, e->dlast, e->lm_head,
-                       e->d_out_ids, e->d_scores, e->n_seq, n_out, e->d.d_model);
-  }
-  HIPCHK(e, hipMemcpyAsync(e->h_scores, e->d_scores, (size_t)e->n_seq * n_out * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipGetLastError());
-  e->last_n_out = n_out;
-  return RK_OK;
+  return score_slot(e, slot, dec_prefix, dec_len, out_token_ids, n_out);
+}
+int rk_t5_score_staged(rk_engine* e, const int32_t* dec_prefix, int dec_len, const int32_t* out_token_ids, int n_out) {
+  return rk_t5_score_slot(e, 0, dec_prefix, dec_len, out_token_ids, n_out);
 }
 
 int rk_engine_sync(rk_engine* e) {
   if (!e) return RK_ERR_INVALID;
   int rc = set_device(e);
   if (rc) return rc;
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  return RK_OK;
+  return sync_all(e);
 }
 
-int rk_t5_read_scores(rk_engine* e, float* out_logits, int n_floats) {
-  if (!e || !out_logits) return RK_ERR_INVALID;
-  if (n_floats > e->n_seq * e->last_n_out) return fail(e, RK_ERR_INVALID, "asked for %d floats, have %d", n_floats, e->n_seq * e->last_n_out);
-  memcpy(out_logits, e->h_scores, (size_t)n_floats * sizeof(float));
+int rk_t5_read_scores_slot(rk_engine* e, int slot, float* out_logits, int n_floats) {
+  if (!e || !out_logits || slot < 0 || slot >= RK_SLOTS) return RK_ERR_INVALID;
+  Slot& sl = e->slots[slot];
+  if (n_floats > sl.n_seq * sl.last_n_out) return fail(e, RK_ERR_INVALID, "asked for %d floats, have %d", n_floats, sl.n_seq * sl.last_n_out);
+  if (sl.dec_pending) { HIPCHK(e, hipEventSynchronize(sl.ev_dec)); sl.dec_pending = false; }
+  memcpy(out_logits, sl.h_scores, (size_t)n_floats * sizeof(float));
   return RK_OK;
 }
+int rk_t5_read_scores(rk_engine* e, float* out_logits, int n_floats) { return rk_t5_read_scores_slot(e, 0, out_logits, n_floats); }
 
 int rk_t5_scores_device_ptr(rk_engine* e, void** out_ptr) {
   if (!e || !out_ptr) return RK_ERR_INVALID;
-  *out_ptr = e->d_scores;
+  *out_ptr = e->slots[0].d_scores;
   return RK_OK;
 }
+
+int rk_engine_num_slots(void) { return RK_SLOTS; }
 
 int rk_t5_score(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq, const int32_t* dec_prefix,
                 int dec_len, const int32_t* out_token_ids, int n_out, float* out_logits) {
   int rc;
   if ((rc = rk_t5_stage(e, tokens, seq_offsets, n_seq))) return rc;
   if ((rc = rk_t5_score_staged(e, dec_prefix, dec_len, out_token_ids, n_out))) return rc;
-  if ((rc = rk_engine_sync(e))) return rc;
   return rk_t5_read_scores(e, out_logits, n_seq * n_out);
 }
 
@@ -676,27 +757,31 @@ int rk_t5_qlm(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, i
               int n_labels, float* out_scores) {
   int rc;
   if ((rc = rk_t5_stage(e, tokens, seq_offsets, n_seq))) return rc;
+  Slot& sl = e->slots[0];
   if (!labels || n_labels <= 0 || n_labels > e->d.max_dec_len) return fail(e, RK_ERR_CAPACITY, "n_labels %d out of range (max %d)", n_labels, e->d.max_dec_len);
   if ((rc = check_ids(e, labels, n_labels, "label"))) return rc;
   // decoder input = shift_right(labels): [decoder_start(0), labels[:-1]]  (hf: modeling_t5.py:618-637)
   std::vector<int> dec_in(n_labels);
   dec_in[0] = 0;
   for (int t = 1; t < n_labels; ++t) dec_in[t] = labels[t - 1];
-  if ((rc = upload_dec_ids_shared(e, dec_in.data(), n_labels))) return rc;
-  HIPCHK(e, hipStreamSynchronize(e->stream));
-  HIPCHK(e, hipMemcpy(e->d_labels, labels, n_labels * sizeof(int), hipMemcpyHostToDevice));
-  if ((rc = run_encoder(e))) return rc;
-  if ((rc = run_decoder(e, n_labels))) return rc;
+  hipStream_t sd = dec_stream(e);
+  if ((rc = upload_dec_ids_shared(e, sl, dec_in.data(), n_labels))) return rc;
+  HIPCHK(e, hipStreamSynchronize(sd));
+  HIPCHK(e, hipMemcpy(sl.d_labels, labels, n_labels * sizeof(int), hipMemcpyHostToDevice));
   const int M = n_seq * n_labels;
   if ((rc = ensure_logits(e, M))) return rc;
-  rmsnorm(e, e->dhidden, e->dec_final_ln, e->dxn, nullptr, M, head_scale(e));
-  gemm(e, PC_HEAD, EPI_STORE_F32, e->dxn, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, M, e->d.vocab, e->d.d_model);
-  hipLaunchKernelGGL(qlm_ce_kernel, dim3(n_seq), dim3(256), 0, e->stream, e->logits, e->d.vocab, e->d.vocab, e->d_labels,
-                     n_labels, e->d_scores);
-  HIPCHK(e, hipMemcpyAsync(e->h_scores, e->d_scores, (size_t)n_seq * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if ((rc = encoder_then_handoff(e, sl))) return rc;
+  if ((rc = run_decoder(e, sl, n_labels))) return rc;
+  rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dxn, nullptr, M, head_scale(e));
+  gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dxn, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, M, e->d.vocab, e->d.d_model);
+  hipLaunchKernelGGL(qlm_ce_kernel, dim3(n_seq), dim3(256), 0, sd, e->logits, e->d.vocab, e->d.vocab, sl.d_labels,
+                     n_labels, sl.d_scores);
+  HIPCHK(e, hipMemcpyAsync(sl.h_scores, sl.d_scores, (size_t)n_seq * sizeof(float), hipMemcpyDeviceToHost, sd));
+  if ((rc = mark_decoder_done(e, sl))) return rc;
+  if ((rc = sync_all(e))) return rc;
+  sl.dec_pending = false;
   HIPCHK(e, hipGetLastError());
-  memcpy(out_scores, e->h_scores, (size_t)n_seq * sizeof(float));
+  memcpy(out_scores, sl.h_scores, (size_t)n_seq * sizeof(float));
   return RK_OK;
 }
 
@@ -704,11 +789,13 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
                  int dec_len, int max_new, int eos_id, int pad_id, int32_t* out_tokens, int32_t* out_steps) {
   int rc;
   if ((rc = rk_t5_stage(e, tokens, seq_offsets, n_seq))) return rc;
+  Slot& sl = e->slots[0];
   if (!dec_prefix || dec_len <= 0 || max_new <= 0 || dec_len + max_new - 1 > e->d.max_dec_len)
     return fail(e, RK_ERR_CAPACITY, "dec_len %d + max_new %d exceeds max_dec_len %d", dec_len, max_new, e->d.max_dec_len);
   if ((rc = check_ids(e, dec_prefix, dec_len, "decoder"))) return rc;
-  if ((rc = run_encoder(e))) return rc;
   if ((rc = ensure_logits(e, n_seq))) return rc;
+  if ((rc = encoder_then_handoff(e, sl))) return rc;
+  hipStream_t sd = dec_stream(e);
   // Per-row decoder ids grow by one token per step; the tiny decoder is recomputed over the whole prefix each
   // step (cross K/V are reused), which equals HF's KV-cached greedy loop (hf: generation/utils.py:2868-2935).
   std::vector<std::vector<int>> rows(n_seq, std::vector<int>(dec_prefix, dec_prefix + dec_len));
@@ -721,16 +808,16 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
     const int Ld = dec_len + t;
     flat.resize((size_t)n_seq * Ld);
     for (int b = 0; b < n_seq; ++b) { memcpy(&flat[(size_t)b * Ld], rows[b].data(), Ld * sizeof(int)); rowmap[b] = b * Ld + Ld - 1; }
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    HIPCHK(e, hipMemcpy(e->d_dec_ids, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(e, hipMemcpy(e->d_last_rows, rowmap.data(), n_seq * sizeof(int), hipMemcpyHostToDevice));
-    e->cache_dec.clear(); e->cache_lab.clear();
-    if ((rc = run_decoder(e, Ld))) return rc;
-    rmsnorm(e, e->dhidden, e->dec_final_ln, e->dlast, e->d_last_rows, n_seq, head_scale(e));
-    gemm(e, PC_HEAD, EPI_STORE_F32, e->dlast, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, n_seq, e->d.vocab, e->d.d_model);
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_seq), dim3(256), 0, e->stream, e->logits, e->d.vocab, e->d.vocab, e->d_argmax);
-    HIPCHK(e, hipMemcpyAsync(amax.data(), e->d_argmax, n_seq * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipStreamSynchronize(sd));
+    HIPCHK(e, hipMemcpy(sl.d_dec_ids, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(sl.d_last_rows, rowmap.data(), n_seq * sizeof(int), hipMemcpyHostToDevice));
+    sl.cache_dec.clear(); sl.cache_rows.clear();
+    if ((rc = run_decoder(e, sl, Ld))) return rc;
+    rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, n_seq, head_scale(e));
+    gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dlast, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, n_seq, e->d.vocab, e->d.d_model);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_seq), dim3(256), 0, sd, e->logits, e->d.vocab, e->d.vocab, sl.d_argmax);
+    HIPCHK(e, hipMemcpyAsync(amax.data(), sl.d_argmax, n_seq * sizeof(int), hipMemcpyDeviceToHost, sd));
+    HIPCHK(e, hipStreamSynchronize(sd));
     HIPCHK(e, hipGetLastError());
     ++steps;
     bool all_done = true;
@@ -743,6 +830,9 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
     }
     if (all_done) break;
   }
+  if ((rc = mark_decoder_done(e, sl))) return rc;
+  if ((rc = sync_all(e))) return rc;
+  sl.dec_pending = false;
   if (out_steps) *out_steps = steps;
   return RK_OK;
 }
@@ -751,7 +841,7 @@ int rk_timer_begin(rk_engine* e) {
   if (!e) return RK_ERR_INVALID;
   int rc = set_device(e);
   if (rc) return rc;
-  HIPCHK(e, hipEventRecord(e->t0, e->stream));
+  HIPCHK(e, hipEventRecord(e->t0, e->s_enc));      // callers synchronise before starting a timed region
   return RK_OK;
 }
 
@@ -759,7 +849,10 @@ int rk_timer_end(rk_engine* e, float* out_ms) {
   if (!e || !out_ms) return RK_ERR_INVALID;
   int rc = set_device(e);
   if (rc) return rc;
-  HIPCHK(e, hipEventRecord(e->t1, e->stream));
+  // stop event must follow the work of BOTH streams: chain the decoder stream behind the encoder stream's tail
+  HIPCHK(e, hipEventRecord(e->t_tmp, e->s_enc));
+  HIPCHK(e, hipStreamWaitEvent(e->s_dec, e->t_tmp, 0));
+  HIPCHK(e, hipEventRecord(e->t1, e->s_dec));
   HIPCHK(e, hipEventSynchronize(e->t1));
   HIPCHK(e, hipEventElapsedTime(out_ms, e->t0, e->t1));
   return RK_OK;
@@ -771,7 +864,7 @@ int rk_profile_reset(rk_engine* e) {
   if (!e) return RK_ERR_INVALID;
   int rc = set_device(e);
   if (rc) return rc;
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if ((rc = sync_all(e))) return rc;
   e->prof_used = 0;
   for (int c = 0; c < PC_COUNT; ++c) { e->prof_flops[c] = 0; e->prof_bytes[c] = 0; e->prof_n[c] = 0; }
   return RK_OK;
@@ -781,7 +874,7 @@ int rk_profile_get(rk_engine* e, int cls, double* total_ms, int64_t* launches, d
   if (!e || cls < 0 || cls >= PC_COUNT) return RK_ERR_INVALID;
   int rc = set_device(e);
   if (rc) return rc;
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if ((rc = sync_all(e))) return rc;
   double ms = 0;
   for (size_t i = 0; i < e->prof_used; ++i) {
     if (e->prof_recs[i].cls != cls) continue;
@@ -800,6 +893,12 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!e || !key) return RK_ERR_INVALID;
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value != 0; return RK_OK; }
+  if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
+    if (set_device(e) || sync_all(e)) return RK_ERR_HIP;
+    for (Slot& sl : e->slots) sl.dec_pending = false;
+    e->opt_overlap = value != 0;
+    return RK_OK;
+  }
   return fail(e, RK_ERR_INVALID, "unknown option %s", key);
 }
 
@@ -815,9 +914,9 @@ int rk_debug_gemm(rk_engine* e, const uint16_t* A, const uint16_t* W, float* C, 
   HIPCHK(e, hipMemcpy(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice));
   const int saved = e->opt_glds;
   e->opt_glds = use_glds;
-  gemm(e, PC_OTHER, EPI_STORE_F32, dA, K, dW, K, dC, N, M, N, K);
+  gemm(e, e->s_enc, PC_OTHER, EPI_STORE_F32, dA, K, dW, K, dC, N, M, N, K);
   e->opt_glds = saved;
-  HIPCHK(e, hipStreamSynchronize(e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->s_enc));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
   hipFree(dA); hipFree(dW); hipFree(dC);
@@ -827,16 +926,17 @@ int rk_debug_gemm(rk_engine* e, const uint16_t* A, const uint16_t* W, float* C, 
 int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_floats) {
   if (!e || !name || !out) return RK_ERR_INVALID;
   if (set_device(e)) return RK_ERR_HIP;
-  if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, RK_ERR_HIP, "sync failed");
+  if (sync_all(e)) return RK_ERR_HIP;
+  const Slot& sl = e->slots[0];
   const std::string n(name);
   const int I = e->inner, dm = e->d.d_model;
   const void* src = nullptr; int64_t cnt = 0; bool is_half = true;
-  if (n == "enc_hidden") { src = e->hidden; cnt = (int64_t)e->T * dm; is_half = false; }
-  else if (n == "enc_out") { src = e->enc_out; cnt = (int64_t)e->T * dm; }
-  else if (n == "qkv") { src = e->qkv; cnt = (int64_t)e->T * 3 * I; }
-  else if (n == "ctx") { src = e->ctx; cnt = (int64_t)e->T * I; }
-  else if (n == "xn") { src = e->xn; cnt = (int64_t)e->T * dm; }
-  else if (n == "dec_hidden") { src = e->dhidden; cnt = (int64_t)e->n_seq * e->d.max_dec_len * dm; is_half = false; }
+  if (n == "enc_hidden") { src = e->hidden; cnt = (int64_t)sl.T * dm; is_half = false; }
+  else if (n == "enc_out") { src = e->enc_out; cnt = (int64_t)sl.T * dm; }
+  else if (n == "qkv") { src = e->qkv; cnt = (int64_t)sl.T * 3 * I; }
+  else if (n == "ctx") { src = e->ctx; cnt = (int64_t)sl.T * I; }
+  else if (n == "xn") { src = e->xn; cnt = (int64_t)sl.T * dm; }
+  else if (n == "dec_hidden") { src = sl.dhidden; cnt = (int64_t)sl.n_seq * e->d.max_dec_len * dm; is_half = false; }
   else return fail(e, RK_ERR_INVALID, "unknown buffer %s", name);
   cnt = std::min(cnt, max_floats);
   if (is_half) {

@@ -45,6 +45,10 @@ ABI = {
     "rk_t5_stage": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int]),
     "rk_t5_score_staged": (C.c_int, [C.c_void_p, _i32p, C.c_int, _i32p, C.c_int]),
     "rk_engine_sync": (C.c_int, [C.c_void_p]),
+    "rk_engine_num_slots": (C.c_int, []),
+    "rk_t5_stage_slot": (C.c_int, [C.c_void_p, C.c_int, _i32p, _i32p, C.c_int]),
+    "rk_t5_score_slot": (C.c_int, [C.c_void_p, C.c_int, _i32p, C.c_int, _i32p, C.c_int]),
+    "rk_t5_read_scores_slot": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.c_int]),
     "rk_t5_read_scores": (C.c_int, [C.c_void_p, _f32p, C.c_int]),
     "rk_t5_scores_device_ptr": (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
     "rk_timer_begin": (C.c_int, [C.c_void_p]),
@@ -191,22 +195,29 @@ class RkEngine:
         return out, int(steps.value)
 
     # -- staged / async form (bench, multi-GPU) --------------------------------------------------------
-    def stage(self, seqs: Sequence[Sequence[int]]):
-        tok, off = pack_ragged(seqs)
-        self._chk(self.lib.rk_t5_stage(self.h, tok.ctypes.data_as(_i32p), off.ctypes.data_as(_i32p), len(seqs)))
-        self._staged_n = len(seqs)
+    @property
+    def num_slots(self) -> int:
+        return int(self.lib.rk_engine_num_slots())
 
-    def score_staged(self, dec_prefix: Sequence[int], out_ids: Sequence[int]):
+    def stage(self, seqs: Sequence[Sequence[int]], slot: int = 0):
+        tok, off = pack_ragged(seqs)
+        self._chk(self.lib.rk_t5_stage_slot(self.h, slot, tok.ctypes.data_as(_i32p), off.ctypes.data_as(_i32p), len(seqs)))
+        self._slot_shape = getattr(self, "_slot_shape", {})
+        self._slot_shape[slot] = [len(seqs), 0]
+
+    def score_staged(self, dec_prefix: Sequence[int], out_ids: Sequence[int], slot: int = 0):
+        """Enqueue encoder (encoder stream) + decoder/head (decoder stream) for the slot's batch; returns at once."""
         dp, oi = _i32(dec_prefix), _i32(out_ids)
-        self._last_n_out = len(oi)
-        self._chk(self.lib.rk_t5_score_staged(self.h, dp.ctypes.data_as(_i32p), len(dp), oi.ctypes.data_as(_i32p), len(oi)))
+        self._slot_shape[slot][1] = len(oi)
+        self._chk(self.lib.rk_t5_score_slot(self.h, slot, dp.ctypes.data_as(_i32p), len(dp), oi.ctypes.data_as(_i32p), len(oi)))
 
     def sync(self):
         self._chk(self.lib.rk_engine_sync(self.h))
 
-    def read_scores(self) -> np.ndarray:
-        out = np.empty((self._staged_n, self._last_n_out), dtype=np.float32)
-        self._chk(self.lib.rk_t5_read_scores(self.h, out.ctypes.data_as(_f32p), out.size))
+    def read_scores(self, slot: int = 0) -> np.ndarray:
+        n, k = self._slot_shape[slot]
+        out = np.empty((n, k), dtype=np.float32)
+        self._chk(self.lib.rk_t5_read_scores_slot(self.h, slot, out.ctypes.data_as(_f32p), out.size))
         return out
 
     def scores_device_ptr(self) -> int:
