@@ -29,7 +29,7 @@ def _softmax_first(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 class PointwiseLlmRanker(LlmRanker):
 
     def __init__(self, model_name_or_path, tokenizer_name_or_path, device, method="qlm", batch_size=1, cache_dir=None,
-                 _runtime=None, _tokenizer=None):
+                 _runtime=None, _tokenizer=None, shard_candidates=False):
         # ref: pointwise.py:13-34.  `_runtime` / `_tokenizer` are test seams; production builds the HIP engine.
         if _tokenizer is None:
             from transformers import T5Tokenizer
@@ -45,6 +45,10 @@ class PointwiseLlmRanker(LlmRanker):
         self.device = device
         self.method = method
         self.batch_size = batch_size
+        # opt-in data parallelism (one process per GPU under torchrun): each rank scores a contiguous chunk of the
+        # candidate list, one all_gather collects the scores (llmrankers/_dist.py).  Counters then describe the
+        # local chunk; scores and rank order are identical to a single-GPU run.
+        self.shard_candidates = shard_candidates
         self.total_compare = 0
         self.total_completion_tokens = 0
         self.total_prompt_tokens = 0
@@ -64,7 +68,29 @@ class PointwiseLlmRanker(LlmRanker):
             self.total_prompt_tokens += len(chunk) * dec_len     # decoder inputs count as prompt (ref :68,114)
             yield s, chunk
 
+    def _rerank_sharded(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
+        from . import _dist
+
+        def score_chunk(chunk):
+            if not len(chunk):
+                return []
+            saved, self.shard_candidates = self.shard_candidates, False
+            try:
+                self.rerank(query, list(chunk))          # mutates the chunk's objects in place
+            finally:
+                self.shard_candidates = saved
+            return [d.score for d in chunk]
+
+        scores = _dist.sharded_scores(score_chunk, ranking)
+        for doc, sc in zip(ranking, scores):
+            doc.score = float(sc)
+        return sorted(ranking, key=lambda x: x.score, reverse=True)
+
     def rerank(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
+        if self.shard_candidates:
+            from . import _dist
+            if _dist.world()[1] > 1:
+                return self._rerank_sharded(query, ranking)
         self._reset()
         if self.method == "qlm":
             # ref: pointwise.py:41-82 — score = -sum_t CE(label_t), labels = "<pad> {query}" without specials

@@ -1,0 +1,73 @@
+"""Multi-process candidate sharding on CPU: world_size 2, gloo backend, rendezvous on 127.0.0.1.
+
+Exercises the N>1 path of the pointwise ranker (llmrankers/_dist.py): contiguous shards, one all_gather, identical
+scores and rank order on every rank and identical to the single-process result.  The model is the oracle-backed
+test stub (no GPU here); on the GPU box the same code runs with backend 'nccl' (= RCCL over xGMI)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import GOLD, REPO
+
+
+def test_shard_bounds():
+    from llmrankers._dist import shard_bounds
+    assert [e - s for s, e in shard_bounds(100, 8)] == [13, 13, 13, 13, 12, 12, 12, 12]
+    assert shard_bounds(3, 4) == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    assert shard_bounds(0, 2) == [(0, 0), (0, 0)]
+    for n in (1, 7, 100, 101):
+        for w in (1, 2, 3, 8):
+            b = shard_bounds(n, w)
+            assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+
+
+WORKER = r'''
+import json, os, sys
+sys.path[:0] = [os.path.join(sys.argv[1], "llm-rankers_amd"), sys.argv[1], os.path.join(sys.argv[1], "tests")]
+import torch.distributed as dist
+from conftest import load_state
+from _stub import OracleRuntime
+from llmrankers import _synth
+from llmrankers.rankers import SearchResult
+from llmrankers.pointwise import PointwiseLlmRanker
+from transformers import T5Tokenizer
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=int(sys.argv[4]))
+ck = sys.argv[5]
+dims, state = load_state(ck)
+case = json.load(open(sys.argv[6]))
+tok = T5Tokenizer.from_pretrained(ck)
+rk = PointwiseLlmRanker(None, None, "cuda", method=case["method"], batch_size=case["batch_size"],
+                        _runtime=OracleRuntime(dims, state), _tokenizer=tok, shard_candidates=True)
+ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+res = rk.rerank(case["query"], ranking)
+print("RESULT " + json.dumps([[r.docid, r.score] for r in res]))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sharded_rerank_matches_reference(ckpt_dirs, tmp_path):
+    with open(os.path.join(GOLD, "rerank_cases.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["kind"] == "pointwise" and c["ckpt"] == "ckpt_gated_untied"]
+    case = next(c for c in cases if c["method"] == "yes_no" and len(c["input"]) == 13)   # 13 docs -> shards of 7 and 6
+    cpath = tmp_path / "case.json"
+    cpath.write_text(json.dumps(case))
+    wpath = tmp_path / "worker.py"
+    wpath.write_text(WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(wpath), REPO, str(port), str(r), "2", ckpt_dirs["ckpt_gated_untied"], str(cpath)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(json.loads(next(l for l in out.splitlines() if l.startswith("RESULT "))[7:]))
+    assert outs[0] == outs[1]                                          # every rank holds the same final ranking
+    assert [d for d, _ in outs[0]] == [d for d, _ in case["result"]]   # = the reference's order
+    np.testing.assert_allclose([s for _, s in outs[0]], [s for _, s in case["result"]], atol=2e-5)
