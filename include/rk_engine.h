@@ -120,6 +120,9 @@ int rk_abi_version(void);
 int rk_rel_bucket(int relative_position, int bidirectional, int num_buckets, int max_distance);
 /* debug: run one GEMM through the engine's kernel on host data (A[M,K] fp16, W[N,K] fp16 -> C[M,N] fp32) */
 int rk_debug_gemm(rk_engine* e, const uint16_t* A, const uint16_t* W, float* C, int M, int N, int K, int use_glds);
+/* measurement: average ms per launch of the engine's GEMM kernel at one shape (epi = 0 store f16, 1 residual f32,
+ * 2 GEGLU, 3 ReLU, 4 store f32), random operands, `iters` back-to-back launches timed with HIP events */
+int rk_debug_gemm_bench(rk_engine* e, int M, int N, int K, int epi, int iters, float* out_ms);
 /* debug: copy an internal activation buffer to the host as fp32. name: "enc_hidden" [T,d], "enc_out" [T,d],
  * "qkv" [T,3I], "ctx" [T,I], "dec_hidden" [B*Ld,d]. Returns number of floats written or a negative status. */
 int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_floats);

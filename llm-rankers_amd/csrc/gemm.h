@@ -38,10 +38,11 @@ struct GemmArgs {
 #define GEMM_LDS_BYTES (2 * 2 * GEMM_TILE_HALFS * 2)   // 2 stages x {A,W} x 16 KiB = 64 KiB
 
 __device__ __forceinline__ float gelu_new_f(float x) {
-  // hf: activations.py:59-66
-  const float c = 0.7978845608028654f;
-  float u = c * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(u));
+  // hf: activations.py:59-66:  0.5 x (1 + tanh(u)),  u = sqrt(2/pi) (x + 0.044715 x^3).
+  // 0.5 (1 + tanh u) == 1 / (1 + exp(-2u)) exactly; evaluated with the hardware exp2 / rcp (about 1e-6 relative,
+  // far below the fp16 rounding of the result) instead of libm tanhf, which cost ~200 cycles per output here.
+  const float u2 = -1.5957691216057308f * (x + 0.044715f * x * x * x);   // -2u
+  return x * __frcp_rn(1.0f + __expf(u2));
 }
 
 template <bool GLDS>
@@ -77,6 +78,24 @@ __device__ __forceinline__ void gemm_write_tile(half_t* s_tile, int wave, int la
 
 __device__ __forceinline__ half8 gemm_frag(const half_t* s_tile, int r, int cc) {
   return *(const half8*)(s_tile + r * 64 + ((cc ^ ((r >> 1) & 7)) << 3));
+}
+
+// XCD-aware, L2-friendly tile order.  Block b runs on XCD b%8 and an XCD starts its blocks in increasing b, about
+// one (v2) or two (v1) per CU at a time.  Each XCD is handed a contiguous run of a GROUPED tile list - column panels
+// of GROUP_N tiles, row-major inside a panel - so the ~32 workgroups co-resident on one XCD form a compact
+// (32/GROUP_N rows x GROUP_N cols) block of the output and share A / W panels through that XCD's private L2.
+// Bijective for any grid size.
+#define GEMM_GROUP_N 8
+__device__ __forceinline__ void gemm_tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int per_panel = tiles_m * GEMM_GROUP_N;
+  const int pn = lin / per_panel, rem = lin - pn * per_panel;
+  const int w = min(GEMM_GROUP_N, tiles_n - pn * GEMM_GROUP_N);
+  tm = rem / w;
+  tn = pn * GEMM_GROUP_N + rem - tm * w;
 }
 
 // Epilogue shared by the tiled and the skinny kernel.  acc[ni][mi] are 32x32 MFMA C fragments of a 64(n) x 64(m)
@@ -136,6 +155,88 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
   }
 }
 
+// LDS-staged epilogue for the tiled kernels.  A lane's accumulators are 4-column pieces of 32 different rows, so
+// storing them directly makes every store instruction touch 32+ cache lines with 8-byte pieces (measured: ~10 us
+// of a 35 us tile).  Instead each wave drops one 32-row slab (32 x NI*32 outputs) at a time into a wave-private LDS
+// region (the main-loop stages are dead by then) and writes it back with 16 bytes per lane along the rows, i.e.
+// whole 64..256-byte row segments per instruction; the fp32 residual add reads the old row the same way.
+// `stage` = this wave's LDS region, at least 32 * (NI*32*4 + 16) bytes.
+template <int EPI, int NI, int MI>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase,
+                                                     int lane, unsigned char* stage) {
+  const int l31 = lane & 31, hh = lane >> 5;
+  constexpr bool GEGLU = EPI == EPI_GEGLU_F16;
+  constexpr bool F32 = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32;
+  constexpr int COLS = GEGLU ? NI * 16 : NI * 32;            // output columns of this wave
+  constexpr int ELT = F32 ? 4 : 2;
+  constexpr int ROWB = COLS * ELT + 16;                        // padded LDS row (bytes), 16-B aligned
+  constexpr int CHUNKS = COLS * ELT / 16;                      // 16-B pieces per row
+  constexpr int ROWS_PER_PASS = 64 / CHUNKS;
+  const int ncol0 = GEGLU ? (nbase >> 1) : nbase;
+  const int nlimit = GEGLU ? (p.N >> 1) : p.N;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    // ---- registers -> LDS (row l31 of the slab) ----
+    unsigned char* myrow = stage + l31 * ROWB;
+    if (GEGLU) {
+#pragma unroll
+      for (int g = 0; g < NI / 2; ++g)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          half4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = f2h_sat(gelu_new_f(acc[2 * g][mi][4 * q + j] * p.scale) * (acc[2 * g + 1][mi][4 * q + j] * p.scale));
+          *(half4*)(myrow + (g * 32 + 8 * q + 4 * hh) * 2) = o;
+        }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = ni * 32 + 8 * q + 4 * hh;
+          if (F32) {
+            f32x4 o = {acc[ni][mi][4 * q] * p.scale, acc[ni][mi][4 * q + 1] * p.scale, acc[ni][mi][4 * q + 2] * p.scale,
+                       acc[ni][mi][4 * q + 3] * p.scale};
+            *(f32x4*)(myrow + c * 4) = o;
+          } else {
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float v = acc[ni][mi][4 * q + j] * p.scale;
+              o[j] = f2h_sat(EPI == EPI_RELU_F16 ? fmaxf(v, 0.f) : v);
+            }
+            *(half4*)(myrow + c * 2) = o;
+          }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are done (region is wave-private)
+    __builtin_amdgcn_wave_barrier();
+    // ---- LDS -> global, 16 B per lane along the rows ----
+#pragma unroll
+    for (int r0 = 0; r0 < 32; r0 += ROWS_PER_PASS) {
+      const int row = r0 + lane / CHUNKS, ch = lane % CHUNKS;
+      const int m = mbase + mi * 32 + row;
+      int n = ncol0 + ch * (16 / ELT);
+      if (lane / CHUNKS < ROWS_PER_PASS && row < 32 && m < p.M && n < nlimit) {
+        const unsigned char* sp = stage + row * ROWB + ch * 16;
+        size_t base = 0;
+        if (p.n_split > 0) { base = (size_t)(n / p.n_split) * (size_t)p.split_stride; n = n % p.n_split; }
+        if (F32) {
+          float* c = (float*)p.C + base + (size_t)m * p.ldc + n;
+          f32x4 v = *(const f32x4*)sp;
+          if (EPI == EPI_RESID_F32) { const f32x4 old = *(const f32x4*)c; v = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]}; }
+          *(f32x4*)c = v;
+        } else {
+          *(half8*)((half_t*)p.C + base + (size_t)m * p.ldc + n) = *(const half8*)sp;
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();      // slab fully read before the next one overwrites it
+  }
+}
+
 template <int EPI, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
@@ -143,8 +244,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, hh = lane >> 5;
   const int wm = wave & 1, wn = wave >> 1;
-  const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM;
-  const int tm = blockIdx.x % tiles_m, tn = blockIdx.x / tiles_m;
+  const int tiles_m = (p.M + GEMM_BM - 1) / GEMM_BM, tiles_n = (p.N + GEMM_BN - 1) / GEMM_BN;
+  int tm, tn;
+  gemm_tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
 
   f32x16 acc[2][2];
@@ -196,7 +298,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
     }
   }
 
-  gemm_epilogue<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, l31, hh);
+  __syncthreads();   // every wave is done reading the last stage: LDS becomes the epilogue staging area
+  gemm_epilogue_staged<EPI, 2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, gemm_smem + wave * (32 * (64 * 4 + 16)));
 }
 
 // ---- skinny GEMM: M <= 32 rows (the single-step decoder: M = sequences in the batch) ----------------------------
@@ -271,4 +374,105 @@ __global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p)
     __syncthreads();
   }
   if (wave == 0) gemm_epilogue<EPI, NT, 1>(p, acc, 0, n0, l31, hh);
+}
+
+// ================================= GEMM v2: 256-row tiles ==================================================
+// Why: a 128x128 tile needs 8138/128 = 64 B/clk/CU of L2->LDS fill to run the MFMA pipe at peak, more than the ~56
+// B/clk/CU a CU can pull (measured: MFMA busy 25 %, PMC in profiles/); a 256-wide tile halves that.  Structure:
+//   * 512 threads = 8 waves as WM x WN, wave tile (MI*32) x (NI*32), fp32 accumulators in registers;
+//   * K step of 64 (four MFMA k16 steps): tile rows are 128 B = one full cache line per DMA row (a 64-B row makes
+//     every line travel L2->L1 twice), LDS image and XOR swizzle identical to the 128x128 kernel (conflict-free);
+//   * two LDS stages; the DMA loads of k-tile t+1 are issued DURING the compute of tile t, one load after every
+//     second MFMA of the first two k16 steps, so their issue cost hides under matrix-pipe time and they have the
+//     rest of the step to land; one raw s_barrier per K step;
+//   * XCD-aware tile order: block b runs on XCD b%8, and each XCD is handed a contiguous run of the tm-major tile
+//     list, so the workgroups co-resident on one XCD share A / W panels through its private 4 MiB L2.
+template <int EPI, int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(512, 2) void gemm_v2_kernel(GemmArgs p) {
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  constexpr int A_HALFS = BM * 64, W_HALFS = BN * 64, STAGE_HALFS = A_HALFS + W_HALFS;
+  constexpr int A_INSTR = BM / 8, W_INSTR = BN / 8;            // one DMA instruction = 64 x 16 B = 8 tile rows
+  constexpr int A_PW = A_INSTR / 8, W_PW = (W_INSTR + 7) / 8;  // per wave per stage
+  constexpr int LOADS = A_PW + W_PW;
+  static_assert(WM * WN == 8 && A_INSTR % 8 == 0, "8 waves; A tile must split evenly");
+  constexpr int ISSUE_STRIDE = (3 * MI * NI) / LOADS;           // DMA issues spread over the first three k16 steps
+  static_assert(ISSUE_STRIDE >= 1, "not enough MFMA slots to hide the DMA issues");
+  extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+  half_t* smem = (half_t*)gemm_smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int wm = wave % WM, wn = wave / WM;
+
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  int tm, tn;
+  gemm_tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- per-lane DMA source pointers (k offset added per stage) and LDS destinations ----
+  const half_t* src[LOADS];
+  int dst[LOADS];
+#pragma unroll
+  for (int j = 0; j < LOADS; ++j) {
+    const bool isA = j < A_PW;
+    int instr = isA ? (wave * A_PW + j) : (wave * W_PW + (j - A_PW));
+    if (!isA) instr = instr % W_INSTR;                           // uneven split: duplicate a load (same bytes)
+    const int row = instr * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int grow = (isA ? m0 : n0) + row;
+    const int lim = isA ? p.M : p.N;
+    grow = grow < lim ? grow : lim - 1;
+    src[j] = (isA ? p.A + (size_t)grow * p.lda : p.W + (size_t)grow * p.ldw) + chunk * 8;
+    dst[j] = (isA ? 0 : A_HALFS) + instr * 512;
+  }
+  auto issue = [&](int j, int kt) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + kt * 64),
+                                     (__attribute__((address_space(3))) void*)(smem + (kt & 1) * STAGE_HALFS + dst[j]),
+                                     16, 0, 0);
+  };
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K >> 6;
+#pragma unroll
+  for (int j = 0; j < LOADS; ++j) issue(j, 0);
+  int arow[MI], wrow[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) arow[i] = (wm * MI * 32 + i * 32 + l31);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) wrow[i] = (wn * NI * 32 + i * 32 + l31);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA for tile kt has landed
+    __builtin_amdgcn_s_barrier();                       // ... everyone's has; stage (kt+1)&1 is free again
+    __builtin_amdgcn_sched_barrier(0);
+    const half_t* sA = smem + (kt & 1) * STAGE_HALFS;
+    const half_t* sW = sA + A_HALFS;
+    const bool more = kt + 1 < nk;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      half8 af[MI], wf[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[i] = gemm_frag(sW, wrow[i], ks * 2 + hh);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = gemm_frag(sA, arow[i], ks * 2 + hh);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+          const int slot = ks * (MI * NI) + ni * MI + mi;     // compile-time after unrolling
+          if (slot % ISSUE_STRIDE == 0 && slot / ISSUE_STRIDE < LOADS && more) issue(slot / ISSUE_STRIDE, kt + 1);
+        }
+    }
+  }
+  __syncthreads();   // every wave is done reading the last stage: LDS becomes the epilogue staging area
+  gemm_epilogue_staged<EPI, NI, MI>(p, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, lane,
+                                    gemm_smem + wave * (32 * (NI * 32 * 4 + 16)));
 }

@@ -51,9 +51,13 @@ struct ProfRec { hipEvent_t a, b; int cls; };
 
 #define RK_SLOTS 2
 
-// Everything that belongs to ONE batch in flight.  The encoder workspace is shared (encoders run back to back on
-// the encoder stream); what the decoder of batch i needs while the encoder of batch i+1 already runs lives here.
+// Everything that belongs to ONE batch in flight: own activation workspace and own pair of HIP streams.  Two slots
+// let (a) the latency-bound decoder chain of one batch hide under the MFMA-bound encoder of the next and (b) the
+// encoder kernels of both batches co-run, so workgroups of one fill the tile-quantisation tail of the other
+// (1104 GEMM tiles on 512 resident slots is 3 rounds alone but 2.16 rounds of work).
 struct Slot {
+  hipStream_t se = nullptr, sd = nullptr;   // this slot's encoder chain (MFMA-bound) | decoder chain (latency-bound)
+  float* hidden = nullptr; half_t *xn = nullptr, *qkv = nullptr, *ctx = nullptr, *ffh = nullptr, *enc_out = nullptr;
   int* d_tokens = nullptr; int* d_seq_off = nullptr;
   int n_seq = 0, T = 0, maxL = 0; bool staged = false; int last_n_out = 0;
   half_t* cross_kv = nullptr;                                  // [n_dec][max_tokens][2I] encoder -> decoder hand-off
@@ -68,7 +72,6 @@ struct Slot {
 struct rk_engine {
   rk_model_desc d{};
   int dev = 0;
-  hipStream_t s_enc = nullptr, s_dec = nullptr;   // MFMA-bound encoder chain | latency-bound decoder chain
   std::string err;
   bool finalized = false;
   int inner = 0;
@@ -79,13 +82,11 @@ struct rk_engine {
   std::vector<EncLayerW> enc;
   std::vector<DecLayerW> dec;
   float *enc_final_ln = nullptr, *dec_final_ln = nullptr, *lut_enc = nullptr, *lut_dec = nullptr;
-  // shared encoder workspace
-  float* hidden = nullptr; half_t *xn = nullptr, *qkv = nullptr, *ctx = nullptr, *ffh = nullptr, *enc_out = nullptr;
   float* logits = nullptr; size_t logits_cap = 0;              // full-vocabulary paths (qlm, greedy); slot 0 only
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 1, opt_overlap = 1;
+  int opt_glds = 1, opt_skinny = 1, opt_overlap = 1, opt_gemm_variant = 0;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
@@ -145,11 +146,46 @@ struct Bracket {
   ~Bracket() { if (idx >= 0) hipEventRecord(e->prof_recs[idx].b, st); }
 };
 
-hipStream_t dec_stream(rk_engine* e) { return e->opt_overlap ? e->s_dec : e->s_enc; }
+// overlap = 0 puts every launch of every slot on ONE stream (serial timeline, used for per-kernel event timing)
+hipStream_t enc_stream(rk_engine* e, Slot& sl) { return e->opt_overlap ? sl.se : e->slots[0].se; }
+hipStream_t dec_stream(rk_engine* e, Slot& sl) { return e->opt_overlap ? sl.sd : e->slots[0].se; }
 
 // ---- kernel launch helpers ------------------------------------------------------------------------------
+template <int EPI, int WM, int WN, int MI, int NI>
+void launch_v2(hipStream_t st, const GemmArgs& a) {
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  constexpr int smem = 2 * (BM + BN) * 64 * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t rc = hipFuncSetAttribute((const void*)gemm_v2_kernel<EPI, WM, WN, MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (rc != hipSuccess) fprintf(stderr, "[rk_engine] hipFuncSetAttribute(%d B LDS) failed: %s\n", smem, hipGetErrorString(rc));
+    attr_done = true;
+  }
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL((gemm_v2_kernel<EPI, WM, WN, MI, NI>), dim3(tiles), dim3(512), smem, st, a);
+}
+
+// Tile-shape choice.  variant: 0 = auto, 1 = 128x128 (v1), 2 = 256x256, 3 = 256x192, 4 = 256x128 (v2 kernels).
+// auto = what measured fastest per shape class on MI355X at M = 5888 (tools/gemm_bench.py, profiles/r01c_gemm_bench.txt):
+// wide outputs -> 256x256; N around 3k -> 256x192 (more tiles for the 256 CUs); narrow N -> 256x128; too few 256-row
+// tiles to occupy the chip -> 128x128 at two workgroups per CU.  GEGLU pairs gate/up inside 64-row wave tiles (NI even).
+int choose_variant(const rk_engine* e, int epi, int M, int N, int K) {
+  (void)K;
+  if (e->opt_gemm_variant) return (e->opt_gemm_variant == 3 && epi == EPI_GEGLU_F16) ? 2 : e->opt_gemm_variant;
+  const long tm = (M + 255) / 256;
+  int v = N >= 4096 ? 2 : (N >= 2048 ? 3 : 4);
+  if (v == 3 && epi == EPI_GEGLU_F16) v = 2;
+  const int bn = v == 2 ? 256 : (v == 3 ? 192 : 128);
+  if (tm * ((N + bn - 1) / bn) < 96) return 1;
+  return v;
+}
+
 template <int EPI>
 void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
+  const int variant = choose_variant(e, EPI, a.M, a.N, a.K);
+  if (variant == 2) { launch_v2<EPI, 2, 4, 4, 2>(st, a); return; }
+  if (variant == 3 && EPI != EPI_GEGLU_F16) { launch_v2<EPI, 4, 2, 2, 3>(st, a); return; }
+  if (variant == 4) { launch_v2<EPI, 4, 2, 2, 2>(st, a); return; }
   const int tiles = ((a.M + GEMM_BM - 1) / GEMM_BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
   if (e->opt_glds)
     hipLaunchKernelGGL((gemm_f16_kernel<EPI, true>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);
@@ -253,29 +289,29 @@ int upload_small(rk_engine* e, Slot& sl, hipStream_t st, std::vector<int>* cache
 // cross-attention K/V projections of all decoder layers (:325-326 with key_value_states = encoder output).
 int run_encoder(rk_engine* e, Slot& sl) {
   const rk_model_desc& d = e->d;
-  hipStream_t st = e->s_enc;
+  hipStream_t st = enc_stream(e, sl);
   const int T = sl.T, I = e->inner, dm = d.d_model, F = d.d_ff;
-  embed(e, st, sl.d_tokens, e->hidden, T);
+  embed(e, st, sl.d_tokens, sl.hidden, T);
   for (int l = 0; l < d.n_enc_layers; ++l) {
     const EncLayerW& w = e->enc[l];
-    rmsnorm(e, st, e->hidden, w.ln0, e->xn, nullptr, T);
-    gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, e->xn, dm, w.qkv, dm, e->qkv, 3 * I, T, 3 * I, dm);
+    rmsnorm(e, st, sl.hidden, w.ln0, sl.xn, nullptr, T);
+    gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xn, dm, w.qkv, dm, sl.qkv, 3 * I, T, 3 * I, dm);
     {
-      AttnEncArgs a{e->qkv, e->ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I};
+      AttnEncArgs a{sl.qkv, sl.ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I};
       const double att_flops = 4.0 * (double)sl.maxL * T * I;   // exact for uniform lengths, upper bound if ragged
       Bracket br(e, st, PC_ENC_ATTN, att_flops, (double)T * 4 * I * 2.0);
       hipLaunchKernelGGL(attn_enc_kernel, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
     }
-    gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, e->ctx, I, w.o, I, e->hidden, dm, T, dm, I);
-    rmsnorm(e, st, e->hidden, w.ln1, e->xn, nullptr, T);
+    gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, I, w.o, I, sl.hidden, dm, T, dm, I);
+    rmsnorm(e, st, sl.hidden, w.ln1, sl.xn, nullptr, T);
     if (d.gated_gelu)
-      gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_GEGLU_F16, e->xn, dm, w.ffn_in, dm, e->ffh, F, T, 2 * F, dm);
+      gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_GEGLU_F16, sl.xn, dm, w.ffn_in, dm, sl.ffh, F, T, 2 * F, dm);
     else
-      gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_RELU_F16, e->xn, dm, w.ffn_in, dm, e->ffh, F, T, F, dm);
-    gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, e->ffh, F, w.ffn_out, F, e->hidden, dm, T, dm, F);
+      gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_RELU_F16, sl.xn, dm, w.ffn_in, dm, sl.ffh, F, T, F, dm);
+    gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, sl.ffh, F, w.ffn_out, F, sl.hidden, dm, T, dm, F);
   }
-  rmsnorm(e, st, e->hidden, e->enc_final_ln, e->enc_out, nullptr, T);
-  gemm(e, st, PC_GEMM_CROSS_KV, EPI_STORE_F16, e->enc_out, dm, e->cross_kv_w, dm, sl.cross_kv, 2 * I, T,
+  rmsnorm(e, st, sl.hidden, e->enc_final_ln, sl.enc_out, nullptr, T);
+  gemm(e, st, PC_GEMM_CROSS_KV, EPI_STORE_F16, sl.enc_out, dm, e->cross_kv_w, dm, sl.cross_kv, 2 * I, T,
        d.n_dec_layers * 2 * I, dm, 2 * I, (long)d.max_tokens * 2 * I);
   HIPCHK(e, hipGetLastError());
   return RK_OK;
@@ -285,7 +321,7 @@ int run_encoder(rk_engine* e, Slot& sl) {
 // device in sl.d_dec_ids, row = b*Ld + t).  Leaves the residual stream in sl.dhidden.
 int run_decoder(rk_engine* e, Slot& sl, int Ld) {
   const rk_model_desc& d = e->d;
-  hipStream_t st = dec_stream(e);
+  hipStream_t st = dec_stream(e, sl);
   const int B = sl.n_seq, M = B * Ld, I = e->inner, dm = d.d_model, F = d.d_ff;
   embed(e, st, sl.d_dec_ids, sl.dhidden, M);
   const size_t smem_self = (64 + 256 + 8 + (size_t)Ld) * sizeof(float);
@@ -327,25 +363,28 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
 // Encoder on s_enc, decoder on s_dec, ordered by events; the decoder of this slot's PREVIOUS batch must have
 // finished reading cross_kv before the encoder overwrites it.
 int encoder_then_handoff(rk_engine* e, Slot& sl) {
-  if (sl.dec_pending && dec_stream(e) != e->s_enc) HIPCHK(e, hipStreamWaitEvent(e->s_enc, sl.ev_dec, 0));
+  hipStream_t se = enc_stream(e, sl), sd = dec_stream(e, sl);
+  if (sl.dec_pending && sd != se) HIPCHK(e, hipStreamWaitEvent(se, sl.ev_dec, 0));
   int rc = run_encoder(e, sl);
   if (rc) return rc;
-  if (dec_stream(e) != e->s_enc) {
-    HIPCHK(e, hipEventRecord(sl.ev_enc, e->s_enc));
-    HIPCHK(e, hipStreamWaitEvent(dec_stream(e), sl.ev_enc, 0));
+  if (sd != se) {
+    HIPCHK(e, hipEventRecord(sl.ev_enc, se));
+    HIPCHK(e, hipStreamWaitEvent(sd, sl.ev_enc, 0));
   }
   return RK_OK;
 }
 
 int mark_decoder_done(rk_engine* e, Slot& sl) {
-  HIPCHK(e, hipEventRecord(sl.ev_dec, dec_stream(e)));
+  HIPCHK(e, hipEventRecord(sl.ev_dec, dec_stream(e, sl)));
   sl.dec_pending = true;
   return RK_OK;
 }
 
 int sync_all(rk_engine* e) {
-  HIPCHK(e, hipStreamSynchronize(e->s_enc));
-  HIPCHK(e, hipStreamSynchronize(e->s_dec));
+  for (Slot& sl : e->slots) {
+    HIPCHK(e, hipStreamSynchronize(sl.se));
+    HIPCHK(e, hipStreamSynchronize(sl.sd));
+  }
   return RK_OK;
 }
 
@@ -395,7 +434,7 @@ int check_ids(rk_engine* e, const int32_t* ids, int n, const char* what) {
 int upload_dec_ids_shared(rk_engine* e, Slot& sl, const int32_t* prefix, int Ld) {
   std::vector<int> ids((size_t)sl.n_seq * Ld);
   for (int b = 0; b < sl.n_seq; ++b) memcpy(&ids[(size_t)b * Ld], prefix, Ld * sizeof(int));
-  hipStream_t st = dec_stream(e);
+  hipStream_t st = dec_stream(e, sl);
   if (ids.size() > 8192) {   // larger than a pinned slot: plain synchronous copy
     HIPCHK(e, hipStreamSynchronize(st));
     HIPCHK(e, hipMemcpy(sl.d_dec_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -414,7 +453,7 @@ int stage_slot(rk_engine* e, int slot, const int32_t* tokens, const int32_t* seq
   if ((rc = check_batch(e, sl, tokens, seq_offsets, n_seq))) return rc;
   // the slot's previous batch (encoder reads tokens, decoder reads seq_off) must be done before overwriting
   if (sl.dec_pending) { HIPCHK(e, hipEventSynchronize(sl.ev_dec)); sl.dec_pending = false; }
-  HIPCHK(e, hipStreamSynchronize(e->s_enc));
+  HIPCHK(e, hipStreamSynchronize(enc_stream(e, sl)));
   HIPCHK(e, hipMemcpy(sl.d_tokens, tokens, (size_t)sl.T * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(e, hipMemcpy(sl.d_seq_off, seq_offsets, (size_t)(n_seq + 1) * sizeof(int), hipMemcpyHostToDevice));
   sl.staged = true;
@@ -430,7 +469,7 @@ int score_slot(rk_engine* e, int slot, const int32_t* dec_prefix, int dec_len, c
   if (!dec_prefix || dec_len <= 0 || dec_len > e->d.max_dec_len) return fail(e, RK_ERR_CAPACITY, "dec_len %d out of range (max %d)", dec_len, e->d.max_dec_len);
   if (!out_token_ids || n_out <= 0 || n_out > 64) return fail(e, RK_ERR_INVALID, "n_out must be in 1..64 (got %d)", n_out);
   if ((rc = check_ids(e, dec_prefix, dec_len, "decoder")) || (rc = check_ids(e, out_token_ids, n_out, "output"))) return rc;
-  hipStream_t sd = dec_stream(e);
+  hipStream_t sd = dec_stream(e, sl);
   if ((rc = upload_dec_ids_shared(e, sl, dec_prefix, dec_len))) return rc;
   if ((rc = upload_small(e, sl, sd, &sl.cache_out, sl.d_out_ids, 1, out_token_ids, n_out))) return rc;
   std::vector<int> rows(sl.n_seq);
@@ -495,8 +534,9 @@ int rk_engine_create(const rk_model_desc* desc, int device_ordinal, rk_engine** 
   ok = ok && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess;
   // the decoder chain is a long sequence of tiny dependent kernels: give it dispatch priority over the encoder's
   // chip-filling GEMM grids so it progresses while they run
-  ok = ok && hipStreamCreateWithPriority(&e->s_enc, hipStreamNonBlocking, prio_lo) == hipSuccess;
-  ok = ok && hipStreamCreateWithPriority(&e->s_dec, hipStreamNonBlocking, prio_hi) == hipSuccess;
+  for (int i = 0; ok && i < RK_SLOTS; ++i)
+    ok = hipStreamCreateWithPriority(&e->slots[i].se, hipStreamNonBlocking, prio_lo) == hipSuccess &&
+         hipStreamCreateWithPriority(&e->slots[i].sd, hipStreamNonBlocking, prio_hi) == hipSuccess;
   ok = ok && hipEventCreate(&e->t0) == hipSuccess && hipEventCreate(&e->t1) == hipSuccess &&
        hipEventCreateWithFlags(&e->t_tmp, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; ok && i < RK_SLOTS; ++i)
@@ -513,8 +553,10 @@ int rk_engine_create(const rk_model_desc* desc, int device_ordinal, rk_engine** 
 void rk_engine_destroy(rk_engine* e) {
   if (!e) return;
   hipSetDevice(e->dev);
-  if (e->s_enc) hipStreamSynchronize(e->s_enc);
-  if (e->s_dec) hipStreamSynchronize(e->s_dec);
+  for (auto& sl : e->slots) {
+    if (sl.se) hipStreamSynchronize(sl.se);
+    if (sl.sd) hipStreamSynchronize(sl.sd);
+  }
   for (void* p : e->allocs) hipFree(p);
   if (e->logits) hipFree(e->logits);
   for (auto& sl : e->slots) {
@@ -527,8 +569,10 @@ void rk_engine_destroy(rk_engine* e) {
   if (e->t0) hipEventDestroy(e->t0);
   if (e->t1) hipEventDestroy(e->t1);
   if (e->t_tmp) hipEventDestroy(e->t_tmp);
-  if (e->s_enc) hipStreamDestroy(e->s_enc);
-  if (e->s_dec) hipStreamDestroy(e->s_dec);
+  for (auto& sl : e->slots) {
+    if (sl.se) hipStreamDestroy(sl.se);
+    if (sl.sd) hipStreamDestroy(sl.sd);
+  }
   delete e;
 }
 
@@ -671,10 +715,10 @@ int rk_engine_finalize(rk_engine* e) {
 
   // workspaces, sized once for the 288 GB part: nothing is allocated on the hot path afterwards
   const size_t Tc = d.max_tokens, Bc = d.max_seqs, Mc = (size_t)d.max_seqs * d.max_dec_len;
-  RC(dalloc(e, &e->hidden, Tc * dm)); RC(dalloc(e, &e->xn, Tc * dm)); RC(dalloc(e, &e->qkv, Tc * 3 * I));
-  RC(dalloc(e, &e->ctx, Tc * I)); RC(dalloc(e, &e->ffh, Tc * F)); RC(dalloc(e, &e->enc_out, Tc * dm));
   e->scores_cap = Bc * 64;
   for (Slot& sl : e->slots) {
+    RC(dalloc(e, &sl.hidden, Tc * dm)); RC(dalloc(e, &sl.xn, Tc * dm)); RC(dalloc(e, &sl.qkv, Tc * 3 * I));
+    RC(dalloc(e, &sl.ctx, Tc * I)); RC(dalloc(e, &sl.ffh, Tc * F)); RC(dalloc(e, &sl.enc_out, Tc * dm));
     RC(dalloc(e, &sl.d_tokens, Tc)); RC(dalloc(e, &sl.d_seq_off, Bc + 1));
     RC(dalloc(e, &sl.cross_kv, (size_t)d.n_dec_layers * Tc * 2 * I));
     RC(dalloc(e, &sl.d_dec_ids, Mc)); RC(dalloc(e, &sl.d_last_rows, Bc)); RC(dalloc(e, &sl.d_out_ids, 8192));
@@ -764,7 +808,7 @@ int rk_t5_qlm(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, i
   std::vector<int> dec_in(n_labels);
   dec_in[0] = 0;
   for (int t = 1; t < n_labels; ++t) dec_in[t] = labels[t - 1];
-  hipStream_t sd = dec_stream(e);
+  hipStream_t sd = dec_stream(e, sl);
   if ((rc = upload_dec_ids_shared(e, sl, dec_in.data(), n_labels))) return rc;
   HIPCHK(e, hipStreamSynchronize(sd));
   HIPCHK(e, hipMemcpy(sl.d_labels, labels, n_labels * sizeof(int), hipMemcpyHostToDevice));
@@ -795,7 +839,7 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
   if ((rc = check_ids(e, dec_prefix, dec_len, "decoder"))) return rc;
   if ((rc = ensure_logits(e, n_seq))) return rc;
   if ((rc = encoder_then_handoff(e, sl))) return rc;
-  hipStream_t sd = dec_stream(e);
+  hipStream_t sd = dec_stream(e, sl);
   // Per-row decoder ids grow by one token per step; the tiny decoder is recomputed over the whole prefix each
   // step (cross K/V are reused), which equals HF's KV-cached greedy loop (hf: generation/utils.py:2868-2935).
   std::vector<std::vector<int>> rows(n_seq, std::vector<int>(dec_prefix, dec_prefix + dec_len));
@@ -841,7 +885,13 @@ int rk_timer_begin(rk_engine* e) {
   if (!e) return RK_ERR_INVALID;
   int rc = set_device(e);
   if (rc) return rc;
-  HIPCHK(e, hipEventRecord(e->t0, e->s_enc));      // callers synchronise before starting a timed region
+  // callers synchronise before a timed region; make every other stream start behind the start event anyway
+  hipStream_t s0 = e->slots[0].se;
+  HIPCHK(e, hipEventRecord(e->t0, s0));
+  for (Slot& sl : e->slots) {
+    if (sl.se != s0) HIPCHK(e, hipStreamWaitEvent(sl.se, e->t0, 0));
+    HIPCHK(e, hipStreamWaitEvent(sl.sd, e->t0, 0));
+  }
   return RK_OK;
 }
 
@@ -849,10 +899,13 @@ int rk_timer_end(rk_engine* e, float* out_ms) {
   if (!e || !out_ms) return RK_ERR_INVALID;
   int rc = set_device(e);
   if (rc) return rc;
-  // stop event must follow the work of BOTH streams: chain the decoder stream behind the encoder stream's tail
-  HIPCHK(e, hipEventRecord(e->t_tmp, e->s_enc));
-  HIPCHK(e, hipStreamWaitEvent(e->s_dec, e->t_tmp, 0));
-  HIPCHK(e, hipEventRecord(e->t1, e->s_dec));
+  // the stop event must follow the work of ALL streams: chain them into slot 0's encoder stream
+  hipStream_t s0 = e->slots[0].se;
+  for (Slot& sl : e->slots) {
+    if (sl.se != s0) { HIPCHK(e, hipEventRecord(e->t_tmp, sl.se)); HIPCHK(e, hipStreamWaitEvent(s0, e->t_tmp, 0)); }
+    HIPCHK(e, hipEventRecord(e->t_tmp, sl.sd)); HIPCHK(e, hipStreamWaitEvent(s0, e->t_tmp, 0));
+  }
+  HIPCHK(e, hipEventRecord(e->t1, s0));
   HIPCHK(e, hipEventSynchronize(e->t1));
   HIPCHK(e, hipEventElapsedTime(out_ms, e->t0, e->t1));
   return RK_OK;
@@ -893,6 +946,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!e || !key) return RK_ERR_INVALID;
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value != 0; return RK_OK; }
+  if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..4 see choose_variant
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
     if (set_device(e) || sync_all(e)) return RK_ERR_HIP;
     for (Slot& sl : e->slots) sl.dec_pending = false;
@@ -906,7 +960,7 @@ int rk_debug_gemm(rk_engine* e, const uint16_t* A, const uint16_t* W, float* C, 
   if (!e || !A || !W || !C) return RK_ERR_INVALID;
   int rc = set_device(e);
   if (rc) return rc;
-  if (K % GEMM_BK || N % 4) return fail(e, RK_ERR_INVALID, "debug gemm needs K%%64==0 and N%%4==0");
+  if (K % 64 || N % 4) return fail(e, RK_ERR_INVALID, "debug gemm needs K%%64==0 and N%%4==0");
   half_t *dA = nullptr, *dW = nullptr; float* dC = nullptr;
   HIPCHK(e, hipMalloc((void**)&dA, (size_t)M * K * 2)); HIPCHK(e, hipMalloc((void**)&dW, (size_t)N * K * 2));
   HIPCHK(e, hipMalloc((void**)&dC, (size_t)M * N * 4));
@@ -914,11 +968,44 @@ int rk_debug_gemm(rk_engine* e, const uint16_t* A, const uint16_t* W, float* C, 
   HIPCHK(e, hipMemcpy(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice));
   const int saved = e->opt_glds;
   e->opt_glds = use_glds;
-  gemm(e, e->s_enc, PC_OTHER, EPI_STORE_F32, dA, K, dW, K, dC, N, M, N, K);
+  gemm(e, e->slots[0].se, PC_OTHER, EPI_STORE_F32, dA, K, dW, K, dC, N, M, N, K);
   e->opt_glds = saved;
-  HIPCHK(e, hipStreamSynchronize(e->s_enc));
+  HIPCHK(e, hipStreamSynchronize(e->slots[0].se));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+  hipFree(dA); hipFree(dW); hipFree(dC);
+  return RK_OK;
+}
+
+// debug/measurement: time `iters` back-to-back launches of the engine's GEMM at one shape (random fp16 operands on
+// the device, epilogue `epi` as in GemmEpi).  *out_ms = average per launch from HIP events on the encoder stream.
+int rk_debug_gemm_bench(rk_engine* e, int M, int N, int K, int epi, int iters, float* out_ms) {
+  if (!e || !out_ms || M <= 0 || N <= 0 || K <= 0 || iters <= 0) return RK_ERR_INVALID;
+  int rc = set_device(e);
+  if (rc) return rc;
+  if (K % 64 || N % 4) return fail(e, RK_ERR_INVALID, "gemm bench needs K%%64==0 and N%%4==0");
+  const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N;
+  half_t *dA = nullptr, *dW = nullptr; void* dC = nullptr;
+  HIPCHK(e, hipMalloc((void**)&dA, na * 2)); HIPCHK(e, hipMalloc((void**)&dW, nw * 2));
+  HIPCHK(e, hipMalloc(&dC, nc * 4));
+  {
+    std::vector<half_t> h(std::max(na, nw));
+    uint32_t x = 12345u;
+    for (size_t i = 0; i < h.size(); ++i) { x = x * 1664525u + 1013904223u; h[i] = (half_t)(((int)(x >> 16) % 2001 - 1000) * 1e-3f); }
+    HIPCHK(e, hipMemcpy(dA, h.data(), na * 2, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(dW, h.data(), nw * 2, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemset(dC, 0, nc * 4));
+  }
+  const int ldc = (epi == EPI_GEGLU_F16) ? N / 2 : N;
+  for (int i = 0; i < 2; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, K, dW, K, dC, ldc, M, N, K);
+  HIPCHK(e, hipEventRecord(e->t0, e->slots[0].se));
+  for (int i = 0; i < iters; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, K, dW, K, dC, ldc, M, N, K);
+  HIPCHK(e, hipEventRecord(e->t1, e->slots[0].se));
+  HIPCHK(e, hipEventSynchronize(e->t1));
+  float ms = 0;
+  HIPCHK(e, hipEventElapsedTime(&ms, e->t0, e->t1));
+  HIPCHK(e, hipGetLastError());
+  *out_ms = ms / iters;
   hipFree(dA); hipFree(dW); hipFree(dC);
   return RK_OK;
 }
@@ -931,11 +1018,11 @@ int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_fl
   const std::string n(name);
   const int I = e->inner, dm = e->d.d_model;
   const void* src = nullptr; int64_t cnt = 0; bool is_half = true;
-  if (n == "enc_hidden") { src = e->hidden; cnt = (int64_t)sl.T * dm; is_half = false; }
-  else if (n == "enc_out") { src = e->enc_out; cnt = (int64_t)sl.T * dm; }
-  else if (n == "qkv") { src = e->qkv; cnt = (int64_t)sl.T * 3 * I; }
-  else if (n == "ctx") { src = e->ctx; cnt = (int64_t)sl.T * I; }
-  else if (n == "xn") { src = e->xn; cnt = (int64_t)sl.T * dm; }
+  if (n == "enc_hidden") { src = sl.hidden; cnt = (int64_t)sl.T * dm; is_half = false; }
+  else if (n == "enc_out") { src = sl.enc_out; cnt = (int64_t)sl.T * dm; }
+  else if (n == "qkv") { src = sl.qkv; cnt = (int64_t)sl.T * 3 * I; }
+  else if (n == "ctx") { src = sl.ctx; cnt = (int64_t)sl.T * I; }
+  else if (n == "xn") { src = sl.xn; cnt = (int64_t)sl.T * dm; }
   else if (n == "dec_hidden") { src = sl.dhidden; cnt = (int64_t)sl.n_seq * e->d.max_dec_len * dm; is_half = false; }
   else return fail(e, RK_ERR_INVALID, "unknown buffer %s", name);
   cnt = std::min(cnt, max_floats);

@@ -62,6 +62,7 @@ ABI = {
     "rk_abi_version": (C.c_int, []),
     "rk_rel_bucket": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "rk_debug_gemm": (C.c_int, [C.c_void_p, _P(C.c_uint16), _P(C.c_uint16), _f32p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rk_debug_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     "rk_debug_read": (C.c_int64, [C.c_void_p, C.c_char_p, _f32p, C.c_int64]),
 }
 
@@ -263,6 +264,12 @@ class RkEngine:
                                          w16.view(np.uint16).ctypes.data_as(_P(C.c_uint16)),
                                          out.ctypes.data_as(_f32p), m, n, k, int(use_glds)))
         return out
+
+    def gemm_bench(self, m: int, n: int, k: int, epi: int = 0, iters: int = 20) -> float:
+        """average ms per launch of the engine GEMM at (m, n, k)"""
+        ms = C.c_float(0)
+        self._chk(self.lib.rk_debug_gemm_bench(self.h, m, n, k, epi, iters, C.byref(ms)))
+        return float(ms.value)
 
     def debug_read(self, name: str, n_floats: int) -> np.ndarray:
         out = np.empty(n_floats, dtype=np.float32)

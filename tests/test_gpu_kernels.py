@@ -39,17 +39,24 @@ def toy(ckpt_dirs):
         e.close()
 
 
-@pytest.mark.parametrize("glds", [True, False])
+# variant: 1 = 128x128 tile kernel (glds / register staging), 2..4 = 256x{256,192,128} 4-stage ring kernels
+@pytest.mark.parametrize("variant,glds", [(1, True), (1, False), (2, True), (3, True), (4, True)])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (200, 192, 128), (70, 576, 192), (1, 4, 64), (333, 260, 1024),
                                     (5888, 1024, 2816)])
-def test_gemm_vs_numpy(toy, shape, glds):
+def test_gemm_vs_numpy(toy, shape, variant, glds):
     """C = A W^T with fp16 inputs, fp32 accumulate: exact products, only summation order differs."""
     m, n, k = shape
+    if variant == 1 and k % 64:
+        pytest.skip("128x128 kernel steps K by 64")
     rs = np.random.RandomState(m + n + k)
     a = rs.standard_normal((m, k)).astype(np.float16)
     w = rs.standard_normal((n, k)).astype(np.float16)
     eng = toy["ckpt_gated_untied"][2]
-    got = eng.debug_gemm(a, w, use_glds=glds)
+    eng.set_option("gemm_variant", variant)
+    try:
+        got = eng.debug_gemm(a, w, use_glds=glds)
+    finally:
+        eng.set_option("gemm_variant", 0)
     want = a.astype(np.float32) @ w.astype(np.float32).T
     err = np.abs(got - want)
     assert err.max() < 2e-3 * np.sqrt(k), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}; " \
