@@ -144,6 +144,146 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
   }
 }
 
+// Short-sequence variant (L <= 192: the pointwise prompts).  The K rows and the TRANSPOSED V of one (sequence, head)
+// fit in LDS at once (27.6 + 25.1 KB), so they are loaded exactly once behind a single exposed memory latency and a
+// single barrier (the tiled kernel above pays a global-load round trip and two barriers per 64-key tile), V^T is
+// written as key PAIRS (ds_write_b32), 6 waves x 32 queries cover the whole sequence, and the output goes through LDS
+// so that stores are whole 128-byte context rows.  grid = (H, B), 384 threads, 3 workgroups per CU.
+#define ATTS_MAXL 192
+#define ATTS_VSTR 196   // sVt row stride in halfs (392 B: 8-B aligned; 98 dwords -> conflict-free b64 reads)
+__global__ __launch_bounds__(384) void attn_enc_short_kernel(AttnEncArgs p) {
+  __shared__ __attribute__((aligned(16))) half_t sK[ATTS_MAXL * ATT_KSTR];
+  __shared__ __attribute__((aligned(16))) half_t sVt[64 * ATTS_VSTR];
+  __shared__ float sLut[RK_LUT_N + 3];
+  const int b = blockIdx.y, h = blockIdx.x;
+  const int tok0 = p.seq_off[b];
+  const int L = p.seq_off[b + 1] - tok0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int hh = lane >> 5, l31 = lane & 31;
+  for (int i = tid; i < RK_LUT_N; i += 384) sLut[i] = p.bias_lut[h * RK_LUT_N + i];
+  const int nkt = (L + 63) >> 6;
+  const int nrows = nkt * 64;
+  // K rows: 16-B chunks, row-major (clamped rows are masked later)
+  for (int c = tid; c < nrows * 8; c += 384) {
+    const int row = c >> 3, cc = c & 7;
+    const int key = row < L ? row : L - 1;
+    *(half8*)(sK + row * ATT_KSTR + cc * 8) = *(const half8*)(p.qkv + (size_t)(tok0 + key) * p.ld + p.I + h * 64 + cc * 8);
+  }
+  // V^T: one thread takes 2 adjacent keys x 8 d and writes 8 key-pairs (32-bit) into the transposed image
+  for (int c = tid; c < (nrows >> 1) * 8; c += 384) {
+    const int kp = c >> 3, cc = c & 7;
+    const int k0 = 2 * kp < L ? 2 * kp : L - 1, k1 = 2 * kp + 1 < L ? 2 * kp + 1 : L - 1;
+    const half8 v0 = *(const half8*)(p.qkv + (size_t)(tok0 + k0) * p.ld + 2 * p.I + h * 64 + cc * 8);
+    const half8 v1 = *(const half8*)(p.qkv + (size_t)(tok0 + k1) * p.ld + 2 * p.I + h * 64 + cc * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const half2v pr = {v0[j], v1[j]};
+      *(half2v*)(sVt + (cc * 8 + j) * ATTS_VSTR + 2 * kp) = pr;
+    }
+  }
+  const int q0 = wave * 32;
+  const bool wave_active = q0 < L;
+  const int qpos = q0 + l31;
+  const int qrow = qpos < L ? qpos : L - 1;
+  half8 qf[4];
+  {
+    const half_t* qptr = p.qkv + (size_t)(tok0 + qrow) * p.ld + h * 64 + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const half8*)(qptr + 16 * s);
+  }
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+  __syncthreads();
+  if (wave_active) {
+    for (int kt = 0; kt < nkt; ++kt) {
+      const half_t* kb_ = sK + kt * 64 * ATT_KSTR;
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const half8 k0 = *(const half8*)(kb_ + l31 * ATT_KSTR + 16 * s + 8 * hh);
+        const half8 k1 = *(const half8*)(kb_ + (32 + l31) * ATT_KSTR + 16 * s + 8 * hh);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+      }
+      float tmax = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key0 = kt * 64 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int key1 = key0 + 32;
+        int rel0 = key0 - qpos, rel1 = key1 - qpos;
+        rel0 = rel0 < -RK_LUT_R ? -RK_LUT_R : (rel0 > RK_LUT_R ? RK_LUT_R : rel0);
+        rel1 = rel1 < -RK_LUT_R ? -RK_LUT_R : (rel1 > RK_LUT_R ? RK_LUT_R : rel1);
+        s0[r] = key0 < L ? s0[r] + sLut[rel0 + RK_LUT_R] : -1e30f;
+        s1[r] = key1 < L ? s1[r] + sLut[rel1 + RK_LUT_R] : -1e30f;
+        tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __expf(m_run - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __expf(s0[r] - m_new);
+        s1[r] = __expf(s1[r] - m_new);
+        psum += s0[r] + s1[r];
+      }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          half8 pf;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) pf[i] = (half_t)(sub == 0 ? s0[8 * sp + i] : s1[8 * sp + i]);
+          const int kb = kt * 64 + sub * 32 + 16 * sp + 4 * hh;
+          {
+            const half_t* vr = sVt + l31 * ATTS_VSTR + kb;
+            const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
+            const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o0, 0, 0, 0);
+          }
+          {
+            const half_t* vr = sVt + (32 + l31) * ATTS_VSTR + kb;
+            const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
+            const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o1, 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();   // all waves are done with sK: reuse it to turn the per-lane 8-byte pieces into whole context rows
+  if (wave_active) {
+    const float inv = 1.0f / l_run;
+    half_t* st = sK + wave * (32 * ATT_KSTR);            // 32 query rows x 64 d (row stride 72 halfs)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int d = 8 * q + 4 * hh;
+      half4 a, c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = f2h_sat(o0[4 * q + j] * inv); c[j] = f2h_sat(o1[4 * q + j] * inv); }
+      *(half4*)(st + l31 * ATT_KSTR + d) = a;
+      *(half4*)(st + l31 * ATT_KSTR + 32 + d) = c;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r0 = 0; r0 < 32; r0 += 8) {
+      const int row = r0 + (lane >> 3), ch = lane & 7;
+      if (q0 + row < L)
+        *(half8*)(p.ctx + (size_t)(tok0 + q0 + row) * p.ldctx + h * 64 + ch * 8) = *(const half8*)(st + row * ATT_KSTR + ch * 8);
+    }
+  }
+}
+
 // Decoder attention (self: causal + unidirectional bias; cross: zero bias, keys = encoder states of the same
 // sequence).  One 256-thread workgroup per (query position, head, sequence): threads parallel over keys for the
 // scores (q broadcast from LDS, 64 MACs per key in-lane), block reductions for max / sum, then the 4 waves split the

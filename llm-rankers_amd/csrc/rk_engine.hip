@@ -86,7 +86,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 1, opt_overlap = 1, opt_gemm_variant = 0;
+  int opt_glds = 1, opt_skinny = 1, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
@@ -300,7 +300,10 @@ int run_encoder(rk_engine* e, Slot& sl) {
       AttnEncArgs a{sl.qkv, sl.ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I};
       const double att_flops = 4.0 * (double)sl.maxL * T * I;   // exact for uniform lengths, upper bound if ragged
       Bracket br(e, st, PC_ENC_ATTN, att_flops, (double)T * 4 * I * 2.0);
-      hipLaunchKernelGGL(attn_enc_kernel, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
+      if (sl.maxL <= ATTS_MAXL && e->opt_attn_short)
+        hipLaunchKernelGGL(attn_enc_short_kernel, dim3(d.n_heads, sl.n_seq), dim3(384), 0, st, a);
+      else
+        hipLaunchKernelGGL(attn_enc_kernel, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
     }
     gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, I, w.o, I, sl.hidden, dm, T, dm, I);
     rmsnorm(e, st, sl.hidden, w.ln1, sl.xn, nullptr, T);
@@ -946,6 +949,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!e || !key) return RK_ERR_INVALID;
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value != 0; return RK_OK; }
+  if (!strcmp(key, "attn_short")) { e->opt_attn_short = value != 0; return RK_OK; }   // whole-KV-in-LDS kernel for L <= 192
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..4 see choose_variant
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
     if (set_device(e) || sync_all(e)) return RK_ERR_HIP;

@@ -179,11 +179,17 @@ def test_flan_t5_large_dims_vs_oracle_and_properties():
     perm = np.random.RandomState(1).permutation(32)
     np.testing.assert_array_equal(eng.score([batch[i] for i in perm], [0], ids), full[perm])
     np.testing.assert_array_equal(eng.score(batch[5:9], [0], ids), full[5:9])
-    glds_off = None
+    eng.set_option("gemm_variant", 1)
     eng.set_option("gemm_glds", 0)
-    glds_off = eng.score(batch, [0], ids)
+    v1_regs = eng.score(batch, [0], ids)
     eng.set_option("gemm_glds", 1)
-    np.testing.assert_array_equal(glds_off, full)        # both staging variants run the same arithmetic
+    v1_glds = eng.score(batch, [0], ids)
+    eng.set_option("gemm_variant", 0)
+    np.testing.assert_array_equal(v1_regs, v1_glds)      # DMA and register staging run the same arithmetic
+    np.testing.assert_array_equal(v1_glds, full)         # ... and so do all tile shapes (same K order per output)
+    eng.set_option("attn_short", 0)                      # tiled attention kernel instead of the whole-KV-in-LDS one
+    np.testing.assert_array_equal(eng.score(batch, [0], ids), full)
+    eng.set_option("attn_short", 1)
     eng.close()
 
 
