@@ -186,6 +186,9 @@ def main():
                        "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world} (candidate sharding + 1 RCCL all_gather/step)",
                        "weights": "synthetic N(0, HF-init std), seed 929", "engine_stream_ms_per_step": round(ev_ms / args.steps, 3),
                        "algorithmic_gflop_per_passage": round(gfl, 2),
+                       "note_executed_flops": "throughput fractions use the reference's algorithmic FLOPs (SURVEY 8d); the engine skips "
+                                              "the dead decoder q/k at L_d=1 and replaces the 18.5 GFLOP/passage cross-K/V projections by "
+                                              "the exact query-side form (DESIGN.md section 3)",
                        "whole_path_tflops_per_gpu": round(value / world * gfl / 1e3, 1),
                        "whole_path_frac_of_mfma_peak": round(value / world * gfl / 1e3 / MFMA_PEAK_TFLOPS, 4)},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -364,3 +364,145 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
     p.ctx[qrow * p.ldctx + h * 64 + lane] = f2h_sat(acc / sum);
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Direct cross-attention for a handful of decoder rows (M = sequences x decoder positions <= 32).
+// hf: T5LayerCrossAttention (modeling_t5.py:404-432) projects EVERY encoder state to K and V in every decoder layer
+// (13.6 % of all FLOPs of the pointwise path).  With so few queries it is cheaper to move the projections to the
+// query side - exact algebra, no approximation:
+//     score[h][t] = q_h . (W_k,h e_t)            = (W_k,h^T q_h) . e_t
+//     ctx_h       = sum_t p[h][t] (W_v,h e_t)    = W_v,h (sum_t p[h][t] e_t)
+// so per layer: qk = W_k^T q (per-head skinny GEMM), this kernel pair (scores + softmax + weighted sum of the raw
+// encoder states, split over 64-key chunks like flash-decoding), then ctx = W_v (.) (per-head skinny GEMM).
+// 64x fewer FLOPs than the K/V projections and no [n_dec][T][2I] hand-off buffer.
+struct XAttnArgs {
+  const half_t* qk;      // [M, H, d]   W_k^T q per head (fp16)
+  const half_t* enc;     // [T, d]      encoder output after the final norm (fp16)
+  const int* seq_off;    // [B+1]
+  float* part;           // [M, nch, H, d]  unnormalised partial sums, relative to the chunk's own max
+  float* stat;           // [M, nch, H, 2]  (chunk max, chunk sum of exp)
+  half_t* out;           // [M, H, d]   normalised  sum_t p[h][t] e_t  (fp16)
+  int Ld, H, d, nch;
+};
+
+__device__ __forceinline__ float row16_max(float v) {   // max over an aligned group of 16 lanes (DPP, no LDS)
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)));
+  return v;
+}
+__device__ __forceinline__ float row16_sum_f(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+  return v;
+}
+
+// grid = (nch, M, ceil(H/16)); 256 threads.  One 64-key chunk of one decoder row for a group of up to 16 heads.
+__global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
+  __shared__ float sP[16 * 64];
+  __shared__ float sRed[2][4][16];
+  const int ck = blockIdx.x, m = blockIdx.y, hg = blockIdx.z;
+  const int b = m / p.Ld;
+  const int tok0 = p.seq_off[b];
+  const int L = p.seq_off[b + 1] - tok0;
+  const int t0 = ck * 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nh = min(16, p.H - hg * 16);
+  float* stat = p.stat + (((size_t)m * p.nch + ck) * p.H + hg * 16) * 2;
+  if (t0 >= L) {     // this row has no keys here: mark the chunk empty for the combine step
+    if (tid < nh) { stat[tid * 2] = -1e30f; stat[tid * 2 + 1] = 0.f; }
+    return;
+  }
+  // ---- scores: S[h][t] = qk[h] . e_t  by MFMA 16x16x32 (A = the 16 head rows of qk, B = 16 encoder rows per wave) ----
+  const int hrow = min(hg * 16 + l15, p.H - 1);
+  const half_t* ap = p.qk + ((size_t)m * p.H + hrow) * p.d + 8 * g;
+  const int t = t0 + wave * 16 + l15;
+  const half_t* bp = p.enc + (size_t)(tok0 + min(t, L - 1)) * p.d + 8 * g;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int c0 = 0; c0 < p.d; c0 += 32)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8*)(ap + c0), *(const half8*)(bp + c0), acc, 0, 0, 0);
+  // lane holds heads 4g..4g+3 for key t (C layout: col = lane&15, row = 4*(lane>>4) + r)
+  float mx[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (t >= L) acc[r] = -1e30f;
+    mx[r] = row16_max(acc[r]);
+  }
+  if (l15 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[0][wave][4 * g + r] = mx[r];
+  }
+  __syncthreads();
+  float sm[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int h = 4 * g + r;
+    mx[r] = fmaxf(fmaxf(sRed[0][0][h], sRed[0][1][h]), fmaxf(sRed[0][2][h], sRed[0][3][h]));
+    const float e = __expf(acc[r] - mx[r]);
+    sP[h * 64 + wave * 16 + l15] = e;
+    sm[r] = row16_sum_f(e);
+  }
+  if (l15 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[1][wave][4 * g + r] = sm[r];
+  }
+  __syncthreads();
+  if (tid < nh) {
+    stat[tid * 2] = fmaxf(fmaxf(sRed[0][0][tid], sRed[0][1][tid]), fmaxf(sRed[0][2][tid], sRed[0][3][tid]));
+    stat[tid * 2 + 1] = (sRed[1][0][tid] + sRed[1][1][tid]) + (sRed[1][2][tid] + sRed[1][3][tid]);
+  }
+  // ---- partial weighted sums of the raw encoder rows: thread owns 4 consecutive columns ----
+  const int nvalid = min(64, L - t0);
+  float* part = p.part + (((size_t)m * p.nch + ck) * p.H + hg * 16) * p.d;
+  for (int cb = tid * 4; cb < p.d; cb += 1024) {
+    float a[16][4];
+#pragma unroll
+    for (int h = 0; h < 16; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[h][j] = 0.f;
+    const half_t* ep = p.enc + (size_t)(tok0 + t0) * p.d + cb;
+    for (int tt = 0; tt < nvalid; ++tt) {
+      const half4 e4 = *(const half4*)(ep + (size_t)tt * p.d);
+      const float e0 = (float)e4[0], e1 = (float)e4[1], e2 = (float)e4[2], e3 = (float)e4[3];
+#pragma unroll
+      for (int h = 0; h < 16; ++h) {
+        const float w = sP[h * 64 + tt];
+        a[h][0] += w * e0; a[h][1] += w * e1; a[h][2] += w * e2; a[h][3] += w * e3;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 16; ++h)
+      if (h < nh) { f32x4 o = {a[h][0], a[h][1], a[h][2], a[h][3]}; *(f32x4*)(part + (size_t)h * p.d + cb) = o; }
+  }
+}
+
+// grid = (H, M); 256 threads: merge the chunks of one (row, head) in chunk order and normalise.
+__global__ __launch_bounds__(256) void xattn_combine_kernel(XAttnArgs p) {
+  const int h = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+  float gmax = -1e30f;
+  for (int ck = 0; ck < p.nch; ++ck) gmax = fmaxf(gmax, p.stat[(((size_t)m * p.nch + ck) * p.H + h) * 2]);
+  float den = 0.f;
+  for (int ck = 0; ck < p.nch; ++ck) {
+    const float* st = p.stat + (((size_t)m * p.nch + ck) * p.H + h) * 2;
+    if (st[1] > 0.f) den += __expf(st[0] - gmax) * st[1];
+  }
+  const float inv = 1.0f / den;
+  for (int cb = tid * 4; cb < p.d; cb += 1024) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ck = 0; ck < p.nch; ++ck) {
+      const float* st = p.stat + (((size_t)m * p.nch + ck) * p.H + h) * 2;
+      if (st[1] > 0.f) {
+        const float w = __expf(st[0] - gmax);
+        const f32x4 v = *(const f32x4*)(p.part + (((size_t)m * p.nch + ck) * p.H + h) * p.d + cb);
+        acc[0] += w * v[0]; acc[1] += w * v[1]; acc[2] += w * v[2]; acc[3] += w * v[3];
+      }
+    }
+    half4 o = {f2h_sat(acc[0] * inv), f2h_sat(acc[1] * inv), f2h_sat(acc[2] * inv), f2h_sat(acc[3] * inv)};
+    *(half4*)(p.out + ((size_t)m * p.H + h) * p.d + cb) = o;
+  }
+}

@@ -29,6 +29,7 @@ struct GemmArgs {
   int n_split;       // >0: output column n goes to block n / n_split at C + block*split_stride, column n % n_split
   long split_stride; // in elements
   float scale;       // multiplies the accumulator (1.0 normally)
+  long bsA, bsW, bsC; // skinny kernel only: element strides between the blockIdx.y batches (per-head GEMMs)
 };
 
 #define GEMM_BM 128
@@ -318,6 +319,9 @@ __global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p)
   const int n0 = blockIdx.x * 32 * NT;
   const int nsteps = p.K >> 4;
   const int m = l31 < p.M ? l31 : p.M - 1;
+  p.A += (size_t)blockIdx.y * p.bsA;          // batched form: one small GEMM per blockIdx.y (e.g. per attention head)
+  p.W += (size_t)blockIdx.y * p.bsW;
+  p.C = (char*)p.C + (size_t)blockIdx.y * p.bsC * ((EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) ? 4 : 2);
   const half_t* arow = p.A + (size_t)m * p.lda + 8 * hh;
   const half_t* wrow[NT];
 #pragma unroll

@@ -42,6 +42,7 @@ struct HostTensor {
 struct EncLayerW { half_t *qkv = nullptr, *o = nullptr, *ffn_in = nullptr, *ffn_out = nullptr; float *ln0 = nullptr, *ln1 = nullptr; };
 struct DecLayerW {
   half_t *qkv = nullptr, *o = nullptr, *cq = nullptr, *co = nullptr, *ffn_in = nullptr, *ffn_out = nullptr;
+  half_t* ckT = nullptr;    // cross-attention W_k regrouped per head and transposed: [H][d_model][64] (direct path)
   float *ln0 = nullptr, *ln1 = nullptr, *ln2 = nullptr;
 };
 
@@ -63,6 +64,8 @@ struct Slot {
   half_t* cross_kv = nullptr;                                  // [n_dec][max_tokens][2I] encoder -> decoder hand-off
   int *d_dec_ids = nullptr, *d_last_rows = nullptr, *d_out_ids = nullptr, *d_labels = nullptr, *d_argmax = nullptr;
   float* dhidden = nullptr; half_t *dxn = nullptr, *dqkv = nullptr, *dctx = nullptr, *dq = nullptr, *dffh = nullptr, *dlast = nullptr;
+  half_t *xqk = nullptr, *xctx = nullptr;                      // direct cross-attention: [32][H*d] each
+  float *xpart = nullptr, *xstat = nullptr; bool have_cross_kv = false;
   float* d_scores = nullptr; float* h_scores = nullptr;
   int* h_small = nullptr;                                      // pinned staging for small int uploads
   std::vector<int> cache_dec, cache_out, cache_rows;
@@ -86,7 +89,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 1, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1;
+  int opt_glds = 1, opt_skinny = 1, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
@@ -194,22 +197,24 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
 }
 
 void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int lda, const half_t* W, int ldw, void* C,
-          int ldc, int M, int N, int K, int n_split = 0, long split_stride = 0, float scale = 1.f) {
+          int ldc, int M, int N, int K, int n_split = 0, long split_stride = 0, float scale = 1.f,
+          int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
   if (M <= 0) return;
-  GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale};
-  const double flops = 2.0 * M * (double)N * K;
+  GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale, bsA, bsW, bsC};
+  const double flops = 2.0 * M * (double)N * K * batch;
   const double out_elems = (epi == EPI_GEGLU_F16) ? (double)M * N / 2 : (double)M * N;
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
                        out_elems * (epi == EPI_RESID_F32 ? 8.0 : (epi == EPI_STORE_F32 ? 4.0 : 2.0));
   Bracket br(e, st, cls, flops, bytes);
-  if (M <= 32 && e->opt_skinny && n_split == 0) {   // weight-streaming regime (single-step decoder, head)
+  if (M <= 32 && n_split == 0 && (e->opt_skinny || batch > 1)) {   // weight-streaming regime (single-step decoder, head)
     const dim3 b(SKINNY_THREADS);
+    const unsigned gy = (unsigned)batch;
     switch (epi) {
-      case EPI_STORE_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F16, 1>), dim3((N + 31) / 32), b, 0, st, a); break;
-      case EPI_RESID_F32: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RESID_F32, 1>), dim3((N + 31) / 32), b, 0, st, a); break;
-      case EPI_GEGLU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_GEGLU_F16, 2>), dim3((N + 63) / 64), b, 0, st, a); break;
-      case EPI_RELU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RELU_F16, 1>), dim3((N + 31) / 32), b, 0, st, a); break;
-      default: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F32, 1>), dim3((N + 31) / 32), b, 0, st, a); break;
+      case EPI_STORE_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F16, 1>), dim3((N + 31) / 32, gy), b, 0, st, a); break;
+      case EPI_RESID_F32: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RESID_F32, 1>), dim3((N + 31) / 32, gy), b, 0, st, a); break;
+      case EPI_GEGLU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_GEGLU_F16, 2>), dim3((N + 63) / 64, gy), b, 0, st, a); break;
+      case EPI_RELU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RELU_F16, 1>), dim3((N + 31) / 32, gy), b, 0, st, a); break;
+      default: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F32, 1>), dim3((N + 31) / 32, gy), b, 0, st, a); break;
     }
     return;
   }
@@ -287,7 +292,16 @@ int upload_small(rk_engine* e, Slot& sl, hipStream_t st, std::vector<int>* cache
 // ---- forward passes -----------------------------------------------------------------------------------------
 // hf: modeling_t5.py:663-750 (T5Stack.forward, encoder) over the slot's staged ragged batch, then the stacked
 // cross-attention K/V projections of all decoder layers (:325-326 with key_value_states = encoder output).
-int run_encoder(rk_engine* e, Slot& sl) {
+#define XA_MAX_ROWS 32      // decoder rows (sequences x positions) the direct cross-attention path handles
+#define XA_MAX_CHUNKS 1024  // rows x 64-key chunks of partial-sum workspace
+
+// query-side cross-attention (attention.h) applies when the decoder has at most XA_MAX_ROWS rows in every step
+bool use_xattn_direct(const rk_engine* e, const Slot& sl, int max_ld) {
+  const long rows = (long)sl.n_seq * max_ld;
+  return e->opt_xattn_direct && rows <= XA_MAX_ROWS && rows * ((sl.maxL + 63) / 64) <= XA_MAX_CHUNKS;
+}
+
+int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
   const rk_model_desc& d = e->d;
   hipStream_t st = enc_stream(e, sl);
   const int T = sl.T, I = e->inner, dm = d.d_model, F = d.d_ff;
@@ -314,8 +328,11 @@ int run_encoder(rk_engine* e, Slot& sl) {
     gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, sl.ffh, F, w.ffn_out, F, sl.hidden, dm, T, dm, F);
   }
   rmsnorm(e, st, sl.hidden, e->enc_final_ln, sl.enc_out, nullptr, T);
-  gemm(e, st, PC_GEMM_CROSS_KV, EPI_STORE_F16, sl.enc_out, dm, e->cross_kv_w, dm, sl.cross_kv, 2 * I, T,
-       d.n_dec_layers * 2 * I, dm, 2 * I, (long)d.max_tokens * 2 * I);
+  // the stacked K/V projections are only materialised when the decoder has too many rows for the query-side form
+  if (need_cross_kv)
+    gemm(e, st, PC_GEMM_CROSS_KV, EPI_STORE_F16, sl.enc_out, dm, e->cross_kv_w, dm, sl.cross_kv, 2 * I, T,
+         d.n_dec_layers * 2 * I, dm, 2 * I, (long)d.max_tokens * 2 * I);
+  sl.have_cross_kv = need_cross_kv;
   HIPCHK(e, hipGetLastError());
   return RK_OK;
 }
@@ -345,7 +362,20 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
     gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.o, I, sl.dhidden, dm, M, dm, I);
     rmsnorm(e, st, sl.dhidden, w.ln1, sl.dxn, nullptr, M);
     gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.cq, dm, sl.dq, I, M, I, dm);
-    {
+    if (!sl.have_cross_kv) {
+      // query-side cross-attention: qk = W_k^T q per head; scores/softmax/weighted sum over the raw encoder states;
+      // ctx = W_v (.) per head  (attention.h: XAttnArgs)
+      const int H = d.n_heads, nch = (sl.maxL + 63) / 64;
+      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dq, I, w.ckT, 64, sl.xqk, H * dm, M, dm, 64, 0, 0, 1.f, H, 64, (long)dm * 64, dm);
+      XAttnArgs xa{sl.xqk, sl.enc_out, sl.d_seq_off, sl.xpart, sl.xstat, sl.xctx, Ld, H, dm, nch};
+      {
+        Bracket br(e, st, PC_DEC_ATTN, 4.0 * M * (double)sl.maxL * H * dm, (double)sl.T * dm * 2.0 * 2);
+        hipLaunchKernelGGL(xattn_part_kernel, dim3(nch, M, (H + 15) / 16), dim3(256), 0, st, xa);
+        hipLaunchKernelGGL(xattn_combine_kernel, dim3(H, M), dim3(256), 0, st, xa);
+      }
+      const half_t* wv = e->cross_kv_w + ((size_t)l * 2 * I + I) * dm;
+      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.xctx, H * dm, wv, dm, sl.dctx, I, M, 64, dm, 0, 0, 1.f, H, dm, (long)64 * dm, 64);
+    } else {
       const half_t* kv = sl.cross_kv + (size_t)l * d.max_tokens * 2 * I;
       AttnDecArgs a{sl.dq, I, kv, kv + I, 2 * I, sl.d_seq_off, sl.dctx, I, nullptr, Ld, 0, sl.maxL};
       Bracket br(e, st, PC_DEC_ATTN, 4.0 * Ld * (double)sl.T * I, (double)sl.T * 2 * I * 2.0);
@@ -365,10 +395,10 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
 
 // Encoder on s_enc, decoder on s_dec, ordered by events; the decoder of this slot's PREVIOUS batch must have
 // finished reading cross_kv before the encoder overwrites it.
-int encoder_then_handoff(rk_engine* e, Slot& sl) {
+int encoder_then_handoff(rk_engine* e, Slot& sl, int max_ld) {
   hipStream_t se = enc_stream(e, sl), sd = dec_stream(e, sl);
   if (sl.dec_pending && sd != se) HIPCHK(e, hipStreamWaitEvent(se, sl.ev_dec, 0));
-  int rc = run_encoder(e, sl);
+  int rc = run_encoder(e, sl, !use_xattn_direct(e, sl, max_ld));
   if (rc) return rc;
   if (sd != se) {
     HIPCHK(e, hipEventRecord(sl.ev_enc, se));
@@ -478,7 +508,7 @@ int score_slot(rk_engine* e, int slot, const int32_t* dec_prefix, int dec_len, c
   std::vector<int> rows(sl.n_seq);
   for (int b = 0; b < sl.n_seq; ++b) rows[b] = b * dec_len + dec_len - 1;
   if ((rc = upload_small(e, sl, sd, &sl.cache_rows, sl.d_last_rows, 2, rows.data(), sl.n_seq))) return rc;
-  if ((rc = encoder_then_handoff(e, sl))) return rc;
+  if ((rc = encoder_then_handoff(e, sl, dec_len))) return rc;
   if ((rc = run_decoder(e, sl, dec_len))) return rc;
   rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, sl.n_seq, head_scale(e));
   {
@@ -706,6 +736,14 @@ int rk_engine_finalize(rk_engine* e) {
     RC(up_h(&w.o, H(p + ".0.SelfAttention.o.weight")));
     RC(up_h(&w.cq, H(p + ".1.EncDecAttention.q.weight")));
     RC(up_h(&w.co, H(p + ".1.EncDecAttention.o.weight")));
+    {   // W_k regrouped per head and transposed: ckT[h][c][j] = W_k[h*64 + j][c]
+      const auto& wk = H(p + ".1.EncDecAttention.k.weight");
+      std::vector<half_t> t((size_t)I * dm);
+      for (int h = 0; h < d.n_heads; ++h)
+        for (int c = 0; c < dm; ++c)
+          for (int j = 0; j < 64; ++j) t[((size_t)h * dm + c) * 64 + j] = wk[((size_t)h * 64 + j) * dm + c];
+      RC(up_h(&w.ckT, t));
+    }
     RC(up_h(&w.ffn_in, ffn_in(p + ".2.DenseReluDense")));
     RC(up_h(&w.ffn_out, H(p + ".2.DenseReluDense.wo.weight")));
     RC(up_f(&w.ln0, Fv(p + ".0.layer_norm.weight")));
@@ -729,6 +767,8 @@ int rk_engine_finalize(rk_engine* e) {
     RC(dalloc(e, &sl.dhidden, Mc * dm)); RC(dalloc(e, &sl.dxn, Mc * dm)); RC(dalloc(e, &sl.dqkv, Mc * 3 * I));
     RC(dalloc(e, &sl.dctx, Mc * I)); RC(dalloc(e, &sl.dq, Mc * I)); RC(dalloc(e, &sl.dffh, Mc * F));
     RC(dalloc(e, &sl.dlast, Bc * dm));
+    RC(dalloc(e, &sl.xqk, (size_t)XA_MAX_ROWS * d.n_heads * dm)); RC(dalloc(e, &sl.xctx, (size_t)XA_MAX_ROWS * d.n_heads * dm));
+    RC(dalloc(e, &sl.xpart, (size_t)XA_MAX_CHUNKS * d.n_heads * dm)); RC(dalloc(e, &sl.xstat, (size_t)XA_MAX_CHUNKS * d.n_heads * 2));
     RC(dalloc(e, &sl.d_scores, e->scores_cap));
     HIPCHK(e, hipHostMalloc((void**)&sl.h_scores, e->scores_cap * sizeof(float), hipHostMallocDefault));
     HIPCHK(e, hipHostMalloc((void**)&sl.h_small, 4 * 8192 * sizeof(int), hipHostMallocDefault));
@@ -817,7 +857,7 @@ int rk_t5_qlm(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, i
   HIPCHK(e, hipMemcpy(sl.d_labels, labels, n_labels * sizeof(int), hipMemcpyHostToDevice));
   const int M = n_seq * n_labels;
   if ((rc = ensure_logits(e, M))) return rc;
-  if ((rc = encoder_then_handoff(e, sl))) return rc;
+  if ((rc = encoder_then_handoff(e, sl, n_labels))) return rc;
   if ((rc = run_decoder(e, sl, n_labels))) return rc;
   rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dxn, nullptr, M, head_scale(e));
   gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dxn, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, M, e->d.vocab, e->d.d_model);
@@ -841,7 +881,7 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
     return fail(e, RK_ERR_CAPACITY, "dec_len %d + max_new %d exceeds max_dec_len %d", dec_len, max_new, e->d.max_dec_len);
   if ((rc = check_ids(e, dec_prefix, dec_len, "decoder"))) return rc;
   if ((rc = ensure_logits(e, n_seq))) return rc;
-  if ((rc = encoder_then_handoff(e, sl))) return rc;
+  if ((rc = encoder_then_handoff(e, sl, dec_len + max_new - 1))) return rc;
   hipStream_t sd = dec_stream(e, sl);
   // Per-row decoder ids grow by one token per step; the tiny decoder is recomputed over the whole prefix each
   // step (cross K/V are reused), which equals HF's KV-cached greedy loop (hf: generation/utils.py:2868-2935).
@@ -949,6 +989,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!e || !key) return RK_ERR_INVALID;
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value != 0; return RK_OK; }
+  if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
   if (!strcmp(key, "attn_short")) { e->opt_attn_short = value != 0; return RK_OK; }   // whole-KV-in-LDS kernel for L <= 192
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..4 see choose_variant
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream

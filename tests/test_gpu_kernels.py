@@ -190,6 +190,14 @@ def test_flan_t5_large_dims_vs_oracle_and_properties():
     eng.set_option("attn_short", 0)                      # tiled attention kernel instead of the whole-KV-in-LDS one
     np.testing.assert_array_equal(eng.score(batch, [0], ids), full)
     eng.set_option("attn_short", 1)
+    # cross-attention: query-side form (default for <= 32 decoder rows) vs materialised K/V projections — same math,
+    # different rounding points
+    eng.set_option("xattn_direct", 0)
+    kv_path = eng.score(batch, [0], ids)
+    kv_ragged = eng.score(ragged, [0], ids)
+    eng.set_option("xattn_direct", 1)
+    assert np.abs(_sigm(kv_path[:, 0] - kv_path[:, 1]) - _sigm(full[:, 0] - full[:, 1])).max() < SCORE_TOL
+    assert np.abs(_sigm(kv_ragged[:, 0] - kv_ragged[:, 1]) - p_want).max() < SCORE_TOL
     eng.close()
 
 
