@@ -402,7 +402,7 @@ __device__ __forceinline__ float row16_sum_f(float v) {
 
 // grid = (nch, M, ceil(H/16)); 256 threads.  One 64-key chunk of one decoder row for a group of up to 16 heads.
 __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
-  __shared__ float sP[16 * 64];
+  __shared__ __attribute__((aligned(16))) float sP[64 * 16];
   __shared__ float sRed[2][4][16];
   const int ck = blockIdx.x, m = blockIdx.y, hg = blockIdx.z;
   const int b = m / p.Ld;
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
     const int h = 4 * g + r;
     mx[r] = fmaxf(fmaxf(sRed[0][0][h], sRed[0][1][h]), fmaxf(sRed[0][2][h], sRed[0][3][h]));
     const float e = __expf(acc[r] - mx[r]);
-    sP[h * 64 + wave * 16 + l15] = e;
+    sP[(wave * 16 + l15) * 16 + h] = e;          // [key][head]: the 16 weights of one key are contiguous
     sm[r] = row16_sum_f(e);
   }
   if (l15 == 0) {
@@ -470,9 +470,13 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
       const half4 e4 = *(const half4*)(ep + (size_t)tt * p.d);
       const float e0 = (float)e4[0], e1 = (float)e4[1], e2 = (float)e4[2], e3 = (float)e4[3];
 #pragma unroll
-      for (int h = 0; h < 16; ++h) {
-        const float w = sP[h * 64 + tt];
-        a[h][0] += w * e0; a[h][1] += w * e1; a[h][2] += w * e2; a[h][3] += w * e3;
+      for (int hq = 0; hq < 4; ++hq) {
+        const f32x4 w4 = *(const f32x4*)(sP + tt * 16 + hq * 4);      // LDS broadcast read, 4 heads at a time
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int h = hq * 4 + r;
+          a[h][0] += w4[r] * e0; a[h][1] += w4[r] * e1; a[h][2] += w4[r] * e2; a[h][3] += w4[r] * e3;
+        }
       }
     }
 #pragma unroll

@@ -162,7 +162,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
 // region (the main-loop stages are dead by then) and writes it back with 16 bytes per lane along the rows, i.e.
 // whole 64..256-byte row segments per instruction; the fp32 residual add reads the old row the same way.
 // `stage` = this wave's LDS region, at least 32 * (NI*32*4 + 16) bytes.
-template <int EPI, int NI, int MI>
+// Residual epilogue, read side: the old fp32 rows are fetched in ACCUMULATOR layout at kernel start, so the read half
+// of the read-modify-write travels while the main loop computes instead of after it (every tile of these single-round
+// launches reaches its epilogue at the same moment, so un-overlapped epilogue traffic is pure added latency).
+template <int NI, int MI>
+__device__ __forceinline__ void gemm_prefetch_residual(const GemmArgs& p, f32x16 (&res)[NI][MI], int mbase, int nbase,
+                                                       int l31, int hh) {
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    int m = mbase + mi * 32 + l31;
+    m = m < p.M ? m : p.M - 1;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int n = nbase + ni * 32 + 8 * q + 4 * hh;
+        n = n < p.N ? n : p.N - 4;
+        const f32x4 v = *(const f32x4*)((const float*)p.C + (size_t)m * p.ldc + n);
+        res[ni][mi][4 * q] = v[0]; res[ni][mi][4 * q + 1] = v[1]; res[ni][mi][4 * q + 2] = v[2]; res[ni][mi][4 * q + 3] = v[3];
+      }
+  }
+}
+
+template <int EPI, int NI, int MI, bool RESID_IN_ACC = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase,
                                                      int lane, unsigned char* stage) {
   const int l31 = lane & 31, hh = lane >> 5;
@@ -226,7 +248,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         if (F32) {
           float* c = (float*)p.C + base + (size_t)m * p.ldc + n;
           f32x4 v = *(const f32x4*)sp;
-          if (EPI == EPI_RESID_F32) { const f32x4 old = *(const f32x4*)c; v = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]}; }
+          if (EPI == EPI_RESID_F32 && !RESID_IN_ACC) { const f32x4 old = *(const f32x4*)c; v = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]}; }
           *(f32x4*)c = v;
         } else {
           *(half8*)((half_t*)p.C + base + (size_t)m * p.ldc + n) = *(const half8*)sp;
@@ -259,6 +281,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.K / GEMM_BK;
+  f32x16 res[2][2];
+  if (EPI == EPI_RESID_F32) gemm_prefetch_residual<2, 2>(p, res, m0 + wm * 64, n0 + wn * 64, l31, hh);
   half8 ra[4], rw[4];
   // prologue: stage k-tile 0 into stage 0
   gemm_stage_tile<GLDS>(smem, p.A, p.lda, m0, p.M, 0, wave, lane, ra);
@@ -299,8 +323,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
     }
   }
 
+  if (EPI == EPI_RESID_F32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * p.scale + res[i][j][r];
+  }
   __syncthreads();   // every wave is done reading the last stage: LDS becomes the epilogue staging area
-  gemm_epilogue_staged<EPI, 2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, gemm_smem + wave * (32 * (64 * 4 + 16)));
+  if (EPI == EPI_RESID_F32) {
+    GemmArgs q = p; q.scale = 1.f;
+    gemm_epilogue_staged<EPI, 2, 2, true>(q, acc, m0 + wm * 64, n0 + wn * 64, lane, gemm_smem + wave * (32 * (64 * 4 + 16)));
+  } else
+    gemm_epilogue_staged<EPI, 2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, gemm_smem + wave * (32 * (64 * 4 + 16)));
 }
 
 // ---- skinny GEMM: M <= 32 rows (the single-step decoder: M = sequences in the batch) ----------------------------
@@ -446,6 +482,9 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(GemmArgs p) {
   const int nk = p.K >> 6;
 #pragma unroll
   for (int j = 0; j < LOADS; ++j) issue(j, 0);
+  constexpr bool PREFETCH_RES = EPI == EPI_RESID_F32 && NI * MI <= 6;   // register budget: 16 fp32 per fragment
+  f32x16 res[PREFETCH_RES ? NI : 1][PREFETCH_RES ? MI : 1];
+  if (PREFETCH_RES) gemm_prefetch_residual<PREFETCH_RES ? NI : 1, PREFETCH_RES ? MI : 1>(p, res, m0 + wm * MI * 32, n0 + wn * NI * 32, l31, hh);
   int arow[MI], wrow[NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) arow[i] = (wm * MI * 32 + i * 32 + l31);
@@ -476,7 +515,20 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(GemmArgs p) {
         }
     }
   }
+  if (PREFETCH_RES) {
+#pragma unroll
+    for (int i = 0; i < (PREFETCH_RES ? NI : 1); ++i)
+#pragma unroll
+      for (int j = 0; j < (PREFETCH_RES ? MI : 1); ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * p.scale + res[i][j][r];
+  }
   __syncthreads();   // every wave is done reading the last stage: LDS becomes the epilogue staging area
-  gemm_epilogue_staged<EPI, NI, MI>(p, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, lane,
-                                    gemm_smem + wave * (32 * (NI * 32 * 4 + 16)));
+  if (PREFETCH_RES) {
+    GemmArgs q = p; q.scale = 1.f;
+    gemm_epilogue_staged<EPI, NI, MI, true>(q, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, lane,
+                                            gemm_smem + wave * (32 * (NI * 32 * 4 + 16)));
+  } else
+    gemm_epilogue_staged<EPI, NI, MI>(p, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, lane,
+                                      gemm_smem + wave * (32 * (NI * 32 * 4 + 16)));
 }

@@ -43,6 +43,7 @@ struct EncLayerW { half_t *qkv = nullptr, *o = nullptr, *ffn_in = nullptr, *ffn_
 struct DecLayerW {
   half_t *qkv = nullptr, *o = nullptr, *cq = nullptr, *co = nullptr, *ffn_in = nullptr, *ffn_out = nullptr;
   half_t* ckT = nullptr;    // cross-attention W_k regrouped per head and transposed: [H][d_model][64] (direct path)
+  half_t* ov = nullptr;     // self-attention W_o W_v [d_model, d_model]: the whole sub-layer at L_d = 1
   float *ln0 = nullptr, *ln1 = nullptr, *ln2 = nullptr;
 };
 
@@ -352,14 +353,15 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
     if (Ld == 1) {
       // one decoder position: softmax over a single key is 1, so self-attention is exactly o(v(x)) — the q/k
       // projections, scores and bias are dead (hf: modeling_t5.py:448-509 at L_d = 1)
-      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.qkv + (size_t)2 * I * dm, dm, sl.dctx, I, M, I, dm);
+      // ... and o(v(x)) = (W_o W_v) x: one GEMM with the product matrix formed once at finalize
+      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dxn, dm, w.ov, dm, sl.dhidden, dm, M, dm, dm);
     } else {
       gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.qkv, dm, sl.dqkv, 3 * I, M, 3 * I, dm);
       AttnDecArgs a{sl.dqkv, 3 * I, sl.dqkv + I, sl.dqkv + 2 * I, 3 * I, nullptr, sl.dctx, I, e->lut_dec, Ld, 1, Ld};
       Bracket br(e, st, PC_DEC_ATTN, 4.0 * M * Ld * I, 0);
       hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_self, st, a);
+      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.o, I, sl.dhidden, dm, M, dm, I);
     }
-    gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.o, I, sl.dhidden, dm, M, dm, I);
     rmsnorm(e, st, sl.dhidden, w.ln1, sl.dxn, nullptr, M);
     gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.cq, dm, sl.dq, I, M, I, dm);
     if (!sl.have_cross_kv) {
@@ -752,6 +754,28 @@ int rk_engine_finalize(rk_engine* e) {
     for (const char* m : {"k", "v"}) { const auto& s = H(p + ".1.EncDecAttention." + m + ".weight"); ckv.insert(ckv.end(), s.begin(), s.end()); }
   }
   RC(up_h(&e->cross_kv_w, ckv));
+  {
+    // W_ov[n][k] = sum_j W_o[n][j] W_v[j][k]  via the engine GEMM: A = W_o [d, I], W = W_v^T [d, I]  (fp32 out)
+    half_t* d_vT = nullptr; float* d_ov32 = nullptr;
+    RC(dalloc(e, &d_vT, (size_t)dm * I)); RC(dalloc(e, &d_ov32, (size_t)dm * dm));
+    std::vector<half_t> vT((size_t)dm * I), ov16((size_t)dm * dm);
+    std::vector<float> ov32((size_t)dm * dm);
+    const int saved_variant = e->opt_gemm_variant;
+    for (int l = 0; l < d.n_dec_layers; ++l) {
+      const std::string p = "decoder.block." + std::to_string(l) + ".layer.0.SelfAttention.";
+      const auto& wv = H(p + "v.weight");
+      for (int j = 0; j < I; ++j)
+        for (int k = 0; k < dm; ++k) vT[(size_t)k * I + j] = wv[(size_t)j * dm + k];
+      HIPCHK(e, hipMemcpy(d_vT, vT.data(), vT.size() * 2, hipMemcpyHostToDevice));
+      gemm(e, e->slots[0].se, PC_OTHER, EPI_STORE_F32, e->dec[l].o, I, d_vT, I, d_ov32, dm, dm, dm, I);
+      HIPCHK(e, hipStreamSynchronize(e->slots[0].se));
+      HIPCHK(e, hipMemcpy(ov32.data(), d_ov32, ov32.size() * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < ov32.size(); ++i) ov16[i] = (half_t)ov32[i];
+      RC(up_h(&e->dec[l].ov, ov16));
+    }
+    e->opt_gemm_variant = saved_variant;
+    HIPCHK(e, hipGetLastError());
+  }
   e->host.clear();
 
   // workspaces, sized once for the 288 GB part: nothing is allocated on the hot path afterwards
