@@ -22,12 +22,15 @@ struct AttnEncArgs {
 // scalars and the fp16 P values are already in MFMA B-operand position for O^T = V^T P^T (A = V^T rows).
 // The k-slot <-> key assignment is the same permutation for P (B operand) and V^T (A operand), so no
 // cross-lane data movement is needed anywhere except one xor-32 shuffle for the row max and row sum.
+// Pipeline: the global loads of tile t+1 are issued into registers before tile t is computed and written to the
+// other LDS buffer afterwards (double buffer, ONE barrier per tile, memory latency hidden behind the MFMAs);
+// V^T is written as key pairs (ds_write_b32); the output goes through LDS so stores are whole 128-byte rows.
 #define ATT_KSTR 72   // sK row stride in halfs (144 B: 16-B aligned, conflict-free b128 reads)
 #define ATT_VSTR 68   // sVt row stride in halfs (136 B: 8-B aligned, conflict-free b64 reads)
 
 __global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
-  __shared__ __attribute__((aligned(16))) half_t sK[64 * ATT_KSTR];
-  __shared__ __attribute__((aligned(16))) half_t sVt[64 * ATT_VSTR];
+  __shared__ __attribute__((aligned(16))) half_t sK[2][64 * ATT_KSTR];
+  __shared__ __attribute__((aligned(16))) half_t sVt[2][64 * ATT_VSTR];
   __shared__ float sLut[RK_LUT_N + 3];
   const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
   const int tok0 = p.seq_off[b];
@@ -51,30 +54,43 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
   const int nkt = (L + 63) >> 6;
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();   // previous tile fully consumed (first iteration: sLut visible)
+  // staging roles: K: thread takes rows (tid>>3) and 32+(tid>>3), chunk tid&7; V: key pair tid>>3, chunk tid&7
+  const int srow = tid >> 3, scc = tid & 7;
+  half8 rk0, rk1, rv0, rv1;
+  auto load_tile = [&](int kt) {
+    const int ka = min(kt * 64 + srow, L - 1), kb2 = min(kt * 64 + 32 + srow, L - 1);
+    const half_t* base = p.qkv + p.I + h * 64 + scc * 8;
+    rk0 = *(const half8*)(base + (size_t)(tok0 + ka) * p.ld);
+    rk1 = *(const half8*)(base + (size_t)(tok0 + kb2) * p.ld);
+    const int va = min(kt * 64 + 2 * srow, L - 1), vb = min(kt * 64 + 2 * srow + 1, L - 1);
+    rv0 = *(const half8*)(base + p.I + (size_t)(tok0 + va) * p.ld);
+    rv1 = *(const half8*)(base + p.I + (size_t)(tok0 + vb) * p.ld);
+  };
+  auto store_tile = [&](int buf) {
+    *(half8*)(sK[buf] + srow * ATT_KSTR + scc * 8) = rk0;
+    *(half8*)(sK[buf] + (32 + srow) * ATT_KSTR + scc * 8) = rk1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c >> 3, cc = c & 7;
-      int key = kt * 64 + row;
-      key = key < L ? key : L - 1;   // clamp to valid memory; masked below
-      const half_t* src = p.qkv + (size_t)(tok0 + key) * p.ld + p.I + h * 64 + cc * 8;
-      const half8 kv = *(const half8*)src;
-      const half8 vv = *(const half8*)(src + p.I);
-      *(half8*)(sK + row * ATT_KSTR + cc * 8) = kv;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sVt[(cc * 8 + j) * ATT_VSTR + row] = vv[j];
+    for (int j = 0; j < 8; ++j) {
+      const half2v pr = {rv0[j], rv1[j]};
+      *(half2v*)(sVt[buf] + (scc * 8 + j) * ATT_VSTR + 2 * srow) = pr;
     }
-    __syncthreads();
+  };
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);          // in flight while this tile is computed
     if (wave_active) {
+      const half_t* kbuf = sK[cur];
+      const half_t* vbuf = sVt[cur];
       f32x16 s0, s1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const half8 k0 = *(const half8*)(sK + l31 * ATT_KSTR + 16 * s + 8 * hh);
-        const half8 k1 = *(const half8*)(sK + (32 + l31) * ATT_KSTR + 16 * s + 8 * hh);
+        const half8 k0 = *(const half8*)(kbuf + l31 * ATT_KSTR + 16 * s + 8 * hh);
+        const half8 k1 = *(const half8*)(kbuf + (32 + l31) * ATT_KSTR + 16 * s + 8 * hh);
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
       }
@@ -114,13 +130,13 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
           for (int i = 0; i < 8; ++i) pf[i] = (half_t)(sub == 0 ? s0[8 * sp + i] : s1[8 * sp + i]);
           const int kb = sub * 32 + 16 * sp + 4 * hh;   // keys kb..kb+3 and kb+8..kb+11 <-> regs 8sp..8sp+7
           {
-            const half_t* vr = sVt + l31 * ATT_VSTR + kb;
+            const half_t* vr = vbuf + l31 * ATT_VSTR + kb;
             const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
             const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o0, 0, 0, 0);
           }
           {
-            const half_t* vr = sVt + (32 + l31) * ATT_VSTR + kb;
+            const half_t* vr = vbuf + (32 + l31) * ATT_VSTR + kb;
             const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
             const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o1, 0, 0, 0);
@@ -128,18 +144,37 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
         }
       }
     }
+    if (kt + 1 < nkt) store_tile(cur ^ 1);        // buffer cur^1 was last read before the previous barrier
+    __syncthreads();
   }
-  if (wave_active && qpos < L) {
+  // all waves are past the last barrier: reuse sK[0] to turn per-lane 8-byte pieces into whole context rows
+  if (wave_active) {
     const float inv = 1.0f / l_run;
-    half_t* out = p.ctx + (size_t)(tok0 + qpos) * p.ldctx + h * 64;
+    half_t* st = sK[0] + wave * (16 * ATT_KSTR);   // 2 passes of 16 query rows x 64 d per wave (4 x 16 rows = 64 rows)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int d = 8 * q + 4 * hh;
-      half4 a, c;
+    for (int half_i = 0; half_i < 2; ++half_i) {
+      if ((l31 >> 4) == half_i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { a[j] = f2h_sat(o0[4 * q + j] * inv); c[j] = f2h_sat(o1[4 * q + j] * inv); }
-      *(half4*)(out + d) = a;
-      *(half4*)(out + 32 + d) = c;
+        for (int q = 0; q < 4; ++q) {
+          const int d = 8 * q + 4 * hh;
+          half4 a, c;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] = f2h_sat(o0[4 * q + j] * inv); c[j] = f2h_sat(o1[4 * q + j] * inv); }
+          *(half4*)(st + (l31 & 15) * ATT_KSTR + d) = a;
+          *(half4*)(st + (l31 & 15) * ATT_KSTR + 32 + d) = c;
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r0 = 0; r0 < 16; r0 += 8) {
+        const int row = r0 + (lane >> 3), ch = lane & 7;
+        const int qq = q0 + half_i * 16 + row;
+        if (qq < L)
+          *(half8*)(p.ctx + (size_t)(tok0 + qq) * p.ldctx + h * 64 + ch * 8) = *(const half8*)(st + row * ATT_KSTR + ch * 8);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }

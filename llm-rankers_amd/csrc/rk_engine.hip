@@ -169,19 +169,23 @@ void launch_v2(hipStream_t st, const GemmArgs& a) {
   hipLaunchKernelGGL((gemm_v2_kernel<EPI, WM, WN, MI, NI>), dim3(tiles), dim3(512), smem, st, a);
 }
 
-// Tile-shape choice.  variant: 0 = auto, 1 = 128x128 (v1), 2 = 256x256, 3 = 256x192, 4 = 256x128 (v2 kernels).
-// auto = what measured fastest per shape class on MI355X at M = 5888 (tools/gemm_bench.py, profiles/r01c_gemm_bench.txt):
-// wide outputs -> 256x256; N around 3k -> 256x192 (more tiles for the 256 CUs); narrow N -> 256x128; too few 256-row
-// tiles to occupy the chip -> 128x128 at two workgroups per CU.  GEGLU pairs gate/up inside 64-row wave tiles (NI even).
+// Tile-shape choice.  variant: 0 = auto, 1 = 128x128 (v1, two workgroups per CU), 2 = 256x256, 3 = 256x192,
+// 4 = 256x128 (v2 kernels, one workgroup per CU).  auto = cheapest under a measured model: time ~ rounds over the
+// resident slots x the variant's time for one round of K = 1024 (us, MI355X, tools/gemm_bench.py at M = 736 .. 5888,
+// profiles/r01c_gemm_bench.txt).  GEGLU pairs gate/up inside 64-row wave tiles, so it cannot use the 192-wide tile.
 int choose_variant(const rk_engine* e, int epi, int M, int N, int K) {
   (void)K;
   if (e->opt_gemm_variant) return (e->opt_gemm_variant == 3 && epi == EPI_GEGLU_F16) ? 2 : e->opt_gemm_variant;
-  const long tm = (M + 255) / 256;
-  int v = N >= 4096 ? 2 : (N >= 2048 ? 3 : 4);
-  if (v == 3 && epi == EPI_GEGLU_F16) v = 2;
-  const int bn = v == 2 ? 256 : (v == 3 ? 192 : 128);
-  if (tm * ((N + bn - 1) / bn) < 96) return 1;
-  return v;
+  struct V { int id, bm, bn, slots; double round_us; };
+  static const V vs[4] = {{2, 256, 256, 256, 29.8}, {3, 256, 192, 256, 24.7}, {4, 256, 128, 256, 19.0}, {1, 128, 128, 512, 17.3}};
+  double best = 1e30; int bv = 1;
+  for (const V& v : vs) {
+    if (v.id == 3 && epi == EPI_GEGLU_F16) continue;
+    const long tiles = (long)((M + v.bm - 1) / v.bm) * ((N + v.bn - 1) / v.bn);
+    const double cost = (double)((tiles + v.slots - 1) / v.slots) * v.round_us;
+    if (cost < best - 1e-9) { best = cost; bv = v.id; }
+  }
+  return bv;
 }
 
 template <int EPI>

@@ -213,3 +213,52 @@ def test_capacity_and_argument_errors(toy):
     with pytest.raises(RkError):
         eng.score([[5, 1]], [0] * 100, [3])                 # decoder prefix beyond max_dec_len
     assert np.isfinite(eng.score([[5, 1]], [0], [3])).all()   # engine still usable after errors
+
+
+def test_setwise_shape_flan_t5_large_vs_oracle():
+    """BASELINE.json configs[2] call shape: ONE long prompt (11 passages x ~134 tokens + query + template ~ 1.5k tokens),
+    decoder prefix [0, Passage] -> 11 label logits (likelihood) and 2 greedy tokens (generation), flan-t5-large dims."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle
+    dims = _synth.FLAN_T5_LARGE
+    state = _synth.synth_state_dict(dims, seed=929, threads=16)
+    eng = _engine(dims, state, max_tokens=4096, max_seqs=8, max_dec_len=8)
+    orc = T5Oracle(dims, state)
+    seq = _synth.synth_token_batch(1, 1536, 1536, dims.vocab, seed=77)
+    prefix = [0, 5454]
+    labels = list(range(71, 71 + 11))
+    enc = orc.encode(seq[0])
+    want = orc.decode(enc, prefix)[-1]
+    got = eng.score(seq, prefix, labels)[0]
+    err = np.abs(got - want[labels]).max()
+    assert err < 3e-2, err                              # logits of magnitude ~3; fp16 activations over 1.5k keys
+    top2 = np.sort(want[labels])[-2:]
+    if top2[1] - top2[0] > 0.1:                          # decision margin above the noise floor -> same label
+        assert int(np.argmax(got)) == int(np.argmax(want[labels]))
+    toks, steps = eng.greedy(seq, prefix, 2)
+    full_sorted = np.sort(want)
+    if full_sorted[-1] - full_sorted[-2] > 0.1:
+        assert toks[0, 0] == int(np.argmax(want))
+    assert steps in (1, 2)
+    # a second, shorter prompt in the same call must not change the first (ragged batch of long prompts)
+    two = seq + _synth.synth_token_batch(1, 700, 700, dims.vocab, seed=78)
+    np.testing.assert_array_equal(eng.score(two, prefix, labels)[0], got)
+    eng.close()
+
+
+def test_qlm_flan_t5_small_vs_oracle():
+    """BASELINE.json configs[3] method (pointwise qlm) at flan-t5-small dims: 33 label positions, full-vocabulary CE;
+    more than 32 decoder rows -> exercises the materialised cross-K/V path and the tiled GEMM in the decoder."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle
+    dims = _synth.FLAN_T5_SMALL
+    state = _synth.synth_state_dict(dims, seed=929, threads=8)
+    eng = _engine(dims, state, max_tokens=4096, max_seqs=16, max_dec_len=40)
+    seqs = _synth.synth_token_batch(6, 40, 150, dims.vocab, seed=31)
+    labels = [0] + np.random.RandomState(5).randint(3, dims.vocab, size=32).tolist()
+    got = eng.qlm(seqs, labels)
+    want = T5Oracle(dims, state).qlm(seqs, labels)
+    assert np.abs(got - want).max() < 0.15, (got, want)            # sum of 33 log-probs of magnitude ~10 each
+    assert np.abs(got - want).max() / np.abs(want).max() < 5e-4
+    np.testing.assert_array_equal(np.argsort(-got), np.argsort(-want))
+    eng.close()

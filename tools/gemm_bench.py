@@ -18,6 +18,11 @@ SHAPES = [  # name, M, N, K, epi
 
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    m_override = int(os.environ.get("RK_BENCH_M", "0"))
+    if m_override:
+        for i, (name, m, n, k, epi) in enumerate(SHAPES[:5]):
+            SHAPES[i] = (name, m_override, n, k, epi)
+        del SHAPES[5:]
     only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
     dims = _synth.TOY_GATED_UNTIED
     eng = RkEngine(dims, 0, max_tokens=256, max_seqs=4, max_dec_len=4).load_state(_synth.synth_state_dict(dims, 1).items())
