@@ -428,13 +428,14 @@ __global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p)
 //   * XCD-aware tile order: block b runs on XCD b%8, and each XCD is handed a contiguous run of the tm-major tile
 //     list, so the workgroups co-resident on one XCD share A / W panels through its private 4 MiB L2.
 template <int EPI, int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(512, 2) void gemm_v2_kernel(GemmArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void gemm_v2_kernel(GemmArgs p) {
+  constexpr int NW = WM * WN;                                    // waves per workgroup: 8 (2 per SIMD) or 16 (4 per SIMD)
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   constexpr int A_HALFS = BM * 64, W_HALFS = BN * 64, STAGE_HALFS = A_HALFS + W_HALFS;
   constexpr int A_INSTR = BM / 8, W_INSTR = BN / 8;            // one DMA instruction = 64 x 16 B = 8 tile rows
-  constexpr int A_PW = A_INSTR / 8, W_PW = (W_INSTR + 7) / 8;  // per wave per stage
+  constexpr int A_PW = A_INSTR / NW, W_PW = (W_INSTR + NW - 1) / NW;  // per wave per stage
   constexpr int LOADS = A_PW + W_PW;
-  static_assert(WM * WN == 8 && A_INSTR % 8 == 0, "8 waves; A tile must split evenly");
+  static_assert((NW == 8 || NW == 16) && A_INSTR % NW == 0, "8 or 16 waves; A tile must split evenly");
   constexpr int ISSUE_STRIDE = (3 * MI * NI) / LOADS;           // DMA issues spread over the first three k16 steps
   static_assert(ISSUE_STRIDE >= 1, "not enough MFMA slots to hide the DMA issues");
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void gemm_v2_kernel(GemmArgs p) {
   const int nk = p.K >> 6;
 #pragma unroll
   for (int j = 0; j < LOADS; ++j) issue(j, 0);
-  constexpr bool PREFETCH_RES = EPI == EPI_RESID_F32 && NI * MI <= 6;   // register budget: 16 fp32 per fragment
+  constexpr bool PREFETCH_RES = EPI == EPI_RESID_F32 && NI * MI <= 6 && NW == 8;   // register budget: 16 fp32 per fragment
   f32x16 res[PREFETCH_RES ? NI : 1][PREFETCH_RES ? MI : 1];
   if (PREFETCH_RES) gemm_prefetch_residual<PREFETCH_RES ? NI : 1, PREFETCH_RES ? MI : 1>(p, res, m0 + wm * MI * 32, n0 + wn * NI * 32, l31, hh);
   int arow[MI], wrow[NI];

@@ -158,7 +158,8 @@ hipStream_t dec_stream(rk_engine* e, Slot& sl) { return e->opt_overlap ? sl.sd :
 template <int EPI, int WM, int WN, int MI, int NI>
 void launch_v2(hipStream_t st, const GemmArgs& a) {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
-  constexpr int smem = 2 * (BM + BN) * 64 * 2;
+  constexpr int smem_stages = 2 * (BM + BN) * 64 * 2, smem_epi = WM * WN * 32 * (NI * 32 * 4 + 16);
+  constexpr int smem = smem_stages > smem_epi ? smem_stages : smem_epi;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t rc = hipFuncSetAttribute((const void*)gemm_v2_kernel<EPI, WM, WN, MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -166,7 +167,7 @@ void launch_v2(hipStream_t st, const GemmArgs& a) {
     attr_done = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_v2_kernel<EPI, WM, WN, MI, NI>), dim3(tiles), dim3(512), smem, st, a);
+  hipLaunchKernelGGL((gemm_v2_kernel<EPI, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), smem, st, a);
 }
 
 // Tile-shape choice.  variant: 0 = auto, 1 = 128x128 (v1, two workgroups per CU), 2 = 256x256, 3 = 256x192,
@@ -194,6 +195,7 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
   if (variant == 2) { launch_v2<EPI, 2, 4, 4, 2>(st, a); return; }
   if (variant == 3 && EPI != EPI_GEGLU_F16) { launch_v2<EPI, 4, 2, 2, 3>(st, a); return; }
   if (variant == 4) { launch_v2<EPI, 4, 2, 2, 2>(st, a); return; }
+  // (a 16-wave 256x256 form, launch_v2<EPI, 4, 4, 2, 2>, measured 3-9 % slower than the 8-wave one: not instantiated)
   const int tiles = ((a.M + GEMM_BM - 1) / GEMM_BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
   if (e->opt_glds)
     hipLaunchKernelGGL((gemm_f16_kernel<EPI, true>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);

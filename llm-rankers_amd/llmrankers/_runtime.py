@@ -102,6 +102,28 @@ class T5Runtime:
     def score(self, seqs, dec_prefix, out_ids) -> np.ndarray:
         return np.concatenate([self.engine.score(c, dec_prefix, out_ids) for c in self._chunks(seqs)], axis=0)
 
+    def score_batches(self, batches, dec_prefix, out_ids) -> List[np.ndarray]:
+        """Score several independent batches, keeping the engine's batch slots full: batch i+1 is staged and its
+        encoder enqueued while the decoder chain of batch i still runs (rk_t5_stage_slot / rk_t5_score_slot).
+        Results are identical to calling score() per batch; only the waiting is overlapped."""
+        eng = self.engine
+        n_slots = eng.num_slots
+        work = [c for b in batches for c in self._chunks(b)]          # engine-capacity chunks, in order
+        owner = [i for i, b in enumerate(batches) for _ in self._chunks(b)]
+        out: List[List[np.ndarray]] = [[] for _ in batches]
+        pending = []                                                   # (slot, batch index) in submission order
+        for k, chunk in enumerate(work):
+            slot = k % n_slots
+            if len(pending) == n_slots:                                # the slot we are about to reuse must be drained
+                s0, b0 = pending.pop(0)
+                out[b0].append(eng.read_scores(s0))
+            eng.stage(chunk, slot=slot)
+            eng.score_staged(dec_prefix, out_ids, slot=slot)
+            pending.append((slot, owner[k]))
+        for s0, b0 in pending:
+            out[b0].append(eng.read_scores(s0))
+        return [np.concatenate(o, axis=0) if o else np.zeros((0, len(out_ids)), np.float32) for o in out]
+
     def qlm(self, seqs, labels) -> np.ndarray:
         return np.concatenate([self.engine.qlm(c, labels) for c in self._chunks(seqs)], axis=0)
 

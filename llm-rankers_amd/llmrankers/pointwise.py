@@ -86,6 +86,12 @@ class PointwiseLlmRanker(LlmRanker):
             doc.score = float(sc)
         return sorted(ranking, key=lambda x: x.score, reverse=True)
 
+    def _score_all(self, chunks, dec, out_ids):
+        """All batches of one query through the engine; pipelined across its batch slots when the runtime can."""
+        if hasattr(self.llm, "score_batches"):
+            return self.llm.score_batches(chunks, dec, out_ids)
+        return [self.llm.score(c, dec, out_ids) for c in chunks]
+
     def rerank(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
         if self.shard_candidates:
             from . import _dist
@@ -106,8 +112,8 @@ class PointwiseLlmRanker(LlmRanker):
             no_id = self.tokenizer.encode("No", add_special_tokens=False)[0]
             prompts = [YES_NO_PROMPT.format(text=doc.text, query=query) for doc in ranking]
             dec = [self.tokenizer.pad_token_id]
-            for s, chunk in self._scored_batches(prompts, 1):
-                lg = self.llm.score(chunk, dec, [yes_id, no_id])
+            todo = list(self._scored_batches(prompts, 1))
+            for (s, chunk), lg in zip(todo, self._score_all([c for _, c in todo], dec, [yes_id, no_id])):
                 p_yes = _softmax_first(lg[:, 0], lg[:, 1])
                 for i, sc in enumerate(p_yes):
                     ranking[s + i].score = float(sc)
@@ -126,8 +132,8 @@ class MonoT5LlmRanker(PointwiseLlmRanker):
         self._reset()
         prompts = [MONOT5_PROMPT.format(query=query, document=doc.text) for doc in ranking]
         dec = [self.llm.decoder_start_token_id]
-        for s, chunk in self._scored_batches(prompts, 1):
-            lg = self.llm.score(chunk, dec, [self.FALSE_ID, self.TRUE_ID])
+        todo = list(self._scored_batches(prompts, 1))
+        for (s, chunk), lg in zip(todo, self._score_all([c for _, c in todo], dec, [self.FALSE_ID, self.TRUE_ID])):
             p_true = _softmax_first(lg[:, 1], lg[:, 0])
             for i, sc in enumerate(p_true):
                 ranking[s + i].score = float(sc)

@@ -104,3 +104,15 @@ def test_setwise_cases(cases, stack):
         assert [ranker.total_compare, ranker.total_prompt_tokens, ranker.total_completion_tokens] == case["counters"], tag
         n += 1
     assert n >= 16
+
+
+def test_pipelined_batches_equal_blocking_calls(stack):
+    """T5Runtime.score_batches (two batch slots in flight) returns exactly what per-batch blocking calls return."""
+    from llmrankers import _synth
+    rt, _ = stack["ckpt_gated_untied"]
+    batches = [_synth.synth_token_batch(n, 5, 90, rt.dims.vocab, seed=40 + i) for i, n in enumerate([7, 3, 9, 1, 5])]
+    want = [rt.score(b, [0], [11, 12, 13]) for b in batches]
+    got = rt.score_batches(batches, [0], [11, 12, 13])
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
