@@ -46,8 +46,8 @@ def algorithmic_gflop_per_passage(d, L_e, L_d=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", default="flan-t5-large")
     ap.add_argument("--batch_size", type=int, default=32)
     ap.add_argument("--seq_len", type=int, default=184)
@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--no_profile", action="store_true")
     ap.add_argument("--glds", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="1: decoder chain of step i overlaps encoder of step i+1 (two HIP streams)")
+    ap.add_argument("--group", type=int, default=4, help="batches (steps) per engine launch sequence; 4 x 32 = one query's worth")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,33 +81,56 @@ def main():
     B, L = args.batch_size, args.seq_len
     t0 = time.time()
     state = _synth.synth_state_dict(dims, seed=929, threads=min(32, os.cpu_count() or 8))
-    eng = RkEngine(dims, device=local_rank, max_tokens=max(8192, B * L), max_seqs=max(32, B), max_dec_len=4)
+    eng = RkEngine(dims, device=local_rank, max_tokens=max(8192, args.group * B * L), max_seqs=max(32, args.group * B), max_dec_len=4)
     eng.load_state(state.items())
     eng.set_option("gemm_glds", args.glds)
     eng.set_option("overlap", args.overlap)
     if rank == 0:
         print(f"[bench] weights generated + engine finalized in {time.time() - t0:.1f}s", file=sys.stderr)
     n_slots = eng.num_slots
-    slot_seqs = [_synth.synth_token_batch(B, L, L, dims.vocab, seed=929 + rank * 16 + s) for s in range(n_slots)]
-    seqs = slot_seqs[0]
+    G = max(1, args.group)
+    # A step is one batch of B passages (the reference's batch_size).  The engine consumes steps in GROUPS of G batches
+    # per launch sequence (default 4 x 32 = 128 passages, about one query's candidate list at hits=100): the candidates
+    # of a query are all known up front, the reference's batch_size only shapes its host loop, and results do not depend
+    # on batch composition (ragged execution, bit-exact - tests).  Group i runs in slot i % n_slots; its decoder chain
+    # (own stream) overlaps the encoder of group i+1.  Steps that do not fill a last group are run as a smaller group.
+    def group_batch(n_batches, seed):
+        return [s for j in range(n_batches) for s in _synth.synth_token_batch(B, L, L, dims.vocab, seed=seed + j)]
+    slot_seqs = [group_batch(G, 929 + rank * 64 + 8 * s) for s in range(n_slots)]
+    seqs = slot_seqs[0][:B]
     for s in range(n_slots):
         eng.stage(slot_seqs[s], slot=s)                    # inputs resident in HBM before the timed region
     dec, out_ids = [0], [YES_ID, NO_ID]
-    gathered = torch.empty((world, B, 2), dtype=torch.float32, device="cuda") if world > 1 else None
-    state_i = {"i": 0}
+    gathered = torch.empty((world, G * B, 2), dtype=torch.float32, device="cuda") if world > 1 else None
+    state_i = {"i": 0, "launched": 0}
 
-    def gather(slot):                                      # one RCCL all_gather of a finished step's [B,2] scores
-        local = torch.from_numpy(eng.read_scores(slot)).cuda(non_blocking=True)
-        dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
+    def gather(slot):                                      # one RCCL all_gather of a finished group's [G*B,2] scores
+        sc = eng.read_scores(slot)
+        local = torch.zeros((G * B, 2), dtype=torch.float32)
+        local[:sc.shape[0]] = torch.from_numpy(sc)
+        dist.all_gather_into_tensor(gathered.view(-1), local.cuda(non_blocking=True).view(-1))
+
+    def launch_group():
+        g = state_i["launched"]
+        state_i["launched"] = g + 1
+        eng.score_staged(dec, out_ids, slot=g % n_slots)
+        if world > 1 and g > 0:
+            gather((g - 1) % n_slots)                      # lags one group behind so the pipeline stays full
 
     def step():
-        # steps are independent batches (a query's candidate list is 4 such batches): batch i runs in slot i%2, so
-        # its decoder chain (own stream) overlaps the encoder of batch i+1
         i = state_i["i"]
         state_i["i"] = i + 1
-        eng.score_staged(dec, out_ids, slot=i % n_slots)
-        if world > 1 and i > 0:
-            gather((i - 1) % n_slots)                      # lags one step behind so the pipeline stays full
+        if (i + 1) % G == 0:                               # the G-th batch of a group completes it: launch
+            launch_group()
+
+    def flush(total_steps):
+        rem = total_steps % G
+        if rem:                                            # leftover steps: a smaller group (re-stage a shorter slot)
+            slot = state_i["launched"] % n_slots
+            eng.sync()
+            eng.stage(slot_seqs[slot][:rem * B], slot=slot)
+            launch_group()
+        state_i["i"] = 0
 
     def fence():
         eng.sync()
@@ -117,13 +141,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    flush(args.warmup)
     fence()
+    for s_ in range(n_slots):
+        eng.stage(slot_seqs[s_], slot=s_)
     t_start = time.perf_counter()
     eng.timer_begin()
     for _ in range(args.steps):
         step()
+    flush(args.steps)
     if world > 1:
-        gather((state_i["i"] - 1) % n_slots)               # flush the last step's scores
+        gather((state_i["launched"] - 1) % n_slots)        # flush the last group's scores
     ev_ms = eng.timer_end()                                # HIP events on the engine's own streams
     fence()
     elapsed = time.perf_counter() - t_start
@@ -131,7 +159,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    scores = eng.read_scores(0)
+    scores = eng.read_scores(0)[:B]
     assert all(np.isfinite(eng.read_scores(s)).all() for s in range(n_slots))
 
     roofline = None
@@ -139,7 +167,8 @@ def main():
         eng.profile(True)
         eng.profile_reset()
         eng.set_option("overlap", 0)                        # per-kernel events need a serial timeline
-        for _ in range(min(args.steps, 5)):
+        n_prof = 3
+        for _ in range(n_prof):
             eng.score_staged(dec, out_ids, slot=0)
         eng.sync()
         rep = eng.profile_report()
@@ -155,7 +184,7 @@ def main():
                     "kernel": "gemm_f16_kernel (all encoder-side launches: qkv, o, ffn_in+GEGLU, ffn_out, cross_kv)",
                     "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches": int(g_n),
                     "gemm_share_of_gpu_time": round(g_ms / total_ms, 3) if total_ms else None,
-                    "per_class": {k: {"ms_per_step": round(v["ms"] / min(args.steps, 5), 4),
+                    "per_class": {k: {"ms_per_step": round(v["ms"] / (n_prof * G), 4),
                                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
                                   for k, v in rep.items() if v["launches"]}}
 
@@ -181,7 +210,8 @@ def main():
             "unit": "passages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 (MFMA inputs), f32 accumulate + residual stream", "data": "synthetic",
-            "config": {"workload": f"{args.model} pointwise yes_no, hits=100 batch_size={B} (one step = one batch), "
+            "config": {"engine_group": f"{G} batches ({G * B} passages) per engine launch sequence",
+                       "workload": f"{args.model} pointwise yes_no, hits=100 batch_size={B} (one step = one batch), "
                                    f"L_e={L} (128-token passage + 32-token query + template), L_d=1, 2 label rows",
                        "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world} (candidate sharding + 1 RCCL all_gather/step)",
                        "weights": "synthetic N(0, HF-init std), seed 929", "engine_stream_ms_per_step": round(ev_ms / args.steps, 3),

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
     gemm_epilogue_staged<EPI, 2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, gemm_smem + wave * (32 * (64 * 4 + 16)));
 }
 
-// ---- skinny GEMM: M <= 32 rows (the single-step decoder: M = sequences in the batch) ----------------------------
+// ---- skinny GEMM: few rows (the single-step decoder: M = sequences in the batch; 32 rows per blockIdx.z) --------
 // Weight-streaming regime: every weight element is used once, so W is never staged in LDS.  One 512-thread workgroup
 // owns NT consecutive 32-row weight tiles (NT = 2 for GEGLU: gate + up); its 8 waves take the K dimension in
 // interleaved 16-wide steps, each wave streams its weight rows straight from HBM into MFMA A fragments (16 B per
@@ -354,7 +354,8 @@ __global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p)
   const int l31 = lane & 31, hh = lane >> 5;
   const int n0 = blockIdx.x * 32 * NT;
   const int nsteps = p.K >> 4;
-  const int m = l31 < p.M ? l31 : p.M - 1;
+  const int mrow0 = blockIdx.z * 32;          // more than 32 rows: one workgroup per 32-row slab (weights re-read via L2)
+  const int m = mrow0 + l31 < p.M ? mrow0 + l31 : p.M - 1;
   p.A += (size_t)blockIdx.y * p.bsA;          // batched form: one small GEMM per blockIdx.y (e.g. per attention head)
   p.W += (size_t)blockIdx.y * p.bsW;
   p.C = (char*)p.C + (size_t)blockIdx.y * p.bsC * ((EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) ? 4 : 2);
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p)
     }
     __syncthreads();
   }
-  if (wave == 0) gemm_epilogue<EPI, NT, 1>(p, acc, 0, n0, l31, hh);
+  if (wave == 0) gemm_epilogue<EPI, NT, 1>(p, acc, mrow0, n0, l31, hh);
 }
 
 // ================================= GEMM v2: 256-row tiles ==================================================

@@ -90,7 +90,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 1, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1;
+  int opt_glds = 1, opt_skinny = 0x1F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
@@ -151,7 +151,9 @@ struct Bracket {
 };
 
 // overlap = 0 puts every launch of every slot on ONE stream (serial timeline, used for per-kernel event timing)
-hipStream_t enc_stream(rk_engine* e, Slot& sl) { return e->opt_overlap ? sl.se : e->slots[0].se; }
+// encoders alternate between TWO streams however many slots there are (more concurrent GEMM chains only thrash);
+// the extra slots exist to lengthen the distance between a decoder and the next encoder that reuses its buffers
+hipStream_t enc_stream(rk_engine* e, Slot& sl) { return e->opt_overlap ? e->slots[(&sl - e->slots) & 1].se : e->slots[0].se; }
 hipStream_t dec_stream(rk_engine* e, Slot& sl) { return e->opt_overlap ? sl.sd : e->slots[0].se; }
 
 // ---- kernel launch helpers ------------------------------------------------------------------------------
@@ -205,7 +207,7 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
 
 void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int lda, const half_t* W, int ldw, void* C,
           int ldc, int M, int N, int K, int n_split = 0, long split_stride = 0, float scale = 1.f,
-          int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0) {
+          int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0, bool weight_streaming = false) {
   if (M <= 0) return;
   GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale, bsA, bsW, bsC};
   const double flops = 2.0 * M * (double)N * K * batch;
@@ -213,15 +215,17 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
                        out_elems * (epi == EPI_RESID_F32 ? 8.0 : (epi == EPI_STORE_F32 ? 4.0 : 2.0));
   Bracket br(e, st, cls, flops, bytes);
-  if (M <= 32 && n_split == 0 && (e->opt_skinny || batch > 1)) {   // weight-streaming regime (single-step decoder, head)
+  // Kernel family is chosen by the CALLER's regime, never by M: a row's result must not depend on how many other rows
+  // share the launch (the split-K weight-streaming kernel and the tiled kernels sum K in different orders).
+  if ((weight_streaming || batch > 1) && n_split == 0 && (((e->opt_skinny >> epi) & 1) || batch > 1)) {
     const dim3 b(SKINNY_THREADS);
-    const unsigned gy = (unsigned)batch;
+    const unsigned gy = (unsigned)batch, gz = (unsigned)((M + 31) / 32);
     switch (epi) {
-      case EPI_STORE_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F16, 1>), dim3((N + 31) / 32, gy), b, 0, st, a); break;
-      case EPI_RESID_F32: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RESID_F32, 1>), dim3((N + 31) / 32, gy), b, 0, st, a); break;
-      case EPI_GEGLU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_GEGLU_F16, 2>), dim3((N + 63) / 64, gy), b, 0, st, a); break;
-      case EPI_RELU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RELU_F16, 1>), dim3((N + 31) / 32, gy), b, 0, st, a); break;
-      default: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F32, 1>), dim3((N + 31) / 32, gy), b, 0, st, a); break;
+      case EPI_STORE_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F16, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
+      case EPI_RESID_F32: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RESID_F32, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
+      case EPI_GEGLU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_GEGLU_F16, 2>), dim3((N + 63) / 64, gy, gz), b, 0, st, a); break;
+      case EPI_RELU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RELU_F16, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
+      default: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F32, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
     }
     return;
   }
@@ -299,7 +303,7 @@ int upload_small(rk_engine* e, Slot& sl, hipStream_t st, std::vector<int>* cache
 // ---- forward passes -----------------------------------------------------------------------------------------
 // hf: modeling_t5.py:663-750 (T5Stack.forward, encoder) over the slot's staged ragged batch, then the stacked
 // cross-attention K/V projections of all decoder layers (:325-326 with key_value_states = encoder output).
-#define XA_MAX_ROWS 32      // decoder rows (sequences x positions) the direct cross-attention path handles
+#define XA_MAX_ROWS 128     // decoder rows (sequences x positions) the direct cross-attention path handles
 #define XA_MAX_CHUNKS 1024  // rows x 64-key chunks of partial-sum workspace
 
 // query-side cross-attention (attention.h) applies when the decoder has at most XA_MAX_ROWS rows in every step
@@ -350,6 +354,7 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
   const rk_model_desc& d = e->d;
   hipStream_t st = dec_stream(e, sl);
   const int B = sl.n_seq, M = B * Ld, I = e->inner, dm = d.d_model, F = d.d_ff;
+  const bool ws = Ld <= 4;   // few decoder positions: weight-streaming GEMMs (any number of sequences); else tiled
   embed(e, st, sl.d_dec_ids, sl.dhidden, M);
   const size_t smem_self = (64 + 256 + 8 + (size_t)Ld) * sizeof(float);
   const size_t smem_cross = (64 + 256 + 8 + (size_t)sl.maxL) * sizeof(float);
@@ -360,16 +365,16 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
       // one decoder position: softmax over a single key is 1, so self-attention is exactly o(v(x)) — the q/k
       // projections, scores and bias are dead (hf: modeling_t5.py:448-509 at L_d = 1)
       // ... and o(v(x)) = (W_o W_v) x: one GEMM with the product matrix formed once at finalize
-      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dxn, dm, w.ov, dm, sl.dhidden, dm, M, dm, dm);
+      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dxn, dm, w.ov, dm, sl.dhidden, dm, M, dm, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
     } else {
-      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.qkv, dm, sl.dqkv, 3 * I, M, 3 * I, dm);
+      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.qkv, dm, sl.dqkv, 3 * I, M, 3 * I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
       AttnDecArgs a{sl.dqkv, 3 * I, sl.dqkv + I, sl.dqkv + 2 * I, 3 * I, nullptr, sl.dctx, I, e->lut_dec, Ld, 1, Ld};
       Bracket br(e, st, PC_DEC_ATTN, 4.0 * M * Ld * I, 0);
       hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_self, st, a);
-      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.o, I, sl.dhidden, dm, M, dm, I);
+      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.o, I, sl.dhidden, dm, M, dm, I, 0, 0, 1.f, 1, 0, 0, 0, ws);
     }
     rmsnorm(e, st, sl.dhidden, w.ln1, sl.dxn, nullptr, M);
-    gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.cq, dm, sl.dq, I, M, I, dm);
+    gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.cq, dm, sl.dq, I, M, I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
     if (!sl.have_cross_kv) {
       // query-side cross-attention: qk = W_k^T q per head; scores/softmax/weighted sum over the raw encoder states;
       // ctx = W_v (.) per head  (attention.h: XAttnArgs)
@@ -389,13 +394,13 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
       Bracket br(e, st, PC_DEC_ATTN, 4.0 * Ld * (double)sl.T * I, (double)sl.T * 2 * I * 2.0);
       hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_cross, st, a);
     }
-    gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.co, I, sl.dhidden, dm, M, dm, I);
+    gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.co, I, sl.dhidden, dm, M, dm, I, 0, 0, 1.f, 1, 0, 0, 0, ws);
     rmsnorm(e, st, sl.dhidden, w.ln2, sl.dxn, nullptr, M);
     if (d.gated_gelu)
-      gemm(e, st, PC_DEC_GEMM, EPI_GEGLU_F16, sl.dxn, dm, w.ffn_in, dm, sl.dffh, F, M, 2 * F, dm);
+      gemm(e, st, PC_DEC_GEMM, EPI_GEGLU_F16, sl.dxn, dm, w.ffn_in, dm, sl.dffh, F, M, 2 * F, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
     else
-      gemm(e, st, PC_DEC_GEMM, EPI_RELU_F16, sl.dxn, dm, w.ffn_in, dm, sl.dffh, F, M, F, dm);
-    gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dffh, F, w.ffn_out, F, sl.dhidden, dm, M, dm, F);
+      gemm(e, st, PC_DEC_GEMM, EPI_RELU_F16, sl.dxn, dm, w.ffn_in, dm, sl.dffh, F, M, F, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
+    gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dffh, F, w.ffn_out, F, sl.dhidden, dm, M, dm, F, 0, 0, 1.f, 1, 0, 0, 0, ws);
   }
   HIPCHK(e, hipGetLastError());
   return RK_OK;
@@ -517,7 +522,8 @@ int score_slot(rk_engine* e, int slot, const int32_t* dec_prefix, int dec_len, c
   for (int b = 0; b < sl.n_seq; ++b) rows[b] = b * dec_len + dec_len - 1;
   if ((rc = upload_small(e, sl, sd, &sl.cache_rows, sl.d_last_rows, 2, rows.data(), sl.n_seq))) return rc;
   if ((rc = encoder_then_handoff(e, sl, dec_len))) return rc;
-  if ((rc = run_decoder(e, sl, dec_len))) return rc;
+  static const bool skip_dec = getenv("RK_DEBUG_SKIP_DECODER") != nullptr;   // measurement only: encoder-chain floor
+  if (!skip_dec && (rc = run_decoder(e, sl, dec_len))) return rc;
   rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, sl.n_seq, head_scale(e));
   {
     Bracket br(e, sd, PC_HEAD, 2.0 * sl.n_seq * n_out * e->d.d_model, 0);
@@ -576,8 +582,8 @@ int rk_engine_create(const rk_model_desc* desc, int device_ordinal, rk_engine** 
   // the decoder chain is a long sequence of tiny dependent kernels: give it dispatch priority over the encoder's
   // chip-filling GEMM grids so it progresses while they run
   for (int i = 0; ok && i < RK_SLOTS; ++i)
-    ok = hipStreamCreateWithPriority(&e->slots[i].se, hipStreamNonBlocking, prio_lo) == hipSuccess &&
-         hipStreamCreateWithPriority(&e->slots[i].sd, hipStreamNonBlocking, prio_hi) == hipSuccess;
+    ok = hipStreamCreateWithPriority(&e->slots[i].se, hipStreamNonBlocking, getenv("RK_ENC_PRIO_HI") ? prio_hi : prio_lo) == hipSuccess &&
+         hipStreamCreateWithPriority(&e->slots[i].sd, hipStreamNonBlocking, getenv("RK_DEC_PRIO_LO") ? prio_lo : prio_hi) == hipSuccess;
   ok = ok && hipEventCreate(&e->t0) == hipSuccess && hipEventCreate(&e->t1) == hipSuccess &&
        hipEventCreateWithFlags(&e->t_tmp, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; ok && i < RK_SLOTS; ++i)
@@ -931,7 +937,8 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
     sl.cache_dec.clear(); sl.cache_rows.clear();
     if ((rc = run_decoder(e, sl, Ld))) return rc;
     rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, n_seq, head_scale(e));
-    gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dlast, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, n_seq, e->d.vocab, e->d.d_model);
+    gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dlast, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, n_seq, e->d.vocab, e->d.d_model,
+         0, 0, 1.f, 1, 0, 0, 0, true);
     hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_seq), dim3(256), 0, sd, e->logits, e->d.vocab, e->d.vocab, sl.d_argmax);
     HIPCHK(e, hipMemcpyAsync(amax.data(), sl.d_argmax, n_seq * sizeof(int), hipMemcpyDeviceToHost, sd));
     HIPCHK(e, hipStreamSynchronize(sd));
@@ -1018,7 +1025,7 @@ int rk_profile_get(rk_engine* e, int cls, double* total_ms, int64_t* launches, d
 int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!e || !key) return RK_ERR_INVALID;
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
-  if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value != 0; return RK_OK; }
+  if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x1F : value; return RK_OK; }   // bit per epilogue kind
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
   if (!strcmp(key, "attn_short")) { e->opt_attn_short = value != 0; return RK_OK; }   // whole-KV-in-LDS kernel for L <= 192
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..4 see choose_variant
@@ -1042,8 +1049,8 @@ int rk_debug_gemm(rk_engine* e, const uint16_t* A, const uint16_t* W, float* C, 
   HIPCHK(e, hipMemcpy(dA, A, (size_t)M * K * 2, hipMemcpyHostToDevice));
   HIPCHK(e, hipMemcpy(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice));
   const int saved = e->opt_glds;
-  e->opt_glds = use_glds;
-  gemm(e, e->slots[0].se, PC_OTHER, EPI_STORE_F32, dA, K, dW, K, dC, N, M, N, K);
+  e->opt_glds = use_glds != 0;
+  gemm(e, e->slots[0].se, PC_OTHER, EPI_STORE_F32, dA, K, dW, K, dC, N, M, N, K, 0, 0, 1.f, 1, 0, 0, 0, /*weight_streaming=*/use_glds == 2);
   e->opt_glds = saved;
   HIPCHK(e, hipStreamSynchronize(e->slots[0].se));
   HIPCHK(e, hipGetLastError());

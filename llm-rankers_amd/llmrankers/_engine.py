@@ -254,7 +254,7 @@ class RkEngine:
         self._chk(self.lib.rk_engine_set_option(self.h, key.encode(), int(value)))
 
     # -- debug ---------------------------------------------------------------------------------------------
-    def debug_gemm(self, a16: np.ndarray, w16: np.ndarray, use_glds: bool = True) -> np.ndarray:
+    def debug_gemm(self, a16: np.ndarray, w16: np.ndarray, use_glds=True) -> np.ndarray:
         a16 = np.ascontiguousarray(a16, dtype=np.float16)
         w16 = np.ascontiguousarray(w16, dtype=np.float16)
         m, k = a16.shape

@@ -63,6 +63,20 @@ def test_gemm_vs_numpy(toy, shape, variant, glds):
         f"bad rows {np.unique(np.where(err > 1e-2 * np.sqrt(k))[0])[:16]} bad cols {np.unique(np.where(err > 1e-2 * np.sqrt(k))[1])[:16]}"
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 64), (32, 128, 1024), (33, 96, 192), (100, 1024, 2816)])
+def test_weight_streaming_gemm_vs_numpy(toy, shape):
+    """The decoder's split-K kernel: fixed reduction tree -> every row is independent of how many rows share the launch."""
+    m, n, k = shape
+    rs = np.random.RandomState(m * n + k)
+    a = rs.standard_normal((m, k)).astype(np.float16)
+    w = rs.standard_normal((n, k)).astype(np.float16)
+    eng = toy["ckpt_gated_untied"][2]
+    got = eng.debug_gemm(a, w, use_glds=2)
+    want = a.astype(np.float32) @ w.astype(np.float32).T
+    assert np.abs(got - want).max() < 2e-3 * np.sqrt(k)
+    np.testing.assert_array_equal(eng.debug_gemm(a[m - 1:], w, use_glds=2)[0], got[m - 1])
+
+
 def test_encoder_stages_one_layer():
     """1-layer model: every intermediate buffer vs the oracle (localises a wrong kernel)."""
     from llmrankers import _synth

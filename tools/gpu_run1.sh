@@ -9,7 +9,7 @@ timeout 600 python -c "import torch; import __graft_entry__ as g; g.smoke()" > g
 echo "smoke (torch imported first) rc=$?"; tail -3 gpurun_out/smoke_torch.log
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest -m gpu rc=$?"; tail -60 gpurun_out/pytest_gpu.log
-timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.json 2> gpurun_out/bench.err
+timeout 900 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
 echo "bench rc=$?"; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
-timeout 300 python bench.py --steps 10 --warmup 2 --overlap 0 --no_cpu_baseline > gpurun_out/bench_nooverlap.json 2>> gpurun_out/bench.err
-echo "bench(no overlap) rc=$?"; cat gpurun_out/bench_nooverlap.json
+timeout 300 python bench.py --group 1 --no_cpu_baseline > gpurun_out/bench_nooverlap.json 2>> gpurun_out/bench.err
+echo "bench(group=1) rc=$?"; cat gpurun_out/bench_nooverlap.json
