@@ -179,9 +179,23 @@ def main():
         g_n = sum(rep[c]["launches"] for c in gemm_classes)
         achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         total_ms = sum(v["ms"] for v in rep.values())
+        # HBM-side traffic of the dominant GEMM kernel comes from rocprofv3 PMC passes of THIS command (tools/gpu_prof.sh:
+        # FETCH_SIZE and WRITE_SIZE each in their own --pmc run; gfx950: FETCH_SIZE x2 for wide coalesced reads, KiB units;
+        # MI355X_MICROARCH.md HBM section), summarised per launch in profiles/pmc_summary_latest.json.
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(REPO, "profiles", "pmc_summary_latest.json")) as f:
+                pm = json.load(f)["kernels"]
+            gk = [(v["stats"]["pct"], k, v) for k, v in pm.items() if "gemm_" in k and v.get("stats") and "FETCH_SIZE" in v["pmc"]]
+            if gk:
+                _, kname, v = max(gk)
+                traffic = int((2 * v["pmc"]["FETCH_SIZE"]["avg_per_launch"] + v["pmc"]["WRITE_SIZE"]["avg_per_launch"]) * 1024)
+                traffic_src = f"bytes per launch of {kname} (largest share of GPU time), rocprofv3 PMC, profiles/pmc_summary_latest.json"
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "kernel": "gemm_f16_kernel (all encoder-side launches: qkv, o, ffn_in+GEGLU, ffn_out, cross_kv)",
+                    "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": "tiled fp16 MFMA GEMM family gemm_v2_kernel / gemm_f16_kernel (all encoder launches: qkv, o, ffn_in+GEGLU, ffn_out)",
                     "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches": int(g_n),
                     "gemm_share_of_gpu_time": round(g_ms / total_ms, 3) if total_ms else None,
                     "per_class": {k: {"ms_per_step": round(v["ms"] / (n_prof * G), 4),
