@@ -46,8 +46,8 @@ def algorithmic_gflop_per_passage(d, L_e, L_d=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--model", default="flan-t5-large")
     ap.add_argument("--batch_size", type=int, default=32)
     ap.add_argument("--seq_len", type=int, default=184)
@@ -55,7 +55,9 @@ def main():
     ap.add_argument("--no_profile", action="store_true")
     ap.add_argument("--glds", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="1: decoder chain of step i overlaps encoder of step i+1 (two HIP streams)")
-    ap.add_argument("--group", type=int, default=4, help="batches (steps) per engine launch sequence; 4 x 32 = one query's worth")
+    ap.add_argument("--group", type=int, default=8,
+                    help="batches (steps) per engine launch sequence: 8 x 32 passages x 184 tokens = 184 GEMM tile rows, which fills "
+                         "the 256 CUs in whole rounds for every encoder GEMM (tiles: 2208 / 736 / 4048 / 736)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,7 +92,7 @@ def main():
     n_slots = eng.num_slots
     G = max(1, args.group)
     # A step is one batch of B passages (the reference's batch_size).  The engine consumes steps in GROUPS of G batches
-    # per launch sequence (default 4 x 32 = 128 passages, about one query's candidate list at hits=100): the candidates
+    # per launch sequence (default 8 x 32 = 256 passages): the candidates
     # of a query are all known up front, the reference's batch_size only shapes its host loop, and results do not depend
     # on batch composition (ragged execution, bit-exact - tests).  Group i runs in slot i % n_slots; its decoder chain
     # (own stream) overlaps the encoder of group i+1.  Steps that do not fill a last group are run as a smaller group.

@@ -28,6 +28,50 @@ struct AttnEncArgs {
 #define ATT_KSTR 72   // sK row stride in halfs (144 B: 16-B aligned, conflict-free b128 reads)
 #define ATT_VSTR 68   // sVt row stride in halfs (136 B: 8-B aligned, conflict-free b64 reads)
 
+// Online-softmax step for one 64-key tile, shared by both encoder attention kernels so that they stay bit-identical
+// (a sequence must score the same whichever kernel its batch selects).  s0 / s1: raw q.k of this lane's query against
+// keys key_base + (r&3) + 8(r>>2) (+32 for s1); on return they hold the unnormalised probabilities relative to the new
+// running maximum.  Everything is in the log2 domain: t = s * log2(e) + bias * log2(e) (one FMA, the tables are
+// pre-multiplied) and p = exp2(t - m) (one v_exp_f32).  MASK: the tile contains keys >= L (only the last one can).
+// FIRST: tile 0 - no previous maximum, no rescale of the (zero) output accumulators.  bias(r, sub) returns the table
+// entry for register r of s0 (sub = 0) or s1 (sub = 1).
+#define ATT_LOG2E 1.4426950408889634f
+template <bool MASK, bool FIRST, class BiasFn>
+__device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m_run, float& l_run,
+                                                  int key_base, int L, BiasFn bias) {
+  float tmax = -1e30f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    s0[r] = fmaf(s0[r], ATT_LOG2E, bias(r, 0));
+    s1[r] = fmaf(s1[r], ATT_LOG2E, bias(r, 1));
+    if (MASK) {
+      const int key0 = key_base + (r & 3) + 8 * (r >> 2);
+      s0[r] = key0 < L ? s0[r] : -1e30f;
+      s1[r] = key0 + 32 < L ? s1[r] : -1e30f;
+    }
+    tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
+  }
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+  const float m_new = FIRST ? tmax : fmaxf(m_run, tmax);
+  float psum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+    s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+    psum += s0[r] + s1[r];
+  }
+  psum += __shfl_xor(psum, 32);
+  if (FIRST) {
+    l_run = psum;
+  } else {
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+  }
+  m_run = m_new;
+}
+
 __global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
   __shared__ __attribute__((aligned(16))) half_t sK[2][64 * ATT_KSTR];
   __shared__ __attribute__((aligned(16))) half_t sVt[2][64 * ATT_VSTR];
@@ -38,7 +82,7 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
   if (qt * 128 >= L) return;   // uniform for the whole block
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int hh = lane >> 5, l31 = lane & 31;
-  for (int i = tid; i < RK_LUT_N; i += 256) sLut[i] = p.bias_lut[h * RK_LUT_N + i];
+  for (int i = tid; i < RK_LUT_N; i += 256) sLut[i] = p.bias_lut[h * RK_LUT_N + i] * ATT_LOG2E;
   const int q0 = qt * 128 + wave * 32;
   const bool wave_active = q0 < L;
   const int qpos = q0 + l31;
@@ -94,33 +138,22 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
       }
-      float tmax = -1e30f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key0 = kt * 64 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int key1 = key0 + 32;
-        int rel0 = key0 - qpos, rel1 = key1 - qpos;
-        rel0 = rel0 < -RK_LUT_R ? -RK_LUT_R : (rel0 > RK_LUT_R ? RK_LUT_R : rel0);
-        rel1 = rel1 < -RK_LUT_R ? -RK_LUT_R : (rel1 > RK_LUT_R ? RK_LUT_R : rel1);
-        s0[r] = key0 < L ? s0[r] + sLut[rel0 + RK_LUT_R] : -1e30f;
-        s1[r] = key1 < L ? s1[r] + sLut[rel1 + RK_LUT_R] : -1e30f;
-        tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
+      {
+        const int key_base = kt * 64 + 4 * hh;
+        auto bias = [&](int r, int sub) {
+          int rel = key_base + (r & 3) + 8 * (r >> 2) + 32 * sub - qpos;
+          rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
+          return sLut[rel + RK_LUT_R];
+        };
+        const bool last = kt == nkt - 1;
+        if (kt == 0) {
+          if (last) attn_tile_softmax<true, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+          else attn_tile_softmax<false, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+        } else {
+          if (last) attn_tile_softmax<true, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+          else attn_tile_softmax<false, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+        }
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = __expf(m_run - m_new);
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s0[r] = __expf(s0[r] - m_new);
-        s1[r] = __expf(s1[r] - m_new);
-        psum += s0[r] + s1[r];
-      }
-      psum += __shfl_xor(psum, 32);
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -189,13 +222,17 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
 __global__ __launch_bounds__(384) void attn_enc_short_kernel(AttnEncArgs p) {
   __shared__ __attribute__((aligned(16))) half_t sK[ATTS_MAXL * ATT_KSTR];
   __shared__ __attribute__((aligned(16))) half_t sVt[64 * ATTS_VSTR];
-  __shared__ float sLut[RK_LUT_N + 3];
+  __shared__ float sLutX[2 * ATTS_MAXL];   // table over every (key - query) in (-192, 192): no clamp in the loop
   const int b = blockIdx.y, h = blockIdx.x;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int hh = lane >> 5, l31 = lane & 31;
-  for (int i = tid; i < RK_LUT_N; i += 384) sLut[i] = p.bias_lut[h * RK_LUT_N + i];
+  for (int i = tid; i < 2 * ATTS_MAXL - 1; i += 384) {
+    int rel = i - (ATTS_MAXL - 1);
+    rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
+    sLutX[i] = p.bias_lut[h * RK_LUT_N + rel + RK_LUT_R] * ATT_LOG2E;
+  }
   const int nkt = (L + 63) >> 6;
   const int nrows = nkt * 64;
   // K rows: 16-B chunks, row-major (clamped rows are masked later)
@@ -230,6 +267,7 @@ __global__ __launch_bounds__(384) void attn_enc_short_kernel(AttnEncArgs p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
+  const float* lut_q = sLutX + (ATTS_MAXL - 1) - qpos + 4 * hh;   // lut_q[key - 4hh] = bias(key - qpos) * log2(e)
   __syncthreads();
   if (wave_active) {
     for (int kt = 0; kt < nkt; ++kt) {
@@ -244,33 +282,19 @@ __global__ __launch_bounds__(384) void attn_enc_short_kernel(AttnEncArgs p) {
         s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
       }
-      float tmax = -1e30f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key0 = kt * 64 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int key1 = key0 + 32;
-        int rel0 = key0 - qpos, rel1 = key1 - qpos;
-        rel0 = rel0 < -RK_LUT_R ? -RK_LUT_R : (rel0 > RK_LUT_R ? RK_LUT_R : rel0);
-        rel1 = rel1 < -RK_LUT_R ? -RK_LUT_R : (rel1 > RK_LUT_R ? RK_LUT_R : rel1);
-        s0[r] = key0 < L ? s0[r] + sLut[rel0 + RK_LUT_R] : -1e30f;
-        s1[r] = key1 < L ? s1[r] + sLut[rel1 + RK_LUT_R] : -1e30f;
-        tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
+      {
+        const int key_base = kt * 64 + 4 * hh;
+        const float* lq = lut_q + kt * 64;               // this query's table row, shifted to the tile's first key
+        auto bias = [&](int r, int sub) { return lq[(r & 3) + 8 * (r >> 2) + 32 * sub]; };
+        const bool last = kt == nkt - 1;
+        if (kt == 0) {
+          if (last) attn_tile_softmax<true, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+          else attn_tile_softmax<false, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+        } else {
+          if (last) attn_tile_softmax<true, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+          else attn_tile_softmax<false, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+        }
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = __expf(m_run - m_new);
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s0[r] = __expf(s0[r] - m_new);
-        s1[r] = __expf(s1[r] - m_new);
-        psum += s0[r] + s1[r];
-      }
-      psum += __shfl_xor(psum, 32);
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll

@@ -17,6 +17,7 @@
 // (gelu_new(wi_0 x) * wi_1 x with wi_0/wi_1 rows interleaved in groups of 32 by the weight packer), ReLU.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 enum GemmEpi { EPI_STORE_F16 = 0, EPI_RESID_F32 = 1, EPI_GEGLU_F16 = 2, EPI_RELU_F16 = 3, EPI_STORE_F32 = 4 };
 
@@ -533,4 +534,208 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void gemm_v2_kernel(Gemm
   } else
     gemm_epilogue_staged<EPI, NI, MI>(p, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, lane,
                                       gemm_smem + wave * (32 * (NI * 32 * 4 + 16)));
+}
+
+// ================================= GEMM v3: 256x256 ping-pong ================================================
+// The v2 loop above leaves the matrix pipe idle while a wave waits for its fragment reads (every k16 step begins with
+// ds_reads + lgkmcnt(0)) and drains the DMA queue once per K tile.  This kernel keeps the 256x256x64 tile, 8 waves and
+// the LDS image (128-B rows, XOR swizzle, DMA with the swizzle on the source address) but changes the schedule:
+//   * the two waves that share a SIMD (w and w+4) run HALF A PHASE APART: while one executes the MFMAs of a phase the
+//     other issues its ds_reads for the next one, and they swap at every s_barrier (group 1 runs one barrier ahead);
+//   * the tile rows are dealt to four 16 KiB HALF-TILES per K tile so that a wave's work splits into two super-phases
+//     whose operands arrive separately, while its outputs still form ONE contiguous 128 x 64 block (A half h holds tile
+//     rows 128*wm + 64h + [0,64), W half h rows 64*wn + 32h + [0,32)) - the epilogues (incl. the gate/up pairing of
+//     GEGLU) are the v2 ones;
+//   * DMA loads are issued BETWEEN the MFMAs of the issuing wave and waited for with COUNTED vmcnt (never 0 in the
+//     loop), one super-phase before the data is read, followed by a barrier (the ordering LDS-DMA needs).
+// What was measured on the way (tools/gemm_bench.py knock-out variants, 4096^3, profiles/r01e_gemm_pingpong.txt): an
+// 8-phase form (8 MFMA per phase, DMA issued in the read section) ran 122 us = no better than v2; MFMA + barriers alone
+// take 70 us with zero operands but 94 us with random operand bits (the chip clocks to its power budget), DMA alone
+// 53-56 us, fragment reads alone 41 us; moving the DMA issue among the MFMAs gave 119 us, 16-MFMA phases 113-117 us
+// (1.18-1.21 PF; DMA now costs ~12 us and the reads ~7 us over the 94 us MFMA floor).  Issuing the DMA BEFORE the reads
+// of a phase was 10 % slower.
+template <int N>
+__device__ __forceinline__ void gemm_wait_vmcnt() {
+  static_assert(N >= 0 && N <= 10 && N % 2 == 0, "counted vmcnt values used by the ping-pong kernel");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+}
+
+// Per K tile t (LDS stage t&1):   SP0: read A0, W0, W1 (16 ds_read_b128) | 16 MFMA: (A0,W0) (A0,W1)
+//                                 SP1: read A1 (8)                        | 16 MFMA: (A1,W0) (A1,W1)
+// Half-tile order n = 4t + {A0, W0, W1, A1}; the MFMA section of super-phase g issues half-tiles 2g+6 and 2g+7 (two DMA
+// instructions each per wave, after MFMA 1, 5, 9 and 13), so six half-tiles are in flight behind the one being computed;
+// counted waits before the first barrier of g: vmcnt(4) for even g (A1(t) landed), vmcnt(2) for odd g (A0, W0, W1 of
+// t+1 landed).  Buffer n mod 8 is re-filled in super-phase floor(n/2)+1 or later, one full barrier after its last
+// reader (group 1) has its fragments in registers.  Every accumulator sees the K tiles, and the four k16 steps inside
+// one, in increasing order with the same operand slots as the v1/v2 kernels: results are bit-identical to theirs.
+// Needs K >= 128 (two K tiles).  KO: timing-only knock-outs for bottleneck hunting (results are garbage): 1 = no DMA in
+// the loop, 2 = no fragment reads, 4 = no MFMA.  Product code instantiates KO = 0 only.
+template <int EPI, int KO = 0>
+__global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
+  constexpr int HALF = 128 * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+  half_t* smem = (half_t*)gemm_smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int grp = wave >> 2, wm = wave & 1, wn = (wave >> 1) & 3;
+  const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+  int tm, tn;
+  gemm_tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  unsigned off[4][2];   // kind 0 = A0, 1 = A1, 2 = W0, 3 = W1; byte offsets of this wave's two DMA instructions
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ga = m0 + 128 * (r >> 6) + 64 * h + (r & 63);
+      ga = ga < p.M ? ga : p.M - 1;
+      off[h][j] = ((unsigned)ga * (unsigned)p.lda + chunk * 8) * 2u;
+      int gw = n0 + 64 * (r >> 5) + 32 * h + (r & 31);
+      gw = gw < p.N ? gw : p.N - 1;
+      off[2 + h][j] = ((unsigned)gw * (unsigned)p.ldw + chunk * 8) * 2u;
+    }
+  }
+  // buffer of (kind, stage) at (kind * 2 + stage) * 16 KiB
+  auto issue1 = [&](auto kindc, int stage, int tile, auto jc) {
+    constexpr int kind = decltype(kindc)::value, j = decltype(jc)::value;
+    const char* base = (const char*)((kind < 2 ? p.A : p.W) + tile * 64);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[kind][j]),
+                                     (__attribute__((address_space(3))) void*)(smem + (kind * 2 + stage) * HALF + (wave * 2 + j) * 512),
+                                     16, 0, 0);
+  };
+  using std::integral_constant;
+  using I0 = integral_constant<int, 0>; using I1 = integral_constant<int, 1>;
+  using I2 = integral_constant<int, 2>; using I3 = integral_constant<int, 3>;
+
+  const int xs = (l31 >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = ((ks * 2 + hh) ^ xs) << 3;
+  const int a_lane = (wm * 64 + l31) * 64, w_lane = (wn * 32 + l31) * 64;
+  half8 aF[2][4], w0F[4], w1F[4];
+  if constexpr (KO != 0) {   // knock-out runs keep non-trivial operand bits (MFMA power depends on the data)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      union { unsigned u[4]; half8 h; } x;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const unsigned hsh = (unsigned)(lane * 2654435761u + ks * 40503u + i * 9973u + wave * 77u); x.u[i] = (hsh & 0x8FFF8FFFu) | 0x30003000u; }
+      aF[0][ks] = x.h; w0F[ks] = x.h;
+      x.u[0] ^= 0x80000000u; x.u[2] ^= 0x00008000u;
+      aF[1][ks] = x.h; w1F[ks] = x.h;
+    }
+  }
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // one super-phase.  SP: 0 / 1;  ISSUE: the two half-tiles this phase's MFMA section prefetches exist;
+  // WAIT: vmcnt count before the first barrier (-1 = none)
+  auto sp = [&](auto spc, auto issuec, auto waitc, int t) {
+    constexpr int SP = decltype(spc)::value, WAIT = decltype(waitc)::value;
+    constexpr bool ISSUE = decltype(issuec)::value && !(KO & 1);
+    const int st = t & 1;
+    if constexpr (!(KO & 2)) {
+      if constexpr (SP == 0) {
+        const half_t* sw0 = smem + (4 + st) * HALF + w_lane;
+        const half_t* sw1 = smem + (6 + st) * HALF + w_lane;
+        const half_t* sa = smem + (0 + st) * HALF + a_lane;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) w0F[ks] = *(const half8*)(sw0 + koff[ks]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { aF[0][ks] = *(const half8*)(sa + koff[ks]); aF[1][ks] = *(const half8*)(sa + 2048 + koff[ks]); }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) w1F[ks] = *(const half8*)(sw1 + koff[ks]);
+      } else {
+        const half_t* sa = smem + (2 + st) * HALF + a_lane;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { aF[0][ks] = *(const half8*)(sa + koff[ks]); aF[1][ks] = *(const half8*)(sa + 2048 + koff[ks]); }
+      }
+    }
+    if constexpr (WAIT >= 0 && !(KO & 1)) gemm_wait_vmcnt<WAIT >= 0 ? WAIT : 0>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr ((KO & 4) != 0) {   // keep the fragment reads alive when the MFMAs are knocked out
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) asm volatile("" :: "v"(aF[0][ks]), "v"(aF[1][ks]), "v"(w0F[ks]), "v"(w1F[ks]));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ni = q >> 1, mi = q & 1;
+        if constexpr (!(KO & 4))
+          acc[ni][2 * SP + mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ni == 0 ? w0F[ks] : w1F[ks], aF[mi][ks], acc[ni][2 * SP + mi], 0, 0, 0);
+        if constexpr (ISSUE) {
+          if (q == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            // SP0 of tile t prefetches W1(t+1), A1(t+1); SP1 prefetches A0(t+2), W0(t+2)  (stage of tile t+1 = st^1, t+2 = st)
+            if constexpr (SP == 0) {
+              if (ks == 0) issue1(I3{}, st ^ 1, t + 1, I0{});
+              if (ks == 1) issue1(I3{}, st ^ 1, t + 1, I1{});
+              if (ks == 2) issue1(I1{}, st ^ 1, t + 1, I0{});
+              if (ks == 3) issue1(I1{}, st ^ 1, t + 1, I1{});
+            } else {
+              if (ks == 0) issue1(I0{}, st, t + 2, I0{});
+              if (ks == 1) issue1(I0{}, st, t + 2, I1{});
+              if (ks == 2) issue1(I2{}, st, t + 2, I0{});
+              if (ks == 3) issue1(I2{}, st, t + 2, I1{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: half-tiles 0..5 = tile 0 complete, A0 and W0 of tile 1 ----
+  issue1(I0{}, 0, 0, I0{}); issue1(I0{}, 0, 0, I1{});
+  issue1(I2{}, 0, 0, I0{}); issue1(I2{}, 0, 0, I1{});
+  issue1(I3{}, 0, 0, I0{}); issue1(I3{}, 0, 0, I1{});
+  issue1(I1{}, 0, 0, I0{}); issue1(I1{}, 0, 0, I1{});
+  issue1(I0{}, 1, 1, I0{}); issue1(I0{}, 1, 1, I1{});
+  issue1(I2{}, 1, 1, I0{}); issue1(I2{}, 1, 1, I1{});
+  gemm_wait_vmcnt<6>();                        // A0, W0, W1 of tile 0 landed (this wave's share)
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier ahead: its MFMAs meet group 0's reads
+  __builtin_amdgcn_sched_barrier(0);
+
+  using Yes = integral_constant<bool, true>; using No = integral_constant<bool, false>;
+  using W4 = integral_constant<int, 4>; using W2 = integral_constant<int, 2>; using W0c = integral_constant<int, 0>;
+  using WN = integral_constant<int, -1>;
+  const int nk = p.K >> 6;
+  int t = 0;
+  for (; t < nk - 2; ++t) {
+    sp(I0{}, Yes{}, W4{}, t);
+    sp(I1{}, Yes{}, W2{}, t);
+  }
+  // tile nk-2: its SP1 has nothing left to prefetch (would be tile nk)
+  sp(I0{}, Yes{}, W4{}, t);
+  sp(I1{}, No{}, W2{}, t);
+  ++t;
+  // tile nk-1: nothing to prefetch; A1 of this tile is the only load that can still be in flight
+  sp(I0{}, No{}, W0c{}, t);
+  sp(I1{}, No{}, WN{}, t);
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
+  __syncthreads();   // every wave is done reading the stages: LDS becomes the epilogue staging area
+  gemm_epilogue_staged<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, gemm_smem + wave * (32 * (2 * 32 * 4 + 16)));
 }

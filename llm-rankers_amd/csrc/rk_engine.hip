@@ -172,18 +172,32 @@ void launch_v2(hipStream_t st, const GemmArgs& a) {
   hipLaunchKernelGGL((gemm_v2_kernel<EPI, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), smem, st, a);
 }
 
+template <int EPI, int KO = 0>
+void launch_pp2(hipStream_t st, const GemmArgs& a) {
+  constexpr int smem = 2 * 4 * 128 * 64 * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t rc = hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (rc != hipSuccess) fprintf(stderr, "[rk_engine] hipFuncSetAttribute(%d B LDS) failed: %s\n", smem, hipGetErrorString(rc));
+    attr_done = true;
+  }
+  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  hipLaunchKernelGGL((gemm_pp2_kernel<EPI, KO>), dim3(tiles), dim3(512), smem, st, a);
+}
+
 // Tile-shape choice.  variant: 0 = auto, 1 = 128x128 (v1, two workgroups per CU), 2 = 256x256, 3 = 256x192,
-// 4 = 256x128 (v2 kernels, one workgroup per CU).  auto = cheapest under a measured model: time ~ rounds over the
-// resident slots x the variant's time for one round of K = 1024 (us, MI355X, tools/gemm_bench.py at M = 736 .. 5888,
-// profiles/r01c_gemm_bench.txt).  GEGLU pairs gate/up inside 64-row wave tiles, so it cannot use the 192-wide tile.
+// 4 = 256x128 (v2 kernels, one workgroup per CU), 5 = 256x256 ping-pong (v3).  auto = cheapest under a measured model:
+// time ~ rounds over the resident slots x the variant's time for one round of K = 1024 (us, MI355X, tools/gemm_bench.py
+// at M = 736 .. 23552, profiles/r01c_gemm_bench.txt, r01e_gemm_pingpong.txt).  All variants sum K in the same order, so
+// the choice never changes a result bit.  GEGLU pairs gate/up inside 64-row wave tiles: no 192-wide tile for it.
 int choose_variant(const rk_engine* e, int epi, int M, int N, int K) {
-  (void)K;
   if (e->opt_gemm_variant) return (e->opt_gemm_variant == 3 && epi == EPI_GEGLU_F16) ? 2 : e->opt_gemm_variant;
   struct V { int id, bm, bn, slots; double round_us; };
-  static const V vs[4] = {{2, 256, 256, 256, 29.8}, {3, 256, 192, 256, 24.7}, {4, 256, 128, 256, 19.0}, {1, 128, 128, 512, 17.3}};
+  static const V vs[5] = {{5, 256, 256, 256, 27.0}, {2, 256, 256, 256, 29.8}, {3, 256, 192, 256, 24.7}, {4, 256, 128, 256, 19.0}, {1, 128, 128, 512, 17.3}};
   double best = 1e30; int bv = 1;
   for (const V& v : vs) {
     if (v.id == 3 && epi == EPI_GEGLU_F16) continue;
+    if (v.id == 5 && K < 128) continue;
     const long tiles = (long)((M + v.bm - 1) / v.bm) * ((N + v.bn - 1) / v.bn);
     const double cost = (double)((tiles + v.slots - 1) / v.slots) * v.round_us;
     if (cost < best - 1e-9) { best = cost; bv = v.id; }
@@ -193,7 +207,22 @@ int choose_variant(const rk_engine* e, int epi, int M, int N, int K) {
 
 template <int EPI>
 void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
-  const int variant = choose_variant(e, EPI, a.M, a.N, a.K);
+  int variant = choose_variant(e, EPI, a.M, a.N, a.K);
+  if constexpr (EPI == EPI_STORE_F16) {                              // timing-only knock-outs (gemm_variant 80 + mask)
+    if (variant > 80 && variant < 88 && a.K >= 128) {
+      switch (variant - 80) {
+        case 1: launch_pp2<EPI, 1>(st, a); return;
+        case 2: launch_pp2<EPI, 2>(st, a); return;
+        case 3: launch_pp2<EPI, 3>(st, a); return;
+        case 4: launch_pp2<EPI, 4>(st, a); return;
+        case 5: launch_pp2<EPI, 5>(st, a); return;
+        default: launch_pp2<EPI, 6>(st, a); return;
+      }
+    }
+  }
+  if (variant > 5) variant = 5;
+  if (variant == 5 && a.K < 128) variant = 2;                       // the ping-pong kernel needs two K tiles
+  if (variant == 5) { launch_pp2<EPI>(st, a); return; }
   if (variant == 2) { launch_v2<EPI, 2, 4, 4, 2>(st, a); return; }
   if (variant == 3 && EPI != EPI_GEGLU_F16) { launch_v2<EPI, 4, 2, 2, 3>(st, a); return; }
   if (variant == 4) { launch_v2<EPI, 4, 2, 2, 2>(st, a); return; }
@@ -303,8 +332,8 @@ int upload_small(rk_engine* e, Slot& sl, hipStream_t st, std::vector<int>* cache
 // ---- forward passes -----------------------------------------------------------------------------------------
 // hf: modeling_t5.py:663-750 (T5Stack.forward, encoder) over the slot's staged ragged batch, then the stacked
 // cross-attention K/V projections of all decoder layers (:325-326 with key_value_states = encoder output).
-#define XA_MAX_ROWS 128     // decoder rows (sequences x positions) the direct cross-attention path handles
-#define XA_MAX_CHUNKS 1024  // rows x 64-key chunks of partial-sum workspace
+#define XA_MAX_ROWS 256     // decoder rows (sequences x positions) the direct cross-attention path handles
+#define XA_MAX_CHUNKS 2048  // rows x 64-key chunks of partial-sum workspace
 
 // query-side cross-attention (attention.h) applies when the decoder has at most XA_MAX_ROWS rows in every step
 bool use_xattn_direct(const rk_engine* e, const Slot& sl, int max_ld) {
@@ -1028,7 +1057,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x1F : value; return RK_OK; }   // bit per epilogue kind
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
   if (!strcmp(key, "attn_short")) { e->opt_attn_short = value != 0; return RK_OK; }   // whole-KV-in-LDS kernel for L <= 192
-  if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..4 see choose_variant
+  if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
     if (set_device(e) || sync_all(e)) return RK_ERR_HIP;
     for (Slot& sl : e->slots) sl.dec_pending = false;

@@ -73,7 +73,7 @@ def iter_checkpoint_tensors(model_dir: str) -> Iterator[Tuple[str, np.ndarray]]:
 class T5Runtime:
     """Engine + chunking so a call may exceed the engine's token capacity (results are batch-independent)."""
 
-    def __init__(self, model_name_or_path: str, device, max_tokens: int = 32768, max_seqs: int = 128,
+    def __init__(self, model_name_or_path: str, device, max_tokens: int = 49152, max_seqs: int = 256,
                  max_dec_len: int = 136):
         cfg = read_config(model_name_or_path)
         self.model_type = cfg.get("model_type")

@@ -39,10 +39,11 @@ def toy(ckpt_dirs):
         e.close()
 
 
-# variant: 1 = 128x128 tile kernel (glds / register staging), 2..4 = 256x{256,192,128} 4-stage ring kernels
-@pytest.mark.parametrize("variant,glds", [(1, True), (1, False), (2, True), (3, True), (4, True)])
+# variant: 1 = 128x128 tile kernel (glds / register staging), 2..4 = 256x{256,192,128} kernels, 5 = 256x256 ping-pong
+# (falls back to variant 2 for a single K tile)
+@pytest.mark.parametrize("variant,glds", [(1, True), (1, False), (2, True), (3, True), (4, True), (5, True)])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (200, 192, 128), (70, 576, 192), (1, 4, 64), (333, 260, 1024),
-                                    (5888, 1024, 2816)])
+                                    (5888, 1024, 2816), (777, 516, 384), (256, 256, 128)])
 def test_gemm_vs_numpy(toy, shape, variant, glds):
     """C = A W^T with fp16 inputs, fp32 accumulate: exact products, only summation order differs."""
     m, n, k = shape
@@ -59,6 +60,12 @@ def test_gemm_vs_numpy(toy, shape, variant, glds):
         eng.set_option("gemm_variant", 0)
     want = a.astype(np.float32) @ w.astype(np.float32).T
     err = np.abs(got - want)
+    if variant == 5:                                     # every tile shape / schedule sums K in the same order
+        eng.set_option("gemm_variant", 2)
+        try:
+            np.testing.assert_array_equal(got, eng.debug_gemm(a, w, use_glds=True))
+        finally:
+            eng.set_option("gemm_variant", 0)
     assert err.max() < 2e-3 * np.sqrt(k), f"max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}; " \
         f"bad rows {np.unique(np.where(err > 1e-2 * np.sqrt(k))[0])[:16]} bad cols {np.unique(np.where(err > 1e-2 * np.sqrt(k))[1])[:16]}"
 
@@ -198,7 +205,10 @@ def test_flan_t5_large_dims_vs_oracle_and_properties():
     v1_regs = eng.score(batch, [0], ids)
     eng.set_option("gemm_glds", 1)
     v1_glds = eng.score(batch, [0], ids)
+    eng.set_option("gemm_variant", 5)
+    v5 = eng.score(batch, [0], ids)
     eng.set_option("gemm_variant", 0)
+    np.testing.assert_array_equal(v5, full)              # ping-pong schedule: same arithmetic again
     np.testing.assert_array_equal(v1_regs, v1_glds)      # DMA and register staging run the same arithmetic
     np.testing.assert_array_equal(v1_glds, full)         # ... and so do all tile shapes (same K order per output)
     eng.set_option("attn_short", 0)                      # tiled attention kernel instead of the whole-KV-in-LDS one

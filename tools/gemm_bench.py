@@ -12,7 +12,7 @@ from llmrankers._engine import RkEngine            # noqa: E402
 SHAPES = [  # name, M, N, K, epi
     ("qkv", 5888, 3072, 1024, 0), ("o", 5888, 1024, 1024, 1), ("ffn_in_geglu", 5888, 5632, 1024, 2),
     ("ffn_out", 5888, 1024, 2816, 1), ("cross_kv", 5888, 49152, 1024, 0), ("square4k", 4096, 4096, 4096, 0),
-    ("square8k", 8192, 8192, 8192, 0),
+    ("square8k", 8192, 8192, 8192, 0), ("sq4k_k4224", 4096, 4096, 4224, 0), ("sq4k_k3968", 4096, 4096, 3968, 0),
 ]
 
 
@@ -23,17 +23,20 @@ def main():
         for i, (name, m, n, k, epi) in enumerate(SHAPES[:5]):
             SHAPES[i] = (name, m_override, n, k, epi)
         del SHAPES[5:]
+    extra = os.environ.get('RK_BENCH_SHAPES')
+    if extra:
+        SHAPES.extend((f'x{i}', *[int(v) for v in t.split('x')]) for i, t in enumerate(extra.split(',')))
     only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
     dims = _synth.TOY_GATED_UNTIED
     eng = RkEngine(dims, 0, max_tokens=256, max_seqs=4, max_dec_len=4).load_state(_synth.synth_state_dict(dims, 1).items())
     out = {}
-    variants = [int(v) for v in os.environ.get("RK_GEMM_VARIANTS", "0,1,2,3,4").split(",")]
+    variants = [int(v) for v in os.environ.get("RK_GEMM_VARIANTS", "0,1,2,3,4,5").split(",")]
     for name, m, n, k, epi in SHAPES:
         if only and name not in only:
             continue
         row = {}
         for v in variants:
-            if (v == 3 and epi == 2) or (v == 5 and epi in (1, 4)):
+            if v == 3 and epi == 2:
                 continue
             eng.set_option("gemm_variant", v)
             ms = eng.gemm_bench(m, n, k, epi, iters if n < 40000 and m * n * k < 2e11 else max(3, iters // 5))
