@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--seq_len", type=int, default=184)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (rk_engine_set_option), repeatable")
     ap.add_argument("--glds", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="1: decoder chain of step i overlaps encoder of step i+1 (two HIP streams)")
     ap.add_argument("--group", type=int, default=8,
@@ -87,6 +88,9 @@ def main():
     eng.load_state(state.items())
     eng.set_option("gemm_glds", args.glds)
     eng.set_option("overlap", args.overlap)
+    for kv in args.opt:                                    # engine A/B switches for experiments, e.g. --opt gemm_variant=2
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     if rank == 0:
         print(f"[bench] weights generated + engine finalized in {time.time() - t0:.1f}s", file=sys.stderr)
     n_slots = eng.num_slots

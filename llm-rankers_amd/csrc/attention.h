@@ -14,6 +14,8 @@ struct AttnEncArgs {
   const int* seq_off;    // [B+1] token offsets of the packed batch
   const float* bias_lut; // [H][RK_LUT_N]
   int ld, ldctx, I;
+  int heads_per_wg;      // short kernel only: heads blockIdx.x * heads_per_wg .. are handled by one workgroup in turn
+  int ko;                // timing-only knock-outs (short kernel): 1 = skip the compute loop, 2 = skip the K/V/Q global loads
 };
 
 // Flash-style encoder self-attention.  grid = (ceil(maxL/128), H, B), 256 threads = 4 waves x 32 queries.
@@ -219,16 +221,21 @@ __global__ __launch_bounds__(256) void attn_enc_kernel(AttnEncArgs p) {
 // so that stores are whole 128-byte context rows.  grid = (H, B), 384 threads, 3 workgroups per CU.
 #define ATTS_MAXL 192
 #define ATTS_VSTR 196   // sVt row stride in halfs (392 B: 8-B aligned; 98 dwords -> conflict-free b64 reads)
-__global__ __launch_bounds__(384) void attn_enc_short_kernel(AttnEncArgs p) {
+template <int NW>   // waves per workgroup: 6 (one workgroup covers 192 queries) or 4 (128 queries, blockIdx.z picks the half)
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_enc_short_kernel(AttnEncArgs p) {
   __shared__ __attribute__((aligned(16))) half_t sK[ATTS_MAXL * ATT_KSTR];
   __shared__ __attribute__((aligned(16))) half_t sVt[64 * ATTS_VSTR];
   __shared__ float sLutX[2 * ATTS_MAXL];   // table over every (key - query) in (-192, 192): no clamp in the loop
-  const int b = blockIdx.y, h = blockIdx.x;
+  const int b = blockIdx.y;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;
+  if ((int)blockIdx.z * NW * 32 >= L) return;   // uniform for the whole block
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int hh = lane >> 5, l31 = lane & 31;
-  for (int i = tid; i < 2 * ATTS_MAXL - 1; i += 384) {
+  const int h_end = min(p.I >> 6, ((int)blockIdx.x + 1) * p.heads_per_wg);
+  for (int h = blockIdx.x * p.heads_per_wg; h < h_end; ++h) {
+  if (h != (int)blockIdx.x * p.heads_per_wg) __syncthreads();   // the previous head's tables and staging rows are done with
+  for (int i = tid; i < 2 * ATTS_MAXL - 1; i += NW * 64) {
     int rel = i - (ATTS_MAXL - 1);
     rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
     sLutX[i] = p.bias_lut[h * RK_LUT_N + rel + RK_LUT_R] * ATT_LOG2E;
@@ -236,13 +243,13 @@ __global__ __launch_bounds__(384) void attn_enc_short_kernel(AttnEncArgs p) {
   const int nkt = (L + 63) >> 6;
   const int nrows = nkt * 64;
   // K rows: 16-B chunks, row-major (clamped rows are masked later)
-  for (int c = tid; c < nrows * 8; c += 384) {
+  for (int c = tid; c < ((p.ko & 2) ? 0 : nrows * 8); c += NW * 64) {
     const int row = c >> 3, cc = c & 7;
     const int key = row < L ? row : L - 1;
     *(half8*)(sK + row * ATT_KSTR + cc * 8) = *(const half8*)(p.qkv + (size_t)(tok0 + key) * p.ld + p.I + h * 64 + cc * 8);
   }
   // V^T: one thread takes 2 adjacent keys x 8 d and writes 8 key-pairs (32-bit) into the transposed image
-  for (int c = tid; c < (nrows >> 1) * 8; c += 384) {
+  for (int c = tid; c < ((p.ko & 2) ? 0 : (nrows >> 1) * 8); c += NW * 64) {
     const int kp = c >> 3, cc = c & 7;
     const int k0 = 2 * kp < L ? 2 * kp : L - 1, k1 = 2 * kp + 1 < L ? 2 * kp + 1 : L - 1;
     const half8 v0 = *(const half8*)(p.qkv + (size_t)(tok0 + k0) * p.ld + 2 * p.I + h * 64 + cc * 8);
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(384) void attn_enc_short_kernel(AttnEncArgs p) {
       *(half2v*)(sVt + (cc * 8 + j) * ATTS_VSTR + 2 * kp) = pr;
     }
   }
-  const int q0 = wave * 32;
+  const int q0 = (blockIdx.z * NW + wave) * 32;
   const bool wave_active = q0 < L;
   const int qpos = q0 + l31;
   const int qrow = qpos < L ? qpos : L - 1;
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(384) void attn_enc_short_kernel(AttnEncArgs p) {
   const float* lut_q = sLutX + (ATTS_MAXL - 1) - qpos + 4 * hh;   // lut_q[key - 4hh] = bias(key - qpos) * log2(e)
   __syncthreads();
   if (wave_active) {
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = 0; kt < ((p.ko & 1) ? 0 : nkt); ++kt) {
       const half_t* kb_ = sK + kt * 64 * ATT_KSTR;
       f32x16 s0, s1;
 #pragma unroll
@@ -340,6 +347,208 @@ __global__ __launch_bounds__(384) void attn_enc_short_kernel(AttnEncArgs p) {
       if (q0 + row < L)
         *(half8*)(p.ctx + (size_t)(tok0 + q0 + row) * p.ldctx + h * 64 + ch * 8) = *(const half8*)(st + row * ATT_KSTR + ch * 8);
     }
+  }
+  }   // heads
+}
+
+// Pair form of the short-sequence kernel: the production path for L <= 192.
+// Why: the 6-wave workgroup above puts 2+2+1+1 waves on the four SIMDs, runs at one workgroup per CU (163 VGPRs) and
+// exposes its whole load phase; PMC (profiles/r01e_attn_pmc.txt) shows the waves waiting 61 % of their life, the VALU
+// (softmax: ~1200 instructions per wave) busy 31 %, MFMA 9 %, and the time per (sequence, head) is the same 11 us whether
+// a workgroup handles 1 or 16 heads.  Here a 768-thread workgroup runs TWO heads of one sequence side by side (waves
+// 0-5 / 6-11: three waves on every SIMD), walks `heads_per_wg` head pairs in turn, and fetches the next pair's K, V, Q
+// rows and bias table entries into registers while the current pair is computed, so the only exposed memory latency is
+// the first pair's.  Per-(sequence, head) arithmetic is the short kernel's, bit for bit (shared attn_tile_softmax).
+// grid = (ceil(ceil(H/2) / heads_per_wg), B), dynamic LDS = 2 x 54272 B.
+#define ATTP_GROUP_LDS (ATTS_MAXL * ATT_KSTR * 2 + 64 * ATTS_VSTR * 2 + 2 * ATTS_MAXL * 4)
+template <int NG>   // heads side by side in one workgroup: 1 (384 threads) or 2 (768 threads)
+__global__ __launch_bounds__(NG * 384, NG == 1 ? 2 : 3) void attn_enc_pair_kernel(AttnEncArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char attp_smem[];
+  const int g = NG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= 384));   // head of the group this wave works on
+  const int tid = threadIdx.x - g * 384;
+  unsigned char* gbase = attp_smem + g * ATTP_GROUP_LDS;
+  half_t* sK = (half_t*)gbase;
+  half_t* sVt = (half_t*)(gbase + ATTS_MAXL * ATT_KSTR * 2);
+  float* sLutX = (float*)(gbase + ATTS_MAXL * ATT_KSTR * 2 + 64 * ATTS_VSTR * 2);
+  const int b = blockIdx.y;
+  const int tok0 = p.seq_off[b];
+  const int L = p.seq_off[b + 1] - tok0;
+  const int H = p.I >> 6;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int nkt = (L + 63) >> 6;
+  const int nrows = nkt * 64;
+  const int npairs = (H + NG - 1) / NG;
+  const int pr_end = min(npairs, ((int)blockIdx.x + 1) * p.heads_per_wg);
+
+  // loop-invariant element offsets of the rows this thread copies (the head's column offset is added per pair)
+  unsigned koff[4], voff[2][2];   // BYTE offsets from the head's column base (uniform pointer + 32-bit lane offset loads)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 384 * i, row = c >> 3, cc = c & 7;
+    const int key = row < L ? row : L - 1;
+    koff[i] = (unsigned)((tok0 + key) * p.ld + p.I + cc * 8) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 384 * i, kp = c >> 3, cc = c & 7;
+    const int k0 = 2 * kp < L ? 2 * kp : L - 1, k1 = 2 * kp + 1 < L ? 2 * kp + 1 : L - 1;
+    voff[i][0] = (unsigned)((tok0 + k0) * p.ld + 2 * p.I + cc * 8) * 2u;
+    voff[i][1] = (unsigned)((tok0 + k1) * p.ld + 2 * p.I + cc * 8) * 2u;
+  }
+  const int q0 = wave * 32;
+  const bool wave_active = q0 < L;
+  const int qpos = q0 + l31;
+  const unsigned qoff = (unsigned)((tok0 + (qpos < L ? qpos : L - 1)) * p.ld + 8 * hh) * 2u;
+  int lut_idx = tid - (ATTS_MAXL - 1);
+  lut_idx = (lut_idx < -RK_LUT_R ? -RK_LUT_R : (lut_idx > RK_LUT_R ? RK_LUT_R : lut_idx)) + RK_LUT_R;
+  const float* lut_q = sLutX + (ATTS_MAXL - 1) - qpos + 4 * hh;   // lut_q[key - 4hh] = bias(key - qpos) * log2(e)
+
+  half8 kreg[4], vreg[2][2], qnext[4];
+  float lutreg = 0.f;
+  // The prefetch loads are issued through inline asm so that the compiler's waitcnt pass does not see them: tracked
+  // loads made it wait for most of the NEXT heads' rows at the first MFMA of the current ones (in-order vmcnt), which
+  // serialised the two again.  Rules that keep this safe: every load is unconditional (clamped rows - a conditional asm
+  // output becomes a phi, and the copy the compiler may insert for it would read the register before the data lands),
+  // issue and wait sit in the SAME loop iteration (no loop-carried copies), and the wait's "+v" operands order every
+  // use of the destinations after it.
+  auto prefetch = [&](int h) {
+    const char* hb = (const char*)(p.qkv + h * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(kreg[i]) : "v"(koff[i]), "s"(hb));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(vreg[i][0]) : "v"(voff[i][0]), "s"(hb));
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(vreg[i][1]) : "v"(voff[i][1]), "s"(hb));
+    }
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(qnext[0]) : "v"(qoff), "s"(hb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=&v"(qnext[1]) : "v"(qoff), "s"(hb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=&v"(qnext[2]) : "v"(qoff), "s"(hb));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:96" : "=&v"(qnext[3]) : "v"(qoff), "s"(hb));
+    const float* lb = p.bias_lut + h * RK_LUT_N;
+    asm volatile("global_load_dword %0, %1, %2" : "=&v"(lutreg) : "v"(lut_idx * 4), "s"(lb));
+  };
+  auto prefetch_wait = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(kreg[0]), "+v"(kreg[1]), "+v"(kreg[2]), "+v"(kreg[3]), "+v"(vreg[0][0]), "+v"(vreg[0][1]), "+v"(vreg[1][0]),
+                   "+v"(vreg[1][1]), "+v"(qnext[0]), "+v"(qnext[1]), "+v"(qnext[2]), "+v"(qnext[3]), "+v"(lutreg)
+                 :: "memory");
+  };
+
+  const int pr_first = blockIdx.x * p.heads_per_wg;
+  half8 qf[4];
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_) qf[s_] = half8{};
+  // iteration pr: fetch the rows of step pr | compute + store step pr-1 | rows of step pr -> LDS.  One extra iteration
+  // drains the pipeline (its fetch re-reads the last head: harmless).
+  for (int pr = pr_first; pr <= pr_end; ++pr) {
+    {
+      const int hn = NG * (pr < pr_end ? pr : pr_end - 1) + g;
+      prefetch(hn < H ? hn : H - 1);
+    }
+    const int h = NG * (pr - 1) + g;                    // the head computed in this iteration
+    const bool head_active = pr > pr_first && h < H;
+    if (pr > pr_first) {
+      f32x16 o0, o1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+      float m_run = -1e30f, l_run = 0.f;
+      if (head_active && wave_active) {
+        for (int kt = 0; kt < ((p.ko & 1) ? 0 : nkt); ++kt) {
+          const half_t* kb_ = sK + kt * 64 * ATT_KSTR;
+          f32x16 s0, s1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const half8 k0 = *(const half8*)(kb_ + l31 * ATT_KSTR + 16 * s + 8 * hh);
+            const half8 k1 = *(const half8*)(kb_ + (32 + l31) * ATT_KSTR + 16 * s + 8 * hh);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+          }
+          {
+            const int key_base = kt * 64 + 4 * hh;
+            const float* lq = lut_q + kt * 64;
+            auto bias = [&](int r, int sub) { return lq[(r & 3) + 8 * (r >> 2) + 32 * sub]; };
+            const bool last = kt == nkt - 1;
+            if (kt == 0) {
+              if (last) attn_tile_softmax<true, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+              else attn_tile_softmax<false, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+            } else {
+              if (last) attn_tile_softmax<true, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+              else attn_tile_softmax<false, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+            }
+          }
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+              half8 pf;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) pf[i] = (half_t)(sub == 0 ? s0[8 * sp + i] : s1[8 * sp + i]);
+              const int kb = kt * 64 + sub * 32 + 16 * sp + 4 * hh;
+              {
+                const half_t* vr = sVt + l31 * ATTS_VSTR + kb;
+                const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
+                const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o0, 0, 0, 0);
+              }
+              {
+                const half_t* vr = sVt + (32 + l31) * ATTS_VSTR + kb;
+                const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
+                const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o1, 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();   // (2) everyone is done with sK: reuse it to turn the per-lane 8-byte pieces into whole context rows
+      if (head_active && wave_active) {
+        const float inv = 1.0f / l_run;
+        half_t* st = sK + wave * (32 * ATT_KSTR);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int d = 8 * q + 4 * hh;
+          half4 a, c;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[j] = f2h_sat(o0[4 * q + j] * inv); c[j] = f2h_sat(o1[4 * q + j] * inv); }
+          *(half4*)(st + l31 * ATT_KSTR + d) = a;
+          *(half4*)(st + l31 * ATT_KSTR + 32 + d) = c;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += 8) {
+          const int row = r0 + (lane >> 3), ch = lane & 7;
+          if (q0 + row < L)
+            *(half8*)(p.ctx + (size_t)(tok0 + q0 + row) * p.ldctx + h * 64 + ch * 8) = *(const half8*)(st + row * ATT_KSTR + ch * 8);
+        }
+      }
+    }
+    prefetch_wait();
+    __syncthreads();   // (3) the staging rows and tables of step pr-1 are read: LDS may be overwritten
+    if (pr < pr_end) {
+      // registers -> LDS: K rows, V^T as key pairs, the head's bias table (rows beyond the sequence are clamped copies)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = tid + 384 * i;
+        *(half8*)(sK + (c >> 3) * ATT_KSTR + (c & 7) * 8) = kreg[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = tid + 384 * i, kp = c >> 3, cc = c & 7;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const half2v pv = {vreg[i][0][j], vreg[i][1][j]};
+          *(half2v*)(sVt + (cc * 8 + j) * ATTS_VSTR + 2 * kp) = pv;
+        }
+      }
+      sLutX[tid] = lutreg * ATT_LOG2E;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) qf[s_] = qnext[s_];
+    }
+    __syncthreads();   // (1) the rows of step pr are in LDS
   }
 }
 

@@ -90,7 +90,8 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x1F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1;
+  int opt_glds = 1, opt_skinny = 0x1F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0;
+  int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
@@ -351,11 +352,28 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
     rmsnorm(e, st, sl.hidden, w.ln0, sl.xn, nullptr, T);
     gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xn, dm, w.qkv, dm, sl.qkv, 3 * I, T, 3 * I, dm);
     {
-      AttnEncArgs a{sl.qkv, sl.ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I};
+      // L <= 192: pair kernel - a workgroup runs two heads of a sequence side by side and walks `ppw` head pairs, sized so
+      // that the launch has at least one workgroup per CU; the per-(sequence, head) arithmetic does not depend on it.
+      // opt_attn_short: 1 = 4-wave short kernel, 2 = 6-wave short kernel, 3 = pair kernel, 0 = tiled kernel (bit-identical)
+      // opt_attn_short: 1 = pipelined kernel, one head at a time per workgroup; 3 = two heads side by side; 2 / 4 = plain
+      // short kernels with 6 / 4 waves; 0 = tiled kernel.  All bit-identical.
+      const int NG = 1;   // (a two-heads-side-by-side form, 12 waves, measured slower: 168-VGPR cap -> spills; not instantiated)
+      const int npairs = (d.n_heads + NG - 1) / NG;
+      int ppw = 1;
+      while (ppw * 2 <= npairs && npairs % (ppw * 2) == 0 && (long)sl.n_seq * (npairs / (ppw * 2)) >= e->n_cu) ppw *= 2;
+      if (e->opt_attn_heads_per_wg > 0) ppw = e->opt_attn_heads_per_wg;
+      AttnEncArgs a{sl.qkv, sl.ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I, ppw, e->opt_attn_ko};
       const double att_flops = 4.0 * (double)sl.maxL * T * I;   // exact for uniform lengths, upper bound if ragged
       Bracket br(e, st, PC_ENC_ATTN, att_flops, (double)T * 4 * I * 2.0);
-      if (sl.maxL <= ATTS_MAXL && e->opt_attn_short)
-        hipLaunchKernelGGL(attn_enc_short_kernel, dim3(d.n_heads, sl.n_seq), dim3(384), 0, st, a);
+      if (sl.maxL <= ATTS_MAXL && e->opt_attn_short == 1) {
+        hipLaunchKernelGGL(attn_enc_pair_kernel<1>, dim3((npairs + ppw - 1) / ppw, sl.n_seq), dim3(384), ATTP_GROUP_LDS, st, a);
+      } else if (sl.maxL <= ATTS_MAXL && e->opt_attn_short == 2) {
+        a.heads_per_wg = 1;
+        hipLaunchKernelGGL(attn_enc_short_kernel<6>, dim3(d.n_heads, sl.n_seq), dim3(384), 0, st, a);
+      } else if (sl.maxL <= ATTS_MAXL && e->opt_attn_short) {
+        a.heads_per_wg = 1;
+        hipLaunchKernelGGL(attn_enc_short_kernel<4>, dim3(d.n_heads, sl.n_seq, (sl.maxL + 127) / 128), dim3(256), 0, st, a);
+      }
       else
         hipLaunchKernelGGL(attn_enc_kernel, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
     }
@@ -604,7 +622,7 @@ int rk_engine_create(const rk_model_desc* desc, int device_ordinal, rk_engine** 
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(nullptr, RK_ERR_NO_DEVICE, "device %d is %s; kernels are built for gfx950 (MI355X) only", device_ordinal, prop.gcnArchName);
   rk_engine* e = new rk_engine();
-  e->d = d; e->dev = device_ordinal; e->inner = d.n_heads * d.d_kv;
+  e->d = d; e->dev = device_ordinal; e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; e->inner = d.n_heads * d.d_kv;
   int prio_lo = 0, prio_hi = 0;
   bool ok = hipSetDevice(device_ordinal) == hipSuccess;
   ok = ok && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) == hipSuccess;
@@ -1055,8 +1073,10 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!e || !key) return RK_ERR_INVALID;
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x1F : value; return RK_OK; }   // bit per epilogue kind
+  if (!strcmp(key, "attn_ko")) { e->opt_attn_ko = value; return RK_OK; }   // timing-only knock-outs, see AttnEncArgs
+  if (!strcmp(key, "attn_heads_per_wg")) { e->opt_attn_heads_per_wg = value; return RK_OK; }   // 0 auto
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
-  if (!strcmp(key, "attn_short")) { e->opt_attn_short = value != 0; return RK_OK; }   // whole-KV-in-LDS kernel for L <= 192
+  if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 1 pair kernel, 2 one-head kernel, 0 tiled
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
     if (set_device(e) || sync_all(e)) return RK_ERR_HIP;
@@ -1125,6 +1145,17 @@ int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_fl
   if (!e || !name || !out) return RK_ERR_INVALID;
   if (set_device(e)) return RK_ERR_HIP;
   if (sync_all(e)) return RK_ERR_HIP;
+  if (!strcmp(name, "occupancy")) {   // resident workgroups per CU the runtime computes for the main kernels
+    if (max_floats < 6) return RK_ERR_INVALID;
+    int n = 0;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_short_kernel<4>, 256, 0); out[0] = (float)n;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_pair_kernel<1>, 384, ATTP_GROUP_LDS); out[1] = (float)n;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f16_kernel<EPI_STORE_F16, true>, 256, GEMM_LDS_BYTES); out[2] = (float)n;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_pp2_kernel<EPI_STORE_F16, 0>, 512, 131072); out[3] = (float)n;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_kernel, 256, 0); out[4] = (float)n;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rmsnorm_kernel<4>, 256, 0); out[5] = (float)n;
+    return 6;
+  }
   const Slot& sl = e->slots[0];
   const std::string n(name);
   const int I = e->inner, dm = e->d.d_model;
