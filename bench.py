@@ -201,7 +201,7 @@ def main():
             pass
         roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "tiled fp16 MFMA GEMM family gemm_v2_kernel / gemm_f16_kernel (all encoder launches: qkv, o, ffn_in+GEGLU, ffn_out)",
+                    "kernel": "tiled fp16 MFMA GEMM family: gemm_pp2_kernel (256x256 ping-pong) with gemm_v2_kernel / gemm_f16_kernel as fill-in tile shapes (all encoder launches: qkv, o, ffn_in+GEGLU, ffn_out)",
                     "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches": int(g_n),
                     "gemm_share_of_gpu_time": round(g_ms / total_ms, 3) if total_ms else None,
                     "per_class": {k: {"ms_per_step": round(v["ms"] / (n_prof * G), 4),

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 8 --no_cpu_baseline --no_profile"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 64 --warmup 16 --no_cpu_baseline --no_profile --overlap 0"   # one stream: kernels run one at a time, so durations and counters belong to one kernel
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- $CMD > $OUT/bench_stdout.txt 2> $OUT/bench_stderr.txt
 echo "rocprofv3 stats rc=$?"
