@@ -353,7 +353,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_enc_short_kerne
 
 // Pair form of the short-sequence kernel: the production path for L <= 192.
 // Why: the 6-wave workgroup above puts 2+2+1+1 waves on the four SIMDs, runs at one workgroup per CU (163 VGPRs) and
-// exposes its whole load phase; PMC (profiles/r01e_attn_pmc.txt) shows the waves waiting 61 % of their life, the VALU
+// exposes its whole load phase; PMC (profiles/r01e_attn_pmc.json) shows the waves waiting 61 % of their life, the VALU
 // (softmax: ~1200 instructions per wave) busy 31 %, MFMA 9 %, and the time per (sequence, head) is the same 11 us whether
 // a workgroup handles 1 or 16 heads.  Here a 768-thread workgroup runs TWO heads of one sequence side by side (waves
 // 0-5 / 6-11: three waves on every SIMD), walks `heads_per_wg` head pairs in turn, and fetches the next pair's K, V, Q
