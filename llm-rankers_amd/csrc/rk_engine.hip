@@ -248,6 +248,9 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
   // Kernel family is chosen by the CALLER's regime, never by M: a row's result must not depend on how many other rows
   // share the launch (the split-K weight-streaming kernel and the tiled kernels sum K in different orders).
   if ((weight_streaming || batch > 1) && n_split == 0 && (((e->opt_skinny >> epi) & 1) || batch > 1)) {
+    // (a form where one workgroup takes up to 8 row slabs - 8x fewer, fatter workgroups - was bit-identical but made
+    // the step 6 % slower: what the decoder costs the concurrent encoder GEMMs is the serial LENGTH of its chain, every
+    // kernel delaying some tile of the GEMM in flight, not its CU-time; so: many short workgroups)
     const dim3 b(SKINNY_THREADS);
     const unsigned gy = (unsigned)batch, gz = (unsigned)((M + 31) / 32);
     switch (epi) {
@@ -333,8 +336,8 @@ int upload_small(rk_engine* e, Slot& sl, hipStream_t st, std::vector<int>* cache
 // ---- forward passes -----------------------------------------------------------------------------------------
 // hf: modeling_t5.py:663-750 (T5Stack.forward, encoder) over the slot's staged ragged batch, then the stacked
 // cross-attention K/V projections of all decoder layers (:325-326 with key_value_states = encoder output).
-#define XA_MAX_ROWS 256     // decoder rows (sequences x positions) the direct cross-attention path handles
-#define XA_MAX_CHUNKS 2048  // rows x 64-key chunks of partial-sum workspace
+#define XA_MAX_ROWS 512     // decoder rows (sequences x positions) the direct cross-attention path handles
+#define XA_MAX_CHUNKS 4096  // rows x 64-key chunks of partial-sum workspace
 
 // query-side cross-attention (attention.h) applies when the decoder has at most XA_MAX_ROWS rows in every step
 bool use_xattn_direct(const rk_engine* e, const Slot& sl, int max_ld) {

@@ -70,7 +70,7 @@ def test_gemm_vs_numpy(toy, shape, variant, glds):
         f"bad rows {np.unique(np.where(err > 1e-2 * np.sqrt(k))[0])[:16]} bad cols {np.unique(np.where(err > 1e-2 * np.sqrt(k))[1])[:16]}"
 
 
-@pytest.mark.parametrize("shape", [(1, 64, 64), (32, 128, 1024), (33, 96, 192), (100, 1024, 2816)])
+@pytest.mark.parametrize("shape", [(1, 64, 64), (32, 128, 1024), (33, 96, 192), (100, 1024, 2816), (256, 1024, 1024), (200, 96, 2816)])
 def test_weight_streaming_gemm_vs_numpy(toy, shape):
     """The decoder's split-K kernel: fixed reduction tree -> every row is independent of how many rows share the launch."""
     m, n, k = shape
@@ -82,6 +82,9 @@ def test_weight_streaming_gemm_vs_numpy(toy, shape):
     want = a.astype(np.float32) @ w.astype(np.float32).T
     assert np.abs(got - want).max() < 2e-3 * np.sqrt(k)
     np.testing.assert_array_equal(eng.debug_gemm(a[m - 1:], w, use_glds=2)[0], got[m - 1])
+    for lo, hi in ((0, 32), (m // 3, m // 3 + 40), (m // 2, m)):          # any sub-batch (other slab grouping): same bits
+        if hi <= m and hi - lo >= 1:
+            np.testing.assert_array_equal(eng.debug_gemm(a[lo:hi], w, use_glds=2), got[lo:hi])
 
 
 def test_encoder_stages_one_layer():
