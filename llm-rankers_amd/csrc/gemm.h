@@ -185,7 +185,9 @@ __device__ __forceinline__ void gemm_prefetch_residual(const GemmArgs& p, f32x16
   }
 }
 
-template <int EPI, int NI, int MI, bool RESID_IN_ACC = false>
+// ROWS = 32: one pass per 32-row slab; ROWS = 16: two passes of 16 rows (half the staging bytes per wave - the
+// persistent ping-pong kernel stages beside the next tile's DMA targets and has only 48 KiB for it).
+template <int EPI, int NI, int MI, bool RESID_IN_ACC = false, int ROWS = 32>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase,
                                                      int lane, unsigned char* stage) {
   const int l31 = lane & 31, hh = lane >> 5;
@@ -199,9 +201,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
   const int ncol0 = GEGLU ? (nbase >> 1) : nbase;
   const int nlimit = GEGLU ? (p.N >> 1) : p.N;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    // ---- registers -> LDS (row l31 of the slab) ----
-    unsigned char* myrow = stage + l31 * ROWB;
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+  for (int hp = 0; hp < 32 / ROWS; ++hp) {
+    // ---- registers -> LDS (row l31 of the slab; with ROWS = 16 the lanes of the other half sit this pass out) ----
+    unsigned char* myrow = stage + (l31 % ROWS) * ROWB;
+    if (ROWS == 32 || (l31 / ROWS) == hp) {
     if (GEGLU) {
 #pragma unroll
       for (int g = 0; g < NI / 2; ++g)
@@ -234,15 +239,16 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
           }
         }
     }
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are done (region is wave-private)
     __builtin_amdgcn_wave_barrier();
     // ---- LDS -> global, 16 B per lane along the rows ----
 #pragma unroll
-    for (int r0 = 0; r0 < 32; r0 += ROWS_PER_PASS) {
+    for (int r0 = 0; r0 < ROWS; r0 += ROWS_PER_PASS) {
       const int row = r0 + lane / CHUNKS, ch = lane % CHUNKS;
-      const int m = mbase + mi * 32 + row;
+      const int m = mbase + mi * 32 + hp * ROWS + row;
       int n = ncol0 + ch * (16 / ELT);
-      if (lane / CHUNKS < ROWS_PER_PASS && row < 32 && m < p.M && n < nlimit) {
+      if (lane / CHUNKS < ROWS_PER_PASS && row < ROWS && m < p.M && n < nlimit) {
         const unsigned char* sp = stage + row * ROWB + ch * 16;
         size_t base = 0;
         if (p.n_split > 0) { base = (size_t)(n / p.n_split) * (size_t)p.split_stride; n = n % p.n_split; }
@@ -573,7 +579,9 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // t+1 landed).  Buffer n mod 8 is re-filled in super-phase floor(n/2)+1 or later, one full barrier after its last
 // reader (group 1) has its fragments in registers.  Every accumulator sees the K tiles, and the four k16 steps inside
 // one, in increasing order with the same operand slots as the v1/v2 kernels: results are bit-identical to theirs.
-// Needs K >= 128 (two K tiles).  KO: timing-only knock-outs for bottleneck hunting (results are garbage): 1 = no DMA in
+// Needs K >= 128 (two K tiles).  The kernel is PERSISTENT (see set_tile below): launched with one workgroup per CU it
+// walks its tiles and overlaps each tile's epilogue with the next tile's first loads (qkv at M = 23552: 170 -> 149 us,
+// FFN-in 326 -> 308 us).  KO: timing-only knock-outs for bottleneck hunting (results are garbage): 1 = no DMA in
 // the loop, 2 = no fragment reads, 4 = no MFMA.  Product code instantiates KO = 0 only.
 template <int EPI, int KO = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
@@ -585,25 +593,31 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   const int l31 = lane & 31, hh = lane >> 5;
   const int grp = wave >> 2, wm = wave & 1, wn = (wave >> 1) & 3;
   const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
-  int tm, tn;
-  gemm_tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
-
+  const int ntiles = tiles_m * tiles_n;
+  int m0 = 0, n0 = 0;
   unsigned off[4][2];   // kind 0 = A0, 1 = A1, 2 = W0, 3 = W1; byte offsets of this wave's two DMA instructions
+  // PERSISTENT: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8 or the whole grid, so
+  // the tile -> XCD association of gemm_tile_coords holds) and issues the NEXT tile's first six half-tiles before it
+  // runs the epilogue of the current one: pipeline fill and workgroup launch no longer sit between two tiles.
+  auto set_tile = [&](int tile) {
+    int tm, tn;
+    gemm_tile_coords(tile, tiles_m, tiles_n, tm, tn);
+    m0 = tm * 256; n0 = tn * 256;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = (wave * 2 + j) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+    for (int j = 0; j < 2; ++j) {
+      const int r = (wave * 2 + j) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((r >> 1) & 7);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int ga = m0 + 128 * (r >> 6) + 64 * h + (r & 63);
-      ga = ga < p.M ? ga : p.M - 1;
-      off[h][j] = ((unsigned)ga * (unsigned)p.lda + chunk * 8) * 2u;
-      int gw = n0 + 64 * (r >> 5) + 32 * h + (r & 31);
-      gw = gw < p.N ? gw : p.N - 1;
-      off[2 + h][j] = ((unsigned)gw * (unsigned)p.ldw + chunk * 8) * 2u;
+      for (int h = 0; h < 2; ++h) {
+        int ga = m0 + 128 * (r >> 6) + 64 * h + (r & 63);
+        ga = ga < p.M ? ga : p.M - 1;
+        off[h][j] = ((unsigned)ga * (unsigned)p.lda + chunk * 8) * 2u;
+        int gw = n0 + 64 * (r >> 5) + 32 * h + (r & 31);
+        gw = gw < p.N ? gw : p.N - 1;
+        off[2 + h][j] = ((unsigned)gw * (unsigned)p.ldw + chunk * 8) * 2u;
+      }
     }
-  }
+  };
   // buffer of (kind, stage) at (kind * 2 + stage) * 16 KiB
   auto issue1 = [&](auto kindc, int stage, int tile, auto jc) {
     constexpr int kind = decltype(kindc)::value, j = decltype(jc)::value;
@@ -634,12 +648,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     }
   }
   f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // one super-phase.  SP: 0 / 1;  ISSUE: the two half-tiles this phase's MFMA section prefetches exist;
   // WAIT: vmcnt count before the first barrier (-1 = none)
@@ -705,24 +713,38 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // ---- prologue: half-tiles 0..5 = tile 0 complete, A0 and W0 of tile 1 ----
-  issue1(I0{}, 0, 0, I0{}); issue1(I0{}, 0, 0, I1{});
-  issue1(I2{}, 0, 0, I0{}); issue1(I2{}, 0, 0, I1{});
-  issue1(I3{}, 0, 0, I0{}); issue1(I3{}, 0, 0, I1{});
-  issue1(I1{}, 0, 0, I0{}); issue1(I1{}, 0, 0, I1{});
-  issue1(I0{}, 1, 1, I0{}); issue1(I0{}, 1, 1, I1{});
-  issue1(I2{}, 1, 1, I0{}); issue1(I2{}, 1, 1, I1{});
-  gemm_wait_vmcnt<6>();                        // A0, W0, W1 of tile 0 landed (this wave's share)
+  // ---- prologue of a tile: half-tiles 0..5 = K tile 0 complete, A0 and W0 of K tile 1 ----
+  auto issue_prologue = [&]() {
+    issue1(I0{}, 0, 0, I0{}); issue1(I0{}, 0, 0, I1{});
+    issue1(I2{}, 0, 0, I0{}); issue1(I2{}, 0, 0, I1{});
+    issue1(I3{}, 0, 0, I0{}); issue1(I3{}, 0, 0, I1{});
+    issue1(I1{}, 0, 0, I0{}); issue1(I1{}, 0, 0, I1{});
+    issue1(I0{}, 1, 1, I0{}); issue1(I0{}, 1, 1, I1{});
+    issue1(I2{}, 1, 1, I0{}); issue1(I2{}, 1, 1, I1{});
+  };
+  using Yes = integral_constant<bool, true>; using No = integral_constant<bool, false>;
+  using W4 = integral_constant<int, 4>; using W2 = integral_constant<int, 2>; using W0c = integral_constant<int, 0>;
+  using WN = integral_constant<int, -1>;
+  const int nk = p.K >> 6;
+  int tile = blockIdx.x;
+  set_tile(tile);
+  issue_prologue();
+  while (true) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // at most 6 operations outstanding: the six oldest of the 12 prologue loads (A0, W0, W1 of K tile 0, this wave's
+  // share) have landed - epilogue stores of the previous tile are younger and only make the wait stricter
+  gemm_wait_vmcnt<6>();
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier ahead: its MFMAs meet group 0's reads
   __builtin_amdgcn_sched_barrier(0);
 
-  using Yes = integral_constant<bool, true>; using No = integral_constant<bool, false>;
-  using W4 = integral_constant<int, 4>; using W2 = integral_constant<int, 2>; using W0c = integral_constant<int, 0>;
-  using WN = integral_constant<int, -1>;
-  const int nk = p.K >> 6;
   int t = 0;
   for (; t < nk - 2; ++t) {
     sp(I0{}, Yes{}, W4{}, t);
@@ -736,6 +758,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   sp(I0{}, No{}, W0c{}, t);
   sp(I1{}, No{}, WN{}, t);
   if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
-  __syncthreads();   // every wave is done reading the stages: LDS becomes the epilogue staging area
-  gemm_epilogue_staged<EPI, 2, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, gemm_smem + wave * (32 * (2 * 32 * 4 + 16)));
+  __syncthreads();   // every wave is done reading the stages
+  // the next tile's first loads go out now and land under this tile's epilogue.  Their targets are the buffers of
+  // (A0, W0, W1, A1 | stage 0) and (A0, W0 | stage 1); the epilogue stages its rows in the 48 KiB that are not:
+  // W1 | stage 1 (112..128 KiB) and the 32 KiB above the eight buffers.
+  const int mbase = m0 + wm * 128, nbase = n0 + wn * 64;
+  const int next = tile + gridDim.x;
+  if (next < ntiles) { set_tile(next); issue_prologue(); }
+  // fp32 outputs: 16 rows per pass (16 x 272 B per wave); fp16 outputs fit whole 32-row slabs (32 x 144 B)
+  constexpr bool F32OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32;
+  constexpr int EROWS = F32OUT ? 16 : 32;
+  gemm_epilogue_staged<EPI, 2, 4, false, EROWS>(p, acc, mbase, nbase, lane, gemm_smem + 114688 + wave * 4608);
+  if (next >= ntiles) break;
+  tile = next;
+  __syncthreads();   // staging rows are read before the next tile's DMA wraps around to W1 | stage 1
+  }
 }

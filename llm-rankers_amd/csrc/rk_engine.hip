@@ -90,7 +90,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x1F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0;
+  int opt_glds = 1, opt_skinny = 0x1F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1;
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
@@ -174,8 +174,8 @@ void launch_v2(hipStream_t st, const GemmArgs& a) {
 }
 
 template <int EPI, int KO = 0>
-void launch_pp2(hipStream_t st, const GemmArgs& a) {
-  constexpr int smem = 2 * 4 * 128 * 64 * 2;
+void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
+  constexpr int smem = 2 * 4 * 128 * 64 * 2 + 32768;   // 8 half-tile buffers + 32 KiB epilogue staging = all 160 KiB
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t rc = hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -183,7 +183,10 @@ void launch_pp2(hipStream_t st, const GemmArgs& a) {
     attr_done = true;
   }
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
-  hipLaunchKernelGGL((gemm_pp2_kernel<EPI, KO>), dim3(tiles), dim3(512), smem, st, a);
+  // persistent: one workgroup per CU walks the tiles (max_wgs = CUs rounded down to a multiple of 8 keeps the tile -> XCD
+  // association); max_wgs <= 0: one workgroup per tile
+  const int grid = max_wgs > 0 && tiles > max_wgs ? max_wgs : tiles;
+  hipLaunchKernelGGL((gemm_pp2_kernel<EPI, KO>), dim3(grid), dim3(512), smem, st, a);
 }
 
 // Tile-shape choice.  variant: 0 = auto, 1 = 128x128 (v1, two workgroups per CU), 2 = 256x256, 3 = 256x192,
@@ -194,7 +197,7 @@ void launch_pp2(hipStream_t st, const GemmArgs& a) {
 int choose_variant(const rk_engine* e, int epi, int M, int N, int K) {
   if (e->opt_gemm_variant) return (e->opt_gemm_variant == 3 && epi == EPI_GEGLU_F16) ? 2 : e->opt_gemm_variant;
   struct V { int id, bm, bn, slots; double round_us; };
-  static const V vs[5] = {{5, 256, 256, 256, 27.0}, {2, 256, 256, 256, 29.8}, {3, 256, 192, 256, 24.7}, {4, 256, 128, 256, 19.0}, {1, 128, 128, 512, 17.3}};
+  static const V vs[5] = {{5, 256, 256, 256, 25.5}, {2, 256, 256, 256, 29.8}, {3, 256, 192, 256, 24.7}, {4, 256, 128, 256, 19.0}, {1, 128, 128, 512, 17.3}};
   double best = 1e30; int bv = 1;
   for (const V& v : vs) {
     if (v.id == 3 && epi == EPI_GEGLU_F16) continue;
@@ -212,18 +215,18 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
   if constexpr (EPI == EPI_STORE_F16) {                              // timing-only knock-outs (gemm_variant 80 + mask)
     if (variant > 80 && variant < 88 && a.K >= 128) {
       switch (variant - 80) {
-        case 1: launch_pp2<EPI, 1>(st, a); return;
-        case 2: launch_pp2<EPI, 2>(st, a); return;
-        case 3: launch_pp2<EPI, 3>(st, a); return;
-        case 4: launch_pp2<EPI, 4>(st, a); return;
-        case 5: launch_pp2<EPI, 5>(st, a); return;
-        default: launch_pp2<EPI, 6>(st, a); return;
+        case 1: launch_pp2<EPI, 1>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
+        case 2: launch_pp2<EPI, 2>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
+        case 3: launch_pp2<EPI, 3>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
+        case 4: launch_pp2<EPI, 4>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
+        case 5: launch_pp2<EPI, 5>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
+        default: launch_pp2<EPI, 6>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
       }
     }
   }
   if (variant > 5) variant = 5;
   if (variant == 5 && a.K < 128) variant = 2;                       // the ping-pong kernel needs two K tiles
-  if (variant == 5) { launch_pp2<EPI>(st, a); return; }
+  if (variant == 5) { launch_pp2<EPI>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return; }
   if (variant == 2) { launch_v2<EPI, 2, 4, 4, 2>(st, a); return; }
   if (variant == 3 && EPI != EPI_GEGLU_F16) { launch_v2<EPI, 4, 2, 2, 3>(st, a); return; }
   if (variant == 4) { launch_v2<EPI, 4, 2, 2, 2>(st, a); return; }
@@ -1076,6 +1079,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!e || !key) return RK_ERR_INVALID;
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x1F : value; return RK_OK; }   // bit per epilogue kind
+  if (!strcmp(key, "gemm_persistent")) { e->opt_gemm_persistent = value; return RK_OK; }   // ping-pong GEMM: 1 = one workgroup per CU walks the tiles
   if (!strcmp(key, "attn_ko")) { e->opt_attn_ko = value; return RK_OK; }   // timing-only knock-outs, see AttnEncArgs
   if (!strcmp(key, "attn_heads_per_wg")) { e->opt_attn_heads_per_wg = value; return RK_OK; }   // 0 auto
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
@@ -1154,7 +1158,7 @@ int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_fl
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_short_kernel<4>, 256, 0); out[0] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_pair_kernel<1>, 384, ATTP_GROUP_LDS); out[1] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f16_kernel<EPI_STORE_F16, true>, 256, GEMM_LDS_BYTES); out[2] = (float)n;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_pp2_kernel<EPI_STORE_F16, 0>, 512, 131072); out[3] = (float)n;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_pp2_kernel<EPI_STORE_F16, 0>, 512, 163840); out[3] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_kernel, 256, 0); out[4] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rmsnorm_kernel<4>, 256, 0); out[5] = (float)n;
     return 6;
