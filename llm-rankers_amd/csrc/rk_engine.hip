@@ -215,18 +215,18 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
   if constexpr (EPI == EPI_STORE_F16) {                              // timing-only knock-outs (gemm_variant 80 + mask)
     if (variant > 80 && variant < 88 && a.K >= 128) {
       switch (variant - 80) {
-        case 1: launch_pp2<EPI, 1>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
-        case 2: launch_pp2<EPI, 2>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
-        case 3: launch_pp2<EPI, 3>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
-        case 4: launch_pp2<EPI, 4>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
-        case 5: launch_pp2<EPI, 5>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
-        default: launch_pp2<EPI, 6>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return;
+        case 1: launch_pp2<EPI, 1>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
+        case 2: launch_pp2<EPI, 2>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
+        case 3: launch_pp2<EPI, 3>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
+        case 4: launch_pp2<EPI, 4>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
+        case 5: launch_pp2<EPI, 5>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
+        default: launch_pp2<EPI, 6>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
       }
     }
   }
   if (variant > 5) variant = 5;
   if (variant == 5 && a.K < 128) variant = 2;                       // the ping-pong kernel needs two K tiles
-  if (variant == 5) { launch_pp2<EPI>(st, a, e->opt_gemm_persistent ? (e->n_cu & ~7) : 0); return; }
+  if (variant == 5) { launch_pp2<EPI>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return; }
   if (variant == 2) { launch_v2<EPI, 2, 4, 4, 2>(st, a); return; }
   if (variant == 3 && EPI != EPI_GEGLU_F16) { launch_v2<EPI, 4, 2, 2, 3>(st, a); return; }
   if (variant == 4) { launch_v2<EPI, 4, 2, 2, 2>(st, a); return; }
