@@ -668,7 +668,10 @@ __device__ __forceinline__ float row16_sum_f(float v) {
   return v;
 }
 
-// grid = (nch, M, ceil(H/16)); 256 threads.  One 64-key chunk of one decoder row for a group of up to 16 heads.
+// grid = (nch, M, ceil(H/HPW)); 256 threads.  One 64-key chunk of one decoder row for a group of up to HPW heads
+// (16: one workgroup per chunk and row - the 256-passage groups; 4: four times as many, lighter workgroups for the
+// few-row setwise calls, where 48 workgroups of 16 heads left most of the chip idle).  Per-head arithmetic is the same.
+template <int HPW>
 __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
   __shared__ __attribute__((aligned(16))) float sP[64 * 16];
   __shared__ float sRed[2][4][16];
@@ -679,14 +682,14 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
   const int t0 = ck * 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l15 = lane & 15, g = lane >> 4;
-  const int nh = min(16, p.H - hg * 16);
-  float* stat = p.stat + (((size_t)m * p.nch + ck) * p.H + hg * 16) * 2;
+  const int nh = min(HPW, p.H - hg * HPW);
+  float* stat = p.stat + (((size_t)m * p.nch + ck) * p.H + hg * HPW) * 2;
   if (t0 >= L) {     // this row has no keys here: mark the chunk empty for the combine step
     if (tid < nh) { stat[tid * 2] = -1e30f; stat[tid * 2 + 1] = 0.f; }
     return;
   }
   // ---- scores: S[h][t] = qk[h] . e_t  by MFMA 16x16x32 (A = the 16 head rows of qk, B = 16 encoder rows per wave) ----
-  const int hrow = min(hg * 16 + l15, p.H - 1);
+  const int hrow = min(hg * HPW + l15, p.H - 1);
   const half_t* ap = p.qk + ((size_t)m * p.H + hrow) * p.d + 8 * g;
   const int t = t0 + wave * 16 + l15;
   const half_t* bp = p.enc + (size_t)(tok0 + min(t, L - 1)) * p.d + 8 * g;
@@ -726,11 +729,11 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
   }
   // ---- partial weighted sums of the raw encoder rows: thread owns 4 consecutive columns ----
   const int nvalid = min(64, L - t0);
-  float* part = p.part + (((size_t)m * p.nch + ck) * p.H + hg * 16) * p.d;
+  float* part = p.part + (((size_t)m * p.nch + ck) * p.H + hg * HPW) * p.d;
   for (int cb = tid * 4; cb < p.d; cb += 1024) {
-    float a[16][4];
+    float a[HPW][4];
 #pragma unroll
-    for (int h = 0; h < 16; ++h)
+    for (int h = 0; h < HPW; ++h)
 #pragma unroll
       for (int j = 0; j < 4; ++j) a[h][j] = 0.f;
     const half_t* ep = p.enc + (size_t)(tok0 + t0) * p.d + cb;
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
       const half4 e4 = *(const half4*)(ep + (size_t)tt * p.d);
       const float e0 = (float)e4[0], e1 = (float)e4[1], e2 = (float)e4[2], e3 = (float)e4[3];
 #pragma unroll
-      for (int hq = 0; hq < 4; ++hq) {
+      for (int hq = 0; hq < HPW / 4; ++hq) {
         const f32x4 w4 = *(const f32x4*)(sP + tt * 16 + hq * 4);      // LDS broadcast read, 4 heads at a time
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
       }
     }
 #pragma unroll
-    for (int h = 0; h < 16; ++h)
+    for (int h = 0; h < HPW; ++h)
       if (h < nh) { f32x4 o = {a[h][0], a[h][1], a[h][2], a[h][3]}; *(f32x4*)(part + (size_t)h * p.d + cb) = o; }
   }
 }

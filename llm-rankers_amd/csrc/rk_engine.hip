@@ -436,7 +436,10 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
       XAttnArgs xa{sl.xqk, sl.enc_out, sl.d_seq_off, sl.xpart, sl.xstat, sl.xctx, Ld, H, dm, nch};
       {
         Bracket br(e, st, PC_DEC_ATTN, 4.0 * M * (double)sl.maxL * H * dm, (double)sl.T * dm * 2.0 * 2);
-        hipLaunchKernelGGL(xattn_part_kernel, dim3(nch, M, (H + 15) / 16), dim3(256), 0, st, xa);
+        if ((long)nch * M * ((H + 15) / 16) >= 2 * e->n_cu)
+          hipLaunchKernelGGL(xattn_part_kernel<16>, dim3(nch, M, (H + 15) / 16), dim3(256), 0, st, xa);
+        else
+          hipLaunchKernelGGL(xattn_part_kernel<4>, dim3(nch, M, (H + 3) / 4), dim3(256), 0, st, xa);
         hipLaunchKernelGGL(xattn_combine_kernel, dim3(H, M), dim3(256), 0, st, xa);
       }
       const half_t* wv = e->cross_kv_w + ((size_t)l * 2 * I + I) * dm;
