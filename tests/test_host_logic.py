@@ -73,6 +73,30 @@ def test_all_reference_cases_cpu(cases, runtimes):
         check_case(case, build_ranker(case, rt, tok), score_tol=2e-5)
 
 
+@pytest.mark.parametrize("scoring", ["likelihood", "generation"])
+def test_level_batched_build_heap_equals_one_by_one(runtimes, scoring):
+    """The build phase submits the independent sift-downs of a heap level in one engine call: same ranking, caller
+    list and counters as the reference's one-compare-at-a-time order (three internal levels here)."""
+    rt, tok = runtimes["ckpt_gated_untied"]
+    rs = random.Random(7)
+    words = ["alpha", "beta", "gamma", "delta", "eps", "zeta", "eta", "theta"]
+    docs = [(f"d{i}", float(40 - i), " ".join(rs.choice(words) for _ in range(rs.randint(3, 9)))) for i in range(40)]
+    outs = []
+    for batched in (False, True):
+        rk = SetwiseLlmRanker(None, None, "cuda", num_child=3, k=5, scoring=scoring, method="heapsort", _runtime=rt, _tokenizer=tok)
+        rk.batch_independent_compares = batched
+        calls = []
+        many = rk._compare_many
+        rk._compare_many = lambda q, dl, _m=many, _c=calls: (_c.append(len(dl)), _m(q, dl))[1]
+        ranking = [SearchResult(docid=d, score=sc, text=t) for d, sc, t in docs]
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = rk.rerank("which greek letter", ranking)
+        outs.append(([(r.docid, r.score) for r in res], [r.docid for r in ranking],
+                     [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens]))
+        assert (len(calls) > 0 and max(calls) > 1) == batched
+    assert outs[0] == outs[1]
+
+
 def test_truncate(cases, runtimes):
     rt, tok = runtimes["ckpt_gated_untied"]
     pw = PointwiseLlmRanker(None, None, "cuda", method="yes_no", batch_size=2, _runtime=rt, _tokenizer=tok)

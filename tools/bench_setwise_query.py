@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""One setwise heapsort query end to end (BASELINE.json configs[2] shape: hits=100, num_child=10, k=10, flan-t5-large
+dims, ~128-token passages, synthetic weights and the test tokenizer): SetwiseLlmRanker.rerank() wall time with the
+build phase one compare at a time (the reference's order) and with the level-batched build phase."""
+import contextlib
+import io
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(REPO, "llm-rankers_amd"), REPO]
+from llmrankers import _synth                      # noqa: E402
+from llmrankers._engine import RkEngine            # noqa: E402
+from llmrankers.rankers import SearchResult        # noqa: E402
+from llmrankers.setwise import SetwiseLlmRanker    # noqa: E402
+
+
+class EngineRuntime:
+    """T5Runtime's interface on an engine with synthetic weights (no checkpoint directory needed)."""
+    def __init__(self, eng, dims):
+        self.engine, self.config = eng, dims.to_hf_config()
+
+    def score(self, seqs, dec_prefix, out_ids):
+        return self.engine.score(seqs, dec_prefix, out_ids)
+
+    def greedy(self, seqs, dec_prefix, max_new, eos_id=1, pad_id=0):
+        toks, steps = self.engine.greedy(seqs, dec_prefix, max_new, eos_id, pad_id)
+        toks = toks.copy()
+        toks[:, steps:] = -1
+        return toks
+
+
+def main():
+    from transformers import T5Tokenizer
+    tok = T5Tokenizer.from_pretrained(os.path.join(REPO, "tests", "golden", "tok"))
+    dims = _synth.FLAN_T5_LARGE
+    eng = RkEngine(dims, 0, max_tokens=32768, max_seqs=16, max_dec_len=8)
+    eng.load_state(_synth.synth_tensors(dims, seed=929, threads=min(32, os.cpu_count() or 8)))
+    rt = EngineRuntime(eng, dims)
+    rs = random.Random(3)
+    vocab = [tok.convert_ids_to_tokens(i).replace("▁", "") for i in range(10, 200)]
+    vocab = [w for w in vocab if w.isalpha()] or ["a", "b", "c"]
+    docs = [(f"d{i}", float(100 - i), " ".join(rs.choice(vocab) for _ in range(60))) for i in range(100)]
+    out = {}
+    for scoring in ("likelihood", "generation"):
+        for batched in (False, True):
+            rk = SetwiseLlmRanker(None, None, "cuda", num_child=10, k=10, scoring=scoring, method="heapsort", _runtime=rt, _tokenizer=tok)
+            rk.batch_independent_compares = batched
+            best, res0 = None, None
+            for rep in range(3):
+                ranking = [SearchResult(docid=d, score=s, text=rk.truncate(t, 128)) for d, s, t in docs]
+                rk.total_compare = rk.total_prompt_tokens = rk.total_completion_tokens = 0
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    res = rk.rerank("which passage mentions the most relevant words", ranking)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+                res0 = [r.docid for r in res][:10]
+            out[f"{scoring}_{'batched' if batched else 'one_by_one'}"] = {
+                "ms_per_query": round(best * 1e3, 1), "compares": rk.total_compare,
+                "avg_prompt_tokens": round(rk.total_prompt_tokens / max(rk.total_compare, 1), 1), "top10": res0}
+    for scoring in ("likelihood", "generation"):
+        assert out[f"{scoring}_batched"]["top10"] == out[f"{scoring}_one_by_one"]["top10"], "batched build phase changed the ranking"
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
