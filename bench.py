@@ -168,6 +168,7 @@ def main():
     scores = eng.read_scores(0)[:B]
     assert all(np.isfinite(eng.read_scores(s)).all() for s in range(n_slots))
 
+    invalid = "RK_DEBUG_SKIP_DECODER set: decoder skipped, NOT a valid measurement" if os.environ.get("RK_DEBUG_SKIP_DECODER") else None
     roofline = None
     if not args.no_profile:
         eng.profile(True)
@@ -234,7 +235,7 @@ def main():
                        "workload": f"{args.model} pointwise yes_no, hits=100 batch_size={B} (one step = one batch), "
                                    f"L_e={L} (128-token passage + 32-token query + template), L_d=1, 2 label rows",
                        "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world} (candidate sharding + 1 RCCL all_gather/step)",
-                       "weights": "synthetic N(0, HF-init std), seed 929", "engine_stream_ms_per_step": round(ev_ms / args.steps, 3),
+                       "weights": "synthetic N(0, HF-init std), seed 929", **({"INVALID": invalid} if invalid else {}), "engine_stream_ms_per_step": round(ev_ms / args.steps, 3),
                        "algorithmic_gflop_per_passage": round(gfl, 2),
                        "note_executed_flops": "throughput fractions use the reference's algorithmic FLOPs (SURVEY 8d); the engine skips "
                                               "the dead decoder q/k at L_d=1 and replaces the 18.5 GFLOP/passage cross-K/V projections by "

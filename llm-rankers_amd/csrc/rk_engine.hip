@@ -579,6 +579,8 @@ int score_slot(rk_engine* e, int slot, const int32_t* dec_prefix, int dec_len, c
   if ((rc = upload_small(e, sl, sd, &sl.cache_rows, sl.d_last_rows, 2, rows.data(), sl.n_seq))) return rc;
   if ((rc = encoder_then_handoff(e, sl, dec_len))) return rc;
   static const bool skip_dec = getenv("RK_DEBUG_SKIP_DECODER") != nullptr;   // measurement only: encoder-chain floor
+  static bool warned = false;
+  if (skip_dec && !warned) { fprintf(stderr, "[rk_engine] RK_DEBUG_SKIP_DECODER is set: scores are GARBAGE (encoder-only timing run)\n"); warned = true; }
   if (!skip_dec && (rc = run_decoder(e, sl, dec_len))) return rc;
   rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, sl.n_seq, head_scale(e));
   {
@@ -638,8 +640,8 @@ int rk_engine_create(const rk_model_desc* desc, int device_ordinal, rk_engine** 
   // the decoder chain is a long sequence of tiny dependent kernels: give it dispatch priority over the encoder's
   // chip-filling GEMM grids so it progresses while they run
   for (int i = 0; ok && i < RK_SLOTS; ++i)
-    ok = hipStreamCreateWithPriority(&e->slots[i].se, hipStreamNonBlocking, getenv("RK_ENC_PRIO_HI") ? prio_hi : prio_lo) == hipSuccess &&
-         hipStreamCreateWithPriority(&e->slots[i].sd, hipStreamNonBlocking, getenv("RK_DEC_PRIO_LO") ? prio_lo : prio_hi) == hipSuccess;
+    ok = hipStreamCreateWithPriority(&e->slots[i].se, hipStreamNonBlocking, prio_lo) == hipSuccess &&
+         hipStreamCreateWithPriority(&e->slots[i].sd, hipStreamNonBlocking, prio_hi) == hipSuccess;
   ok = ok && hipEventCreate(&e->t0) == hipSuccess && hipEventCreate(&e->t1) == hipSuccess &&
        hipEventCreateWithFlags(&e->t_tmp, hipEventDisableTiming) == hipSuccess;
   for (int i = 0; ok && i < RK_SLOTS; ++i)
