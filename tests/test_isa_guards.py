@@ -1,0 +1,84 @@
+"""Compile-time guards on the generated gfx950 ISA (no GPU needed: hipcc cross-compiles).
+
+Two kernels rely on properties the compiler does not promise:
+* attn_enc_pair_kernel prefetches the next head's rows with inline-asm loads that the waitcnt pass does not track; the
+  destination registers must not be read, copied or spilled before the explicit `s_waitcnt vmcnt(0)`;
+* gemm_pp2_kernel keeps DMA loads in flight across barriers with counted vmcnt: its K loop must contain no
+  `vmcnt(0)` drain and no scratch traffic.
+A compiler upgrade that breaks either would give timing-dependent garbage or a silent 2x slowdown; this test fails instead.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(REPO, "llm-rankers_amd", "csrc", "rk_engine.hip")
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "rk.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",
+                    "-w", SRC, "-o", str(out)], check=True, timeout=600)
+    return out.read_text().split("\n")
+
+
+def kernel_body(lines, mangled):
+    start = next(i for i, l in enumerate(lines) if l.startswith(mangled + ":"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    return lines[start:end + 1]
+
+
+def vregs(text):
+    out = set()
+    for a, b in re.findall(r"v\[(\d+):(\d+)\]", text):
+        out.update(range(int(a), int(b) + 1))
+    out.update(int(a) for a in re.findall(r"\bv(\d+)\b", text))
+    return out
+
+
+def test_attention_prefetch_registers_untouched_until_the_wait(isa):
+    body = kernel_body(isa, "_Z20attn_enc_pair_kernelILi1EEv11AttnEncArgs")
+    dests, first, wait = set(), None, None
+    for i, l in enumerate(body):
+        in_asm = i > 0 and "ASMSTART" in body[i - 1]
+        m = re.match(r"\s*global_load_dword(?:x4)?\s+(v\[\d+:\d+\]|v\d+),", l)
+        if m and in_asm:
+            first = i if first is None else first
+            dests |= vregs(m.group(1))
+        if in_asm and "s_waitcnt vmcnt(0)" in l:
+            wait = i
+    assert first is not None and wait is not None and wait > first and len(dests) == 49, (first, wait, len(dests))
+    for i in range(first, wait):
+        code = body[i].split(";")[0]
+        if not code.strip() or code.strip().startswith(".") or "ASM" in body[i]:
+            continue
+        if i > 0 and "ASMSTART" in body[i - 1] and "global_load" in code:
+            continue
+        assert not (vregs(code) & dests), f"prefetch destination touched before the wait: {body[i].strip()}"
+    assert not any("scratch_" in l for l in body), "attention kernel spills"
+
+
+@pytest.mark.parametrize("epi", range(5))
+def test_pingpong_gemm_k_loop_keeps_loads_in_flight(isa, epi):
+    body = kernel_body(isa, f"_Z15gemm_pp2_kernelILi{epi}ELi0EEv8GemmArgs")
+    assert not any("scratch_" in l for l in body), "ping-pong GEMM spills"
+    # the K loop = the innermost loop that holds MFMAs
+    heads = [i for i, l in enumerate(body) if "Inner Loop Header" in l]
+    assert heads, "no inner loop found"
+    loops = []
+    for h in heads:
+        label = next(body[j].split(":")[0] for j in range(h, h - 3, -1) if body[j].startswith(".LBB"))
+        back = max(j for j, l in enumerate(body) if re.search(r"s_cbranch\w+\s+" + re.escape(label) + r"\b", l))
+        loops.append(body[h:back + 1])
+    kloop = max(loops, key=lambda b: sum("v_mfma" in l for l in b))
+    assert sum("v_mfma" in l for l in kloop) == 32, "two super-phases of 16 MFMA per K tile"
+    assert sum("global_load_lds_dwordx4" in l for l in kloop) == 8
+    assert not any(re.search(r"vmcnt\(0\)", l) for l in kloop), "the K loop drains the DMA queue"
+    assert sum("s_barrier" in l for l in kloop) == 4
