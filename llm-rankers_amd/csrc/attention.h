@@ -358,7 +358,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_enc_short_kerne
 // a workgroup handles 1 or 16 heads.  Here a 768-thread workgroup runs TWO heads of one sequence side by side (waves
 // 0-5 / 6-11: three waves on every SIMD), walks `heads_per_wg` head pairs in turn, and fetches the next pair's K, V, Q
 // rows and bias table entries into registers while the current pair is computed, so the only exposed memory latency is
-// the first pair's.  Per-(sequence, head) arithmetic is the short kernel's, bit for bit (shared attn_tile_softmax).
+// the first pair's.  (Also tried and slower: a warp-specialised form - 6 compute waves + 2 waves that fill a second LDS
+// buffer with the next head, one barrier per head - 0.61 vs 0.42 ms/step, bit-identical; not kept.)  Per-(sequence, head) arithmetic is the short kernel's, bit for bit (shared attn_tile_softmax).
 // grid = (ceil(ceil(H/2) / heads_per_wg), B), dynamic LDS = 2 x 54272 B.
 #define ATTP_GROUP_LDS (ATTS_MAXL * ATT_KSTR * 2 + 64 * ATTS_VSTR * 2 + 2 * ATTS_MAXL * 4)
 template <int NG>   // heads side by side in one workgroup: 1 (384 threads) or 2 (768 threads)
