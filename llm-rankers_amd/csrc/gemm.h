@@ -583,6 +583,12 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // walks its tiles and overlaps each tile's epilogue with the next tile's first loads (qkv at M = 23552: 170 -> 149 us,
 // FFN-in 326 -> 308 us).  KO: timing-only knock-outs for bottleneck hunting (results are garbage): 1 = no DMA in
 // the loop, 2 = no fragment reads, 4 = no MFMA.  Product code instantiates KO = 0 only.
+#ifndef GEMM_PP2_ISSUE_Q
+#define GEMM_PP2_ISSUE_Q 1      // the DMA instruction of a k16 step goes out after its MFMA number ISSUE_Q (0..3)
+#endif
+#ifndef GEMM_PP2_SETPRIO
+#define GEMM_PP2_SETPRIO 1
+#endif
 template <int EPI, int KO = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   constexpr int HALF = 128 * 64;
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if (GEMM_PP2_SETPRIO) __builtin_amdgcn_s_setprio(1);
     if constexpr ((KO & 4) != 0) {   // keep the fragment reads alive when the MFMAs are knocked out
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) asm volatile("" :: "v"(aF[0][ks]), "v"(aF[1][ks]), "v"(w0F[ks]), "v"(w1F[ks]));
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
         if constexpr (!(KO & 4))
           acc[ni][2 * SP + mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ni == 0 ? w0F[ks] : w1F[ks], aF[mi][ks], acc[ni][2 * SP + mi], 0, 0, 0);
         if constexpr (ISSUE) {
-          if (q == 1) {
+          if (q == GEMM_PP2_ISSUE_Q) {
             __builtin_amdgcn_sched_barrier(0);
             // SP0 of tile t prefetches W1(t+1), A1(t+1); SP1 prefetches A0(t+2), W0(t+2)  (stage of tile t+1 = st^1, t+2 = st)
             if constexpr (SP == 0) {
@@ -707,7 +713,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
           }
         }
       }
-    __builtin_amdgcn_s_setprio(0);
+    if (GEMM_PP2_SETPRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
