@@ -70,6 +70,29 @@ def test_gemm_vs_numpy(toy, shape, variant, glds):
         f"bad rows {np.unique(np.where(err > 1e-2 * np.sqrt(k))[0])[:16]} bad cols {np.unique(np.where(err > 1e-2 * np.sqrt(k))[1])[:16]}"
 
 
+def test_pingpong_gemm_random_shapes_bit_equal_to_lockstep_kernel(toy):
+    """The persistent ping-pong kernel keeps DMA loads in flight across barriers and tiles (counted vmcnt, staging
+    beside DMA targets): a schedule bug would show up as a mismatch that comes and goes, so many shapes, each run
+    three times, against the lock-step 256x256 kernel (bit-equal) and numpy."""
+    eng = toy["ckpt_gated_untied"][2]
+    rs = np.random.RandomState(20260926)
+    shapes = [(int(rs.randint(1, 1400)), int(rs.randint(1, 300)) * 4, int(rs.randint(2, 24)) * 64) for _ in range(20)]
+    shapes += [(2048, 1024, 1024), (513, 768, 128), (3000, 256, 2816)]
+    for m, n, k in shapes:
+        a = rs.standard_normal((m, k)).astype(np.float16)
+        w = rs.standard_normal((n, k)).astype(np.float16)
+        try:
+            eng.set_option("gemm_variant", 2)
+            ref = eng.debug_gemm(a, w, use_glds=True)
+            eng.set_option("gemm_variant", 5)
+            for _ in range(3):
+                np.testing.assert_array_equal(eng.debug_gemm(a, w, use_glds=True), ref, err_msg=f"shape {(m, n, k)}")
+        finally:
+            eng.set_option("gemm_variant", 0)
+        want = a.astype(np.float32) @ w.astype(np.float32).T
+        assert np.abs(ref - want).max() < 2e-3 * np.sqrt(k)
+
+
 @pytest.mark.parametrize("shape", [(1, 64, 64), (32, 128, 1024), (33, 96, 192), (100, 1024, 2816), (256, 1024, 1024), (200, 96, 2816)])
 def test_weight_streaming_gemm_vs_numpy(toy, shape):
     """The decoder's split-K kernel: fixed reduction tree -> every row is independent of how many rows share the launch."""
