@@ -674,7 +674,9 @@ __device__ __forceinline__ float row16_sum_f(float v) {
 // few-row setwise calls, where 48 workgroups of 16 heads left most of the chip idle).  Per-head arithmetic is the same.
 template <int HPW>
 __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
-  __shared__ __attribute__((aligned(16))) float sP[64 * 16];
+  // softmax weights of the chunk as fp16 KEY PAIRS [32 pairs][16 heads]: the weighted sums below run on v_dot2_f32_f16
+  // (two keys per instruction, fp32 accumulate) - half the VALU work of an fp32 FMA per key
+  __shared__ __attribute__((aligned(16))) half2v sP2[32 * 16];
   __shared__ float sRed[2][4][16];
   const int ck = blockIdx.x, m = blockIdx.y, hg = blockIdx.z;
   const int b = m / p.Ld;
@@ -716,7 +718,10 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
     const int h = 4 * g + r;
     mx[r] = fmaxf(fmaxf(sRed[0][0][h], sRed[0][1][h]), fmaxf(sRed[0][2][h], sRed[0][3][h]));
     const float e = __expf(acc[r] - mx[r]);
-    sP[(wave * 16 + l15) * 16 + h] = e;          // [key][head]: the 16 weights of one key are contiguous
+    {
+      const int key = wave * 16 + l15;              // [key pair][head][key & 1]
+      ((half_t*)sP2)[(((key >> 1) * 16 + h) << 1) + (key & 1)] = (half_t)e;
+    }
     sm[r] = row16_sum_f(e);
   }
   if (l15 == 0) {
@@ -737,17 +742,34 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
     for (int h = 0; h < HPW; ++h)
 #pragma unroll
       for (int j = 0; j < 4; ++j) a[h][j] = 0.f;
-    const half_t* ep = p.enc + (size_t)(tok0 + t0) * p.d + cb;
-    for (int tt = 0; tt < nvalid; ++tt) {
-      const half4 e4 = *(const half4*)(ep + (size_t)tt * p.d);
-      const float e0 = (float)e4[0], e1 = (float)e4[1], e2 = (float)e4[2], e3 = (float)e4[3];
+    const half_t* ep = p.enc + (size_t)tok0 * p.d + cb;
+    // 8 key pairs per round: the 16 row loads go out together (the loop is bound by memory latency, not by the dots)
+    const int npair = (nvalid + 1) >> 1;
+    for (int tp0 = 0; tp0 < npair; tp0 += 8) {
+      half4 ea[8], eb[8];
 #pragma unroll
-      for (int hq = 0; hq < HPW / 4; ++hq) {
-        const f32x4 w4 = *(const f32x4*)(sP + tt * 16 + hq * 4);      // LDS broadcast read, 4 heads at a time
+      for (int u = 0; u < 8; ++u) {
+        const int r0 = min(t0 + 2 * (tp0 + u), L - 1), r1 = min(t0 + 2 * (tp0 + u) + 1, L - 1);   // clamped rows carry weight 0
+        ea[u] = *(const half4*)(ep + (size_t)r0 * p.d);
+        eb[u] = *(const half4*)(ep + (size_t)r1 * p.d);
+      }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int h = hq * 4 + r;
-          a[h][0] += w4[r] * e0; a[h][1] += w4[r] * e1; a[h][2] += w4[r] * e2; a[h][3] += w4[r] * e3;
+      for (int u = 0; u < 8; ++u) {
+        if (tp0 + u < npair) {
+          half2v e2[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { e2[j][0] = ea[u][j]; e2[j][1] = eb[u][j]; }
+#pragma unroll
+          for (int hq = 0; hq < HPW / 4; ++hq) {
+            const half8 w8 = *(const half8*)(sP2 + (tp0 + u) * 16 + hq * 4);   // LDS broadcast read: 4 heads x (key, key+1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const half2v w2 = {w8[2 * r], w8[2 * r + 1]};
+              const int h = hq * 4 + r;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) a[h][j] = __builtin_amdgcn_fdot2(w2, e2[j], a[h][j], false);
+            }
+          }
         }
       }
     }
