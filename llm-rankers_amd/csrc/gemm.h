@@ -195,7 +195,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
   constexpr bool F32 = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32;
   constexpr int COLS = GEGLU ? NI * 16 : NI * 32;            // output columns of this wave
   constexpr int ELT = F32 ? 4 : 2;
-  constexpr int ROWB = COLS * ELT + 16;                        // padded LDS row (bytes), 16-B aligned
+  // padded LDS row (bytes).  fp32 rows: +16 (16-B accesses).  fp16 rows: +8 - a row stride of 8 x odd bytes puts the 32
+  // lanes' 8-byte pieces on 32 different bank pairs (with +16 the stride is a multiple of 4 banks: 2-way conflicts,
+  // 2-3 % of the kernel's cycles in PMC); rows are then only 8-B aligned, so they are read back as two 8-byte halves
+  constexpr int ROWB = COLS * ELT + (F32 ? 16 : 8);
   constexpr int CHUNKS = COLS * ELT / 16;                      // 16-B pieces per row
   constexpr int ROWS_PER_PASS = 64 / CHUNKS;
   const int ncol0 = GEGLU ? (nbase >> 1) : nbase;
@@ -258,7 +261,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
           if (EPI == EPI_RESID_F32 && !RESID_IN_ACC) { const f32x4 old = *(const f32x4*)c; v = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]}; }
           *(f32x4*)c = v;
         } else {
-          *(half8*)((half_t*)p.C + base + (size_t)m * p.ldc + n) = *(const half8*)sp;
+          const half4 lo = *(const half4*)sp, hi = *(const half4*)(sp + 8);
+          const half8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          *(half8*)((half_t*)p.C + base + (size_t)m * p.ldc + n) = v8;
         }
       }
     }
