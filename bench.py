@@ -56,10 +56,13 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (rk_engine_set_option), repeatable")
     ap.add_argument("--glds", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="1: decoder chain of step i overlaps encoder of step i+1 (two HIP streams)")
-    ap.add_argument("--group", type=int, default=8,
+    ap.add_argument("--group", type=int, default=0,
                     help="batches (steps) per engine launch sequence: 8 x 32 passages x 184 tokens = 184 GEMM tile rows, which fills "
-                         "the 256 CUs in whole rounds for every encoder GEMM (tiles: 2208 / 736 / 4048 / 736)")
+                         "the 256 CUs in whole rounds for every encoder GEMM (tiles: 2208 / 736 / 4048 / 736).  0 = auto: 8, or the "
+                         "largest of 7, 6, 5 that divides --steps when 8 does not (no ragged last group inside the timed region)")
     args = ap.parse_args()
+    if args.group <= 0:
+        args.group = next((g for g in (8, 7, 6, 5) if args.steps % g == 0), 8)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
