@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -158,17 +159,25 @@ hipStream_t enc_stream(rk_engine* e, Slot& sl) { return e->opt_overlap ? e->slot
 hipStream_t dec_stream(rk_engine* e, Slot& sl) { return e->opt_overlap ? sl.sd : e->slots[0].se; }
 
 // ---- kernel launch helpers ------------------------------------------------------------------------------
+// More than 64 KiB of dynamic LDS needs hipFuncSetAttribute, which applies per DEVICE: done once per (kernel, device),
+// whichever engine / thread launches it there first (engines on different GPUs may live in one process).
+inline void ensure_dynamic_lds(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (rc != hipSuccess) fprintf(stderr, "[rk_engine] hipFuncSetAttribute(%d B LDS) failed: %s\n", bytes, hipGetErrorString(rc));
+  done.fetch_or(bit, std::memory_order_release);
+}
+
 template <int EPI, int WM, int WN, int MI, int NI>
 void launch_v2(hipStream_t st, const GemmArgs& a) {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   constexpr int smem_stages = 2 * (BM + BN) * 64 * 2, smem_epi = WM * WN * 32 * (NI * 32 * 4 + 16);
   constexpr int smem = smem_stages > smem_epi ? smem_stages : smem_epi;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t rc = hipFuncSetAttribute((const void*)gemm_v2_kernel<EPI, WM, WN, MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (rc != hipSuccess) fprintf(stderr, "[rk_engine] hipFuncSetAttribute(%d B LDS) failed: %s\n", smem, hipGetErrorString(rc));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  ensure_dynamic_lds((const void*)gemm_v2_kernel<EPI, WM, WN, MI, NI>, smem, attr_done);
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   hipLaunchKernelGGL((gemm_v2_kernel<EPI, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), smem, st, a);
 }
@@ -176,12 +185,8 @@ void launch_v2(hipStream_t st, const GemmArgs& a) {
 template <int EPI, int KO = 0>
 void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
   constexpr int smem = 2 * 4 * 128 * 64 * 2 + 32768;   // 8 half-tile buffers + 32 KiB epilogue staging = all 160 KiB
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t rc = hipFuncSetAttribute((const void*)gemm_pp2_kernel<EPI, KO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (rc != hipSuccess) fprintf(stderr, "[rk_engine] hipFuncSetAttribute(%d B LDS) failed: %s\n", smem, hipGetErrorString(rc));
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  ensure_dynamic_lds((const void*)gemm_pp2_kernel<EPI, KO>, smem, attr_done);
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   // persistent: one workgroup per CU walks the tiles (max_wgs = CUs rounded down to a multiple of 8 keeps the tile -> XCD
   // association); max_wgs <= 0: one workgroup per tile
