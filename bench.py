@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """bench.py — passages/sec of the pointwise yes_no hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without torchrun: re-executes itself under
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   torch.distributed.run)
 
 Workload (BASELINE.json configs[1]): flan-t5-large dimensions, pointwise yes_no, batch_size=32, synthetic
 32-token-query / 128-token-passage prompts -> L_e = 184 encoder tokens per passage, decoder
@@ -12,17 +12,21 @@ passages through encoder + decoder + head with the token ids already resident in
 timed region; the host->device copy of 32x184 int32 = 23.5 KB is noted in DESIGN.md, never part of `value`).
 
 Multi-GPU: passages of a query are independent, so the candidate list shards across ranks (weak scaling: each
-rank scores its own batch of 32 per step) and the per-step scores are collected with ONE RCCL all_gather over
-xGMI (torch.distributed 'nccl' = RCCL).  value = passages all ranks scored / max-over-ranks time.
+rank scores its own batches) and every group's scores are collected with ONE RCCL all_gather over xGMI issued by the
+ENGINE itself (rk_comm_all_gather_slot: straight from the device score buffer, on the stream that produces it).
+torch.distributed ('gloo') only carries the host-side control plane: the RCCL id, the barrier, the max over ranks.
+value = passages all ranks scored / max-over-ranks time.
 
-Extra objects on the JSON line: `roofline` (the encoder GEMM kernel, MFMA-bound: algorithmic 2MNK flops per
-launch / average launch duration measured with HIP events on the engine's stream in a second, profiled pass)
-and `cpu_baseline` (the reference's CPU path — HF transformers fp32 — timed on this box's host cores, rank 0,
-N=1 only, on one batch of the same workload).
+Extra objects on the JSON line: `roofline` (the dominant kernel — the FFN-in + GEGLU GEMM — MFMA-bound: algorithmic
+2MNK flops per launch / average launch duration measured with HIP events on the engine's stream in a second, serial,
+profiled pass; the whole tiled-GEMM family beside it), `cpu_baseline` (the reference's CPU path — HF transformers
+fp32 — timed on this box's host cores, rank 0, N=1 only, on a bounded sample of the same workload) and
+`config.per_query` (what the drop-in API delivers one query at a time).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -32,6 +36,7 @@ sys.path.insert(0, REPO)
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
 YES_ID, NO_ID = 2163, 465     # flan-t5 "Yes"/"No" ids quoted from memory; any two rows cost the same
+GEMM_CLASSES = ["enc_gemm_qkv", "enc_gemm_o", "enc_gemm_ffn_in", "enc_gemm_ffn_out", "gemm_cross_kv"]
 
 
 def algorithmic_gflop_per_passage(d, L_e, L_d=1):
@@ -43,7 +48,17 @@ def algorithmic_gflop_per_passage(d, L_e, L_d=1):
     return (enc + dec) / 1e9
 
 
-def main():
+def auto_group(steps: int) -> int:
+    """Batches per engine launch sequence.  Around 8-10 batches (256-320 passages, 47-59 k tokens) every encoder GEMM
+    is an almost whole number of rounds over the 256 CUs and the decoder chain is amortised; the group size must not
+    put a ragged group inside the timed region, so it is the first preferred size that divides --steps."""
+    for g in (8, 10, 9, 12, 7, 11, 6, 5, 16, 4):
+        if steps % g == 0:
+            return g
+    return 8
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
@@ -53,17 +68,179 @@ def main():
     ap.add_argument("--seq_len", type=int, default=184)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_profile", action="store_true")
+    ap.add_argument("--no_per_query", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (rk_engine_set_option), repeatable")
     ap.add_argument("--glds", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="1: decoder chain of step i overlaps encoder of step i+1 (two HIP streams)")
-    ap.add_argument("--group", type=int, default=0,
-                    help="batches (steps) per engine launch sequence: 8 x 32 passages x 184 tokens = 184 GEMM tile rows, which fills "
-                         "the 256 CUs in whole rounds for every encoder GEMM (tiles: 2208 / 736 / 4048 / 736).  0 = auto: 8, or the "
-                         "largest of 7, 6, 5 that divides --steps when 8 does not (no ragged last group inside the timed region)")
-    args = ap.parse_args()
-    if args.group <= 0:
-        args.group = next((g for g in (8, 7, 6, 5) if args.steps % g == 0), 8)
+    ap.add_argument("--group", type=int, default=0, help="batches (steps) per engine launch sequence; 0 = auto (see auto_group)")
+    return ap.parse_args()
 
+
+def self_spawn(args):
+    """`python bench.py --gpus N` (no torchrun): start the N ranks ourselves, exactly as the driver's own launch line."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a launcher: re-executing as\n        %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    os.execv(sys.executable, cmd)
+
+
+class GroupPipeline:
+    """A step is one batch of B passages (the reference's batch_size).  The engine consumes steps in GROUPS of G batches
+    per launch sequence: the candidates of a query are all known up front, the reference's batch_size only shapes its
+    host loop, and results do not depend on batch composition (ragged execution, bit-exact — tests).  Group i runs in
+    slot i % n_slots; its decoder chain (own stream) overlaps the encoder of group i+1.  Steps that do not fill a last
+    group run as a smaller group."""
+
+    def __init__(self, eng, slot_seqs, B, G, dec, out_ids, world=1):
+        self.eng, self.slot_seqs, self.B, self.G, self.dec, self.out_ids, self.world = eng, slot_seqs, B, G, dec, out_ids, world
+        self.n_slots = len(slot_seqs)
+        self.i = self.launched = 0
+        self.last_slot = None
+
+    def stage_all(self):
+        for s in range(self.n_slots):
+            self.eng.stage(self.slot_seqs[s], slot=s)          # inputs resident in HBM before the timed region
+
+    def _launch_group(self):
+        slot = self.launched % self.n_slots
+        self.launched += 1
+        self.eng.score_staged(self.dec, self.out_ids, slot=slot)
+        if self.world > 1:                                     # ONE RCCL all_gather per group, behind the head kernel
+            self.eng.comm_all_gather(self.G * self.B * len(self.out_ids), slot=slot)
+        self.last_slot = slot
+
+    def run(self, steps):
+        for _ in range(steps):
+            self.i += 1
+            if self.i % self.G == 0:                           # the G-th batch of a group completes it: launch
+                self._launch_group()
+        rem = self.i % self.G
+        if rem:                                                # leftover steps: a smaller group (re-stage a shorter slot)
+            slot = self.launched % self.n_slots
+            self.eng.sync()
+            self.eng.stage(self.slot_seqs[slot][:rem * self.B], slot=slot)
+            self._launch_group()
+        self.i = 0
+
+
+def timed_run(eng, pipe, steps, warmup, fence):
+    """W untimed warm-up steps, then exactly `steps` steps between two fences.  Returns (wall seconds, HIP-event ms)."""
+    pipe.run(warmup)
+    fence()
+    pipe.stage_all()
+    fence()
+    t_start = time.perf_counter()
+    eng.timer_begin()
+    pipe.run(steps)
+    ev_ms = eng.timer_end()                                    # HIP events on the engine's own streams
+    fence()
+    return time.perf_counter() - t_start, ev_ms
+
+
+def profile_pass(eng, pipe, G, M_tokens):
+    """Second, serial pass with an event pair around every launch -> per-class time, the roofline object."""
+    eng.profile(True)
+    eng.profile_reset()
+    eng.set_option("overlap", 0)                               # per-kernel events need a serial timeline
+    n_prof = 3
+    for _ in range(n_prof):
+        eng.score_staged(pipe.dec, pipe.out_ids, slot=0)
+    eng.sync()
+    rep = eng.profile_report()
+    eng.profile(False)
+    eng.set_option("overlap", 1)
+    fam_ms = sum(rep[c]["ms"] for c in GEMM_CLASSES)
+    fam_fl = sum(rep[c]["flops"] for c in GEMM_CLASSES)
+    fam_n = sum(rep[c]["launches"] for c in GEMM_CLASSES)
+    total_ms = sum(v["ms"] for v in rep.values())
+    dom = max(GEMM_CLASSES, key=lambda c: rep[c]["ms"])       # the kernel with the largest share of GPU time
+    d = rep[dom]
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    # HBM-side traffic of the dominant kernel comes from rocprofv3 PMC passes of THIS command (tools/gpu_prof.sh:
+    # FETCH_SIZE and WRITE_SIZE each in their own --pmc run; gfx950: FETCH_SIZE x2 for wide coalesced reads, KiB units;
+    # MI355X_MICROARCH.md HBM section), summarised per launch in profiles/pmc_summary_latest.json.  It is only quoted
+    # when that summary was taken at this run's GEMM M (= tokens per launch sequence); otherwise null.
+    traffic, traffic_src = None, "no PMC summary for M=%d tokens per launch" % M_tokens
+    try:
+        with open(os.path.join(REPO, "profiles", "pmc_summary_latest.json")) as f:
+            pm = json.load(f)
+        if pm.get("tokens_per_launch") == M_tokens:
+            gk = [(v["stats"]["pct"], k, v) for k, v in pm["kernels"].items()
+                  if "gemm_" in k and v.get("stats") and "FETCH_SIZE" in v["pmc"] and "WRITE_SIZE" in v["pmc"]]
+            if gk:
+                _, kname, v = max(gk)
+                traffic = int((2 * v["pmc"]["FETCH_SIZE"]["avg_per_launch"] + v["pmc"]["WRITE_SIZE"]["avg_per_launch"]) * 1024)
+                traffic_src = f"bytes per launch of {kname}, rocprofv3 PMC at the same M, profiles/pmc_summary_latest.json"
+    except Exception:
+        pass
+    return {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": f"{dom}: gemm_pp2_kernel (256x256x64 ping-pong fp16 MFMA GEMM, fused GEGLU epilogue), M={M_tokens} N={2 * eng.dims.d_ff} K={eng.dims.d_model}",
+            "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2), "launches": int(d["launches"]),
+            "algorithmic_gflop_per_launch": round(d["flops"] / max(d["launches"], 1) / 1e9, 1),
+            "family": {"kernel": "all tiled encoder GEMM launches (qkv, o, ffn_in+GEGLU, ffn_out)",
+                       "achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 1) if fam_ms > 0 else None,
+                       "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if fam_ms > 0 else None,
+                       "launches": int(fam_n), "share_of_gpu_time": round(fam_ms / total_ms, 3) if total_ms else None},
+            "per_class": {k: {"ms_per_step": round(v["ms"] / (n_prof * G), 4),
+                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
+                          for k, v in rep.items() if v["launches"]}}
+
+
+def per_query_numbers(eng, dims, B, L):
+    """What the drop-in API delivers ONE query at a time (hits=100, batch_size=32 -> batches 32,32,32,4): (a) the
+    engine part on pre-tokenised prompts of the bench shape through T5Runtime.score_batches (what
+    PointwiseLlmRanker.rerank calls), (b) PointwiseLlmRanker.rerank on text, host tokenisation included (fixture
+    tokenizer, so the prompt length differs from 184)."""
+    import numpy as np
+    from llmrankers import _synth
+    from llmrankers._runtime import T5Runtime
+    rt = T5Runtime.from_engine(eng, dims)
+    out = {}
+    seqs = _synth.synth_token_batch(100, L, L, dims.vocab, seed=4242)
+    chunks = [seqs[s:s + B] for s in range(0, 100, B)]
+    ts = []
+    for _ in range(7):
+        t = time.perf_counter()
+        rt.score_batches(chunks, [0], [YES_ID, NO_ID])
+        ts.append(time.perf_counter() - t)
+    ms = float(np.median(ts[2:])) * 1e3
+    out["pretokenised"] = {"ms_per_query": round(ms, 2), "passages_per_s": round(100 / ms * 1e3, 1), "tokens_per_prompt": L}
+    try:
+        from transformers import T5Tokenizer
+        from llmrankers.pointwise import PointwiseLlmRanker
+        from llmrankers.rankers import SearchResult
+        tok = T5Tokenizer.from_pretrained(os.path.join(REPO, "tests", "golden", "tok"))
+        ranker = PointwiseLlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=B)
+        words = "neural ranking model search engine index retrieval document answer question relevant topic passage".split()
+        rs = np.random.RandomState(0)
+        query = " ".join(rs.choice(words, 30))
+        docs = [" ".join(rs.choice(words, 126)) for _ in range(100)]
+        ts = []
+        for _ in range(6):
+            ranking = [SearchResult(docid=str(i), score=float(100 - i), text=d) for i, d in enumerate(docs)]
+            t = time.perf_counter()
+            ranker.rerank(query, ranking)
+            ts.append(time.perf_counter() - t)
+        ms = float(np.median(ts[2:])) * 1e3
+        out["rerank_api"] = {"ms_per_query": round(ms, 2), "passages_per_s": round(100 / ms * 1e3, 1),
+                             "tokens_per_prompt": round(ranker.total_prompt_tokens / 100.0, 1),
+                             "note": "PointwiseLlmRanker.rerank incl. prompt building, host tokenisation (fixture tokenizer), sort"}
+    except Exception as exc:                                   # never take the headline number down
+        out["rerank_api"] = {"error": repr(exc)}
+    return out
+
+
+def main():
+    args = parse_args()
+    self_spawn(args)
+    if args.group <= 0:
+        args.group = auto_group(args.steps)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,9 +249,11 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")                # host-side control plane only; scores travel over RCCL
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -84,62 +263,30 @@ def main():
     from llmrankers._engine import RkEngine
 
     dims = _synth.NAMED_DIMS[args.model]
-    B, L = args.batch_size, args.seq_len
+    B, L, G = args.batch_size, args.seq_len, max(1, args.group)
     t0 = time.time()
     state = _synth.synth_state_dict(dims, seed=929, threads=min(32, os.cpu_count() or 8))
-    eng = RkEngine(dims, device=local_rank, max_tokens=max(8192, args.group * B * L), max_seqs=max(32, args.group * B), max_dec_len=4)
+    eng = RkEngine(dims, device=local_rank, max_tokens=max(8192, G * B * L, 100 * (L + 72)), max_seqs=max(128, G * B), max_dec_len=4)
     eng.load_state(state.items())
     eng.set_option("gemm_glds", args.glds)
     eng.set_option("overlap", args.overlap)
     for kv in args.opt:                                    # engine A/B switches for experiments, e.g. --opt gemm_variant=2
         k, v = kv.split("=")
         eng.set_option(k, int(v))
+    if world > 1:                                          # engine-owned RCCL communicator (K9); id travels over gloo
+        ids = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        eng.comm_init(ids[0], rank, world, G * B * 2)
     if rank == 0:
-        print(f"[bench] weights generated + engine finalized in {time.time() - t0:.1f}s", file=sys.stderr)
-    n_slots = eng.num_slots
-    G = max(1, args.group)
-    # A step is one batch of B passages (the reference's batch_size).  The engine consumes steps in GROUPS of G batches
-    # per launch sequence (default 8 x 32 = 256 passages): the candidates
-    # of a query are all known up front, the reference's batch_size only shapes its host loop, and results do not depend
-    # on batch composition (ragged execution, bit-exact - tests).  Group i runs in slot i % n_slots; its decoder chain
-    # (own stream) overlaps the encoder of group i+1.  Steps that do not fill a last group are run as a smaller group.
+        print(f"[bench] weights generated + engine finalized in {time.time() - t0:.1f}s; group = {G} batches", file=sys.stderr)
+
     def group_batch(n_batches, seed):
         return [s for j in range(n_batches) for s in _synth.synth_token_batch(B, L, L, dims.vocab, seed=seed + j)]
+    n_slots = eng.num_slots
     slot_seqs = [group_batch(G, 929 + rank * 64 + 8 * s) for s in range(n_slots)]
     seqs = slot_seqs[0][:B]
-    for s in range(n_slots):
-        eng.stage(slot_seqs[s], slot=s)                    # inputs resident in HBM before the timed region
-    dec, out_ids = [0], [YES_ID, NO_ID]
-    gathered = torch.empty((world, G * B, 2), dtype=torch.float32, device="cuda") if world > 1 else None
-    state_i = {"i": 0, "launched": 0}
-
-    def gather(slot):                                      # one RCCL all_gather of a finished group's [G*B,2] scores
-        sc = eng.read_scores(slot)
-        local = torch.zeros((G * B, 2), dtype=torch.float32)
-        local[:sc.shape[0]] = torch.from_numpy(sc)
-        dist.all_gather_into_tensor(gathered.view(-1), local.cuda(non_blocking=True).view(-1))
-
-    def launch_group():
-        g = state_i["launched"]
-        state_i["launched"] = g + 1
-        eng.score_staged(dec, out_ids, slot=g % n_slots)
-        if world > 1 and g > 0:
-            gather((g - 1) % n_slots)                      # lags one group behind so the pipeline stays full
-
-    def step():
-        i = state_i["i"]
-        state_i["i"] = i + 1
-        if (i + 1) % G == 0:                               # the G-th batch of a group completes it: launch
-            launch_group()
-
-    def flush(total_steps):
-        rem = total_steps % G
-        if rem:                                            # leftover steps: a smaller group (re-stage a shorter slot)
-            slot = state_i["launched"] % n_slots
-            eng.sync()
-            eng.stage(slot_seqs[slot][:rem * B], slot=slot)
-            launch_group()
-        state_i["i"] = 0
+    pipe = GroupPipeline(eng, slot_seqs, B, G, [0], [YES_ID, NO_ID], world)
+    pipe.stage_all()
 
     def fence():
         eng.sync()
@@ -148,75 +295,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    flush(args.warmup)
-    fence()
-    for s_ in range(n_slots):
-        eng.stage(slot_seqs[s_], slot=s_)
-    t_start = time.perf_counter()
-    eng.timer_begin()
-    for _ in range(args.steps):
-        step()
-    flush(args.steps)
+    elapsed, ev_ms = timed_run(eng, pipe, args.steps, args.warmup, fence)
     if world > 1:
-        gather((state_i["launched"] - 1) % n_slots)        # flush the last group's scores
-    ev_ms = eng.timer_end()                                # HIP events on the engine's own streams
-    fence()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        got = eng.comm_read_gathered(pipe.last_slot)       # [world, G*B*2]: every rank holds every rank's scores
+        assert got.shape[0] == world and np.isfinite(got[:, :2 * B]).all()
     scores = eng.read_scores(0)[:B]
     assert all(np.isfinite(eng.read_scores(s)).all() for s in range(n_slots))
 
-    invalid = "RK_DEBUG_SKIP_DECODER set: decoder skipped, NOT a valid measurement" if os.environ.get("RK_DEBUG_SKIP_DECODER") else None
     roofline = None
     if not args.no_profile:
-        eng.profile(True)
-        eng.profile_reset()
-        eng.set_option("overlap", 0)                        # per-kernel events need a serial timeline
-        n_prof = 3
-        for _ in range(n_prof):
-            eng.score_staged(dec, out_ids, slot=0)
-        eng.sync()
-        rep = eng.profile_report()
-        eng.profile(False)
-        gemm_classes = ["enc_gemm_qkv", "enc_gemm_o", "enc_gemm_ffn_in", "enc_gemm_ffn_out", "gemm_cross_kv"]
-        g_ms = sum(rep[c]["ms"] for c in gemm_classes)
-        g_fl = sum(rep[c]["flops"] for c in gemm_classes)
-        g_n = sum(rep[c]["launches"] for c in gemm_classes)
-        achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-        total_ms = sum(v["ms"] for v in rep.values())
-        # HBM-side traffic of the dominant GEMM kernel comes from rocprofv3 PMC passes of THIS command (tools/gpu_prof.sh:
-        # FETCH_SIZE and WRITE_SIZE each in their own --pmc run; gfx950: FETCH_SIZE x2 for wide coalesced reads, KiB units;
-        # MI355X_MICROARCH.md HBM section), summarised per launch in profiles/pmc_summary_latest.json.
-        traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(REPO, "profiles", "pmc_summary_latest.json")) as f:
-                pm = json.load(f)["kernels"]
-            gk = [(v["stats"]["pct"], k, v) for k, v in pm.items() if "gemm_" in k and v.get("stats") and "FETCH_SIZE" in v["pmc"]]
-            if gk:
-                _, kname, v = max(gk)
-                traffic = int((2 * v["pmc"]["FETCH_SIZE"]["avg_per_launch"] + v["pmc"]["WRITE_SIZE"]["avg_per_launch"]) * 1024)
-                traffic_src = f"bytes per launch of {kname} (largest share of GPU time), rocprofv3 PMC, profiles/pmc_summary_latest.json"
-        except Exception:
-            pass
-        roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "tiled fp16 MFMA GEMM family: gemm_pp2_kernel (256x256 ping-pong) with gemm_v2_kernel / gemm_f16_kernel as fill-in tile shapes (all encoder launches: qkv, o, ffn_in+GEGLU, ffn_out)",
-                    "avg_launch_us": round(g_ms * 1e3 / max(g_n, 1), 2), "launches": int(g_n),
-                    "gemm_share_of_gpu_time": round(g_ms / total_ms, 3) if total_ms else None,
-                    "per_class": {k: {"ms_per_step": round(v["ms"] / (n_prof * G), 4),
-                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 and v["flops"] > 0 else None}
-                                  for k, v in rep.items() if v["launches"]}}
+        pipe.stage_all()
+        roofline = profile_pass(eng, pipe, G, G * B * L)
+
+    per_query = None
+    if rank == 0 and world == 1 and not args.no_per_query:
+        per_query = per_query_numbers(eng, dims, B, L)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import hf_path
-            cpu = hf_path.time_cpu_baseline(dims, state, [list(s) for s in seqs], B, YES_ID, NO_ID, max_seconds=30.0)
+            cpu = hf_path.time_cpu_baseline(dims, state, [list(s) for s in seqs], YES_ID, NO_ID,
+                                              tokenizer_dir=os.path.join(REPO, "tests", "golden", "tok"))
             ref_logits = cpu.pop("logits")
             p_cpu = 1 / (1 + np.exp(-(ref_logits[:, 0] - ref_logits[:, 1])))
             p_gpu = 1 / (1 + np.exp(-(scores[:len(p_cpu), 0] - scores[:len(p_cpu), 1])))
@@ -237,14 +340,16 @@ def main():
             "config": {"engine_group": f"{G} batches ({G * B} passages) per engine launch sequence",
                        "workload": f"{args.model} pointwise yes_no, hits=100 batch_size={B} (one step = one batch), "
                                    f"L_e={L} (128-token passage + 32-token query + template), L_d=1, 2 label rows",
-                       "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world} (candidate sharding + 1 RCCL all_gather/step)",
-                       "weights": "synthetic N(0, HF-init std), seed 929", **({"INVALID": invalid} if invalid else {}), "engine_stream_ms_per_step": round(ev_ms / args.steps, 3),
+                       "global_batch": B * world, "seq_len": L,
+                       "parallelism": f"dp{world} (candidate sharding; one engine-issued RCCL all_gather per launch sequence)",
+                       "weights": "synthetic N(0, HF-init std), seed 929", "engine_stream_ms_per_step": round(ev_ms / args.steps, 3),
                        "algorithmic_gflop_per_passage": round(gfl, 2),
                        "note_executed_flops": "throughput fractions use the reference's algorithmic FLOPs (SURVEY 8d); the engine skips "
                                               "the dead decoder q/k at L_d=1 and replaces the 18.5 GFLOP/passage cross-K/V projections by "
                                               "the exact query-side form (DESIGN.md section 3)",
                        "whole_path_tflops_per_gpu": round(value / world * gfl / 1e3, 1),
-                       "whole_path_frac_of_mfma_peak": round(value / world * gfl / 1e3 / MFMA_PEAK_TFLOPS, 4)},
+                       "whole_path_frac_of_mfma_peak": round(value / world * gfl / 1e3 / MFMA_PEAK_TFLOPS, 4),
+                       "per_query": per_query},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -100,6 +100,23 @@ int rk_t5_read_scores_slot(rk_engine* e, int slot, float* out_logits, int n_floa
 /* device address of the fp32 score buffer [n_seq][n_out] of the last rk_t5_score_staged (for RCCL gathers) */
 int rk_t5_scores_device_ptr(rk_engine* e, void** out_ptr);
 
+/* ---- score collection across the GPUs of one node: one process per GPU, one engine per process.
+ * The reference has no counterpart (its multi-GPU mode is accelerate's layer placement, ref: pointwise.py:21); this
+ * replaces the torch.distributed round trip of a data-parallel caller.  RCCL (librccl.so.1) is dlopen'ed on first use.
+ * rank 0 makes the id, the caller ships its 128 bytes to every rank out of band (torchrun's store, a file, MPI ...),
+ * then EVERY rank calls rk_comm_init (collective).  max_floats_per_rank bounds the later gathers. */
+#define RK_COMM_ID_BYTES 128
+int rk_comm_unique_id(uint8_t* out_id, int n_bytes);
+int rk_comm_init(rk_engine* e, const uint8_t* id_bytes, int n_bytes, int rank, int world, int max_floats_per_rank);
+int rk_comm_world(const rk_engine* e, int* out_rank, int* out_world);
+/* ONE ncclAllGather of the slot's device score buffer (the first n_floats fp32 of what rk_t5_score_slot / rk_t5_qlm
+ * left there; every rank passes the same n_floats, ranks with fewer scores are read up to their own count by the
+ * caller), enqueued on the stream that produces the scores, followed by an async copy to pinned host memory.
+ * Returns without synchronising.  rk_comm_read_gathered_slot waits and copies out[world][n_floats]. */
+int rk_comm_all_gather_slot(rk_engine* e, int slot, int n_floats);
+int rk_comm_read_gathered_slot(rk_engine* e, int slot, float* out, int n_floats_total);
+int rk_comm_destroy(rk_engine* e);
+
 /* ---- measurement (HIP events on the engine's own stream) ---- */
 int rk_timer_begin(rk_engine* e);                 /* record start event on the engine stream */
 int rk_timer_end(rk_engine* e, float* out_ms);    /* record stop, synchronise, elapsed ms */

@@ -652,22 +652,8 @@ struct XAttnArgs {
   float* stat;           // [M, nch, H, 2]  (chunk max, chunk sum of exp)
   half_t* out;           // [M, H, d]   normalised  sum_t p[h][t] e_t  (fp16)
   int Ld, H, d, nch;
+  int row0;              // decoder row of this pass's first query (blockIdx.y is relative to it; qk / part / stat / out are per pass)
 };
-
-__device__ __forceinline__ float row16_max(float v) {   // max over an aligned group of 16 lanes (DPP, no LDS)
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)));
-  return v;
-}
-__device__ __forceinline__ float row16_sum_f(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
-  return v;
-}
 
 // grid = (nch, M, ceil(H/HPW)); 256 threads.  One 64-key chunk of one decoder row for a group of up to HPW heads
 // (16: one workgroup per chunk and row - the 256-passage groups; 4: four times as many, lighter workgroups for the
@@ -679,7 +665,7 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
   __shared__ __attribute__((aligned(16))) half2v sP2[32 * 16];
   __shared__ float sRed[2][4][16];
   const int ck = blockIdx.x, m = blockIdx.y, hg = blockIdx.z;
-  const int b = m / p.Ld;
+  const int b = (p.row0 + m) / p.Ld;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;
   const int t0 = ck * 64;

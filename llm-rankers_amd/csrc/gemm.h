@@ -31,6 +31,12 @@ struct GemmArgs {
   long split_stride; // in elements
   float scale;       // multiplies the accumulator (1.0 normally)
   long bsA, bsW, bsC; // skinny kernel only: element strides between the blockIdx.y batches (per-head GEMMs)
+  // folded RMSNorm.  Consumer: A is the un-normalised stream as fp16 x xs, W has the norm weight
+  // folded into its columns, rowscale[m] = rsqrt(mean(x_m^2) + eps) / xs multiplies the accumulators of row m.
+  const float* rowscale;
+  // Producer (fp32 residual epilogue): besides C += acc, write fp16(C x xs) to xraw [M, ldx] and the sums of squares of
+  // the new rows per 64-column block to ssq [M, nb]
+  half_t* xraw; float* ssq; int ldx, nb; float xs;
 };
 
 #define GEMM_BM 128
@@ -44,7 +50,8 @@ __device__ __forceinline__ float gelu_new_f(float x) {
   // 0.5 (1 + tanh u) == 1 / (1 + exp(-2u)) exactly; evaluated with the hardware exp2 / rcp (about 1e-6 relative,
   // far below the fp16 rounding of the result) instead of libm tanhf, which cost ~200 cycles per output here.
   const float u2 = -1.5957691216057308f * (x + 0.044715f * x * x * x);   // -2u
-  return x * __frcp_rn(1.0f + __expf(u2));
+  // (the raw v_rcp_f32, 1 ulp: __frcp_rn expands to the ten-instruction IEEE division sequence on this target)
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(u2));
 }
 
 template <bool GLDS>
@@ -187,12 +194,21 @@ __device__ __forceinline__ void gemm_prefetch_residual(const GemmArgs& p, f32x16
 
 // ROWS = 32: one pass per 32-row slab; ROWS = 16: two passes of 16 rows (half the staging bytes per wave - the
 // persistent ping-pong kernel stages beside the next tile's DMA targets and has only 48 KiB for it).
-template <int EPI, int NI, int MI, bool RESID_IN_ACC = false, int ROWS = 32>
+// rsc[mi]: the factor this lane's row of slab mi is multiplied by (p.scale, times the consumer-side RMSNorm row factor
+// when the GEMM reads the un-normalised stream - GemmArgs::rowscale).
+// DEPTH (fp32 residual epilogue): the OLD rows of DEPTH slabs ahead are already being fetched while a slab is staged,
+// added and stored - the read half of the read-modify-write is a chain of HBM round trips otherwise (a wave has one
+// slab = 4 loads of 1 KiB in flight, 32 KiB per CU: 3 TB/s over the chip however little else is running).
+// Producer side of the folded RMSNorm (p.xraw != nullptr, fp32 residual epilogue only): next to the new fp32 rows the
+// epilogue writes them once more as fp16 x p.xs (the next GEMM's A operand) and the sum of their squares per row and
+// 64-column block (one wave = one block; fixed in-lane + DPP order, so any tile shape writes the same bits).
+template <int EPI, int NI, int MI, bool RESID_IN_ACC = false, int ROWS = 32, int DEPTH = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase,
-                                                     int lane, unsigned char* stage) {
+                                                     int lane, unsigned char* stage, const float (&rsc)[MI]) {
   const int l31 = lane & 31, hh = lane >> 5;
   constexpr bool GEGLU = EPI == EPI_GEGLU_F16;
   constexpr bool F32 = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32;
+  constexpr bool RMW = EPI == EPI_RESID_F32 && !RESID_IN_ACC;  // the old rows are read here (not pre-added by the caller)
   constexpr int COLS = GEGLU ? NI * 16 : NI * 32;            // output columns of this wave
   constexpr int ELT = F32 ? 4 : 2;
   // padded LDS row (bytes).  fp32 rows: +16 (16-B accesses).  fp16 rows: +8 - a row stride of 8 x odd bytes puts the 32
@@ -201,12 +217,45 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
   constexpr int ROWB = COLS * ELT + (F32 ? 16 : 8);
   constexpr int CHUNKS = COLS * ELT / 16;                      // 16-B pieces per row
   constexpr int ROWS_PER_PASS = 64 / CHUNKS;
+  constexpr int HP = 32 / ROWS, NSLAB = MI * HP;
+  constexpr int PASSES = (ROWS + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+  constexpr int NPRE = RMW ? NSLAB : 1;
   const int ncol0 = GEGLU ? (nbase >> 1) : nbase;
   const int nlimit = GEGLU ? (p.N >> 1) : p.N;
+  const bool fold_out = EPI == EPI_RESID_F32 && p.xraw != nullptr;     // uniform
+  // this lane's place in the write-back passes: row (within a pass) and 16-byte chunk
+  const int prow = lane / CHUNKS, ch = lane % CHUNKS;
+  const bool lane_on = prow < ROWS_PER_PASS;
+  int n = ncol0 + ch * (16 / ELT);
+  const bool n_ok = n < nlimit;
+  size_t cbase = 0;
+  if (p.n_split > 0) { cbase = (size_t)(n / p.n_split) * (size_t)p.split_stride; n = n % p.n_split; }
+  f32x4 oldv[NPRE][PASSES];
+  auto fetch_old = [&](int sl) {       // sl is a compile-time constant after unrolling
+    const int mi = sl / HP, hp = sl % HP;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      const int row = i * ROWS_PER_PASS + prow;
+      int m = mbase + mi * 32 + hp * ROWS + row;
+      m = m < p.M ? m : p.M - 1;                                 // clamped rows are never stored
+      const int nn = n_ok ? n : 0;
+      oldv[RMW ? sl : 0][i] = *(const f32x4*)((const float*)p.C + cbase + (size_t)m * p.ldc + nn);
+    }
+  };
+  if constexpr (RMW && DEPTH > 0) {
+#pragma unroll
+    for (int sl = 0; sl < (DEPTH < NSLAB ? DEPTH : NSLAB); ++sl) fetch_old(sl);
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-  for (int hp = 0; hp < 32 / ROWS; ++hp) {
+  for (int hp = 0; hp < HP; ++hp) {
+    const int sl = mi * HP + hp;
+    if constexpr (RMW) {
+      if constexpr (DEPTH > 0) { if (sl + DEPTH < NSLAB) fetch_old(sl + DEPTH); }
+      else fetch_old(sl);
+    }
+    const float sc = rsc[mi];
     // ---- registers -> LDS (row l31 of the slab; with ROWS = 16 the lanes of the other half sit this pass out) ----
     unsigned char* myrow = stage + (l31 % ROWS) * ROWB;
     if (ROWS == 32 || (l31 / ROWS) == hp) {
@@ -218,7 +267,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
           half4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            o[j] = f2h_sat(gelu_new_f(acc[2 * g][mi][4 * q + j] * p.scale) * (acc[2 * g + 1][mi][4 * q + j] * p.scale));
+            o[j] = f2h_sat(gelu_new_f(acc[2 * g][mi][4 * q + j] * sc) * (acc[2 * g + 1][mi][4 * q + j] * sc));
           *(half4*)(myrow + (g * 32 + 8 * q + 4 * hh) * 2) = o;
         }
     } else {
@@ -228,14 +277,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
         for (int q = 0; q < 4; ++q) {
           const int c = ni * 32 + 8 * q + 4 * hh;
           if (F32) {
-            f32x4 o = {acc[ni][mi][4 * q] * p.scale, acc[ni][mi][4 * q + 1] * p.scale, acc[ni][mi][4 * q + 2] * p.scale,
-                       acc[ni][mi][4 * q + 3] * p.scale};
+            f32x4 o = {acc[ni][mi][4 * q] * sc, acc[ni][mi][4 * q + 1] * sc, acc[ni][mi][4 * q + 2] * sc,
+                       acc[ni][mi][4 * q + 3] * sc};
             *(f32x4*)(myrow + c * 4) = o;
           } else {
             half4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float v = acc[ni][mi][4 * q + j] * p.scale;
+              const float v = acc[ni][mi][4 * q + j] * sc;
               o[j] = f2h_sat(EPI == EPI_RELU_F16 ? fmaxf(v, 0.f) : v);
             }
             *(half4*)(myrow + c * 2) = o;
@@ -247,28 +296,50 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
     __builtin_amdgcn_wave_barrier();
     // ---- LDS -> global, 16 B per lane along the rows ----
 #pragma unroll
-    for (int r0 = 0; r0 < ROWS; r0 += ROWS_PER_PASS) {
-      const int row = r0 + lane / CHUNKS, ch = lane % CHUNKS;
+    for (int i = 0; i < PASSES; ++i) {
+      const int row = i * ROWS_PER_PASS + prow;
       const int m = mbase + mi * 32 + hp * ROWS + row;
-      int n = ncol0 + ch * (16 / ELT);
-      if (lane / CHUNKS < ROWS_PER_PASS && row < ROWS && m < p.M && n < nlimit) {
-        const unsigned char* sp = stage + row * ROWB + ch * 16;
-        size_t base = 0;
-        if (p.n_split > 0) { base = (size_t)(n / p.n_split) * (size_t)p.split_stride; n = n % p.n_split; }
-        if (F32) {
-          float* c = (float*)p.C + base + (size_t)m * p.ldc + n;
-          f32x4 v = *(const f32x4*)sp;
-          if (EPI == EPI_RESID_F32 && !RESID_IN_ACC) { const f32x4 old = *(const f32x4*)c; v = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]}; }
-          *(f32x4*)c = v;
-        } else {
-          const half4 lo = *(const half4*)sp, hi = *(const half4*)(sp + 8);
-          const half8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          *(half8*)((half_t*)p.C + base + (size_t)m * p.ldc + n) = v8;
+      const bool ok = lane_on && row < ROWS && m < p.M && n_ok;
+      const unsigned char* sp = stage + (row < ROWS ? row : 0) * ROWB + ch * 16;
+      if (F32) {
+        f32x4 v = *(const f32x4*)sp;
+        if constexpr (RMW) { const f32x4 old = oldv[sl][i]; v = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]}; }
+        if (ok) *(f32x4*)((float*)p.C + cbase + (size_t)m * p.ldc + n) = v;
+        if constexpr (EPI == EPI_RESID_F32 && CHUNKS == 16) {   // one wave = one 64-column block (the host never picks the 192-wide tile here)
+          if (fold_out) {
+            // explicit fma chain: left to the compiler, a*a + b*b contracts differently in different instantiations of
+            // this epilogue and the row statistics (hence every score) would depend on the tile shape
+            float ss = ok ? __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], v[0] * v[0]))) : 0.f;
+            ss = row16_sum_f(ss);                                // the 16 lanes of one row
+            if (ok) {
+              half4 xr = {f2h_sat(v[0] * p.xs), f2h_sat(v[1] * p.xs), f2h_sat(v[2] * p.xs), f2h_sat(v[3] * p.xs)};
+              *(half4*)(p.xraw + (size_t)m * p.ldx + n) = xr;
+              if (ch == 0) p.ssq[(size_t)m * p.nb + (ncol0 >> 6)] = ss;
+            }
+          }
         }
+      } else if (ok) {
+        const half4 lo = *(const half4*)sp, hi = *(const half4*)(sp + 8);
+        const half8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        *(half8*)((half_t*)p.C + cbase + (size_t)m * p.ldc + n) = v8;
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();      // slab fully read before the next one overwrites it
+  }
+}
+
+// Row factors of a wave's MI slabs for the staged epilogue: p.scale, times the RMSNorm row factor when the GEMM reads the
+// un-normalised stream (GemmArgs::rowscale; written by rowscale_kernel / embed_gather_kernel).
+template <int MI>
+__device__ __forceinline__ void gemm_row_factors(const GemmArgs& p, int mbase, int l31, float (&rsc)[MI]) {
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    rsc[mi] = p.scale;
+    if (p.rowscale) {
+      const int m = mbase + mi * 32 + l31;
+      rsc[mi] *= p.rowscale[m < p.M ? m : p.M - 1];
+    }
   }
 }
 
@@ -346,9 +417,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
   __syncthreads();   // every wave is done reading the last stage: LDS becomes the epilogue staging area
   if (EPI == EPI_RESID_F32) {
     GemmArgs q = p; q.scale = 1.f;
-    gemm_epilogue_staged<EPI, 2, 2, true>(q, acc, m0 + wm * 64, n0 + wn * 64, lane, gemm_smem + wave * (32 * (64 * 4 + 16)));
-  } else
-    gemm_epilogue_staged<EPI, 2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, gemm_smem + wave * (32 * (64 * 4 + 16)));
+    float rsc[2] = {1.f, 1.f};
+    gemm_epilogue_staged<EPI, 2, 2, true>(q, acc, m0 + wm * 64, n0 + wn * 64, lane, gemm_smem + wave * (32 * (64 * 4 + 16)), rsc);
+  } else {
+    float rsc[2];
+    gemm_row_factors<2>(p, m0 + wm * 64, l31, rsc);
+    gemm_epilogue_staged<EPI, 2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, gemm_smem + wave * (32 * (64 * 4 + 16)), rsc);
+  }
 }
 
 // ---- skinny GEMM: few rows (the single-step decoder: M = sequences in the batch; 32 rows per blockIdx.z) --------
@@ -540,11 +615,17 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN / 4) void gemm_v2_kernel(Gemm
   __syncthreads();   // every wave is done reading the last stage: LDS becomes the epilogue staging area
   if (PREFETCH_RES) {
     GemmArgs q = p; q.scale = 1.f;
+    float rsc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) rsc[i] = 1.f;
     gemm_epilogue_staged<EPI, NI, MI, true>(q, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, lane,
-                                            gemm_smem + wave * (32 * (NI * 32 * 4 + 16)));
-  } else
+                                            gemm_smem + wave * (32 * (NI * 32 * 4 + 16)), rsc);
+  } else {
+    float rsc[MI];
+    gemm_row_factors<MI>(p, m0 + wm * MI * 32, l31, rsc);
     gemm_epilogue_staged<EPI, NI, MI>(p, acc, m0 + wm * MI * 32, n0 + wn * NI * 32, lane,
-                                      gemm_smem + wave * (32 * (NI * 32 * 4 + 16)));
+                                      gemm_smem + wave * (32 * (NI * 32 * 4 + 16)), rsc);
+  }
 }
 
 // ================================= GEMM v3: 256x256 ping-pong ================================================
@@ -594,7 +675,8 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 #ifndef GEMM_PP2_SETPRIO
 #define GEMM_PP2_SETPRIO 1
 #endif
-template <int EPI, int KO = 0>
+// RS: consumer side of the folded RMSNorm - the accumulators of row m are multiplied by p.rowscale[m] (gemm_epilogue_staged)
+template <int EPI, int KO = 0, bool RS = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   constexpr int HALF = 128 * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
@@ -767,6 +849,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   ++t;
   // tile nk-1: nothing to prefetch; A1 of this tile is the only load that can still be in flight
   sp(I0{}, No{}, W0c{}, t);
+  // nothing is in flight and the loop has no counted wait left: the row factors of the folded RMSNorm travel under the
+  // last 16 MFMAs.  Issued through inline asm (one 32-bit lane offset against the uniform base, immediate offsets for
+  // the four 32-row slabs - the buffer is padded, rows beyond M read defined junk) so that neither 64-bit address
+  // registers nor compiler-placed waits appear here: with 254 VGPRs live the tracked form became two load / vmcnt(0)
+  // pairs in front of the last super-phase.  Waited for explicitly at the top of the epilogue (same loop iteration).
+  float rsc[4] = {p.scale, p.scale, p.scale, p.scale};
+  if constexpr (RS) {
+    const unsigned roff = (unsigned)(m0 + wm * 128 + l31) * 4u;
+    asm volatile("global_load_dword %0, %1, %2" : "=&v"(rsc[0]) : "v"(roff), "s"(p.rowscale));
+    asm volatile("global_load_dword %0, %1, %2 offset:128" : "=&v"(rsc[1]) : "v"(roff), "s"(p.rowscale));
+    asm volatile("global_load_dword %0, %1, %2 offset:256" : "=&v"(rsc[2]) : "v"(roff), "s"(p.rowscale));
+    asm volatile("global_load_dword %0, %1, %2 offset:384" : "=&v"(rsc[3]) : "v"(roff), "s"(p.rowscale));
+  }
+  __builtin_amdgcn_sched_barrier(0);
   sp(I1{}, No{}, WN{}, t);
   if (grp == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
   __syncthreads();   // every wave is done reading the stages
@@ -776,10 +872,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   const int mbase = m0 + wm * 128, nbase = n0 + wn * 64;
   const int next = tile + gridDim.x;
   if (next < ntiles) { set_tile(next); issue_prologue(); }
+  if constexpr (RS) {
+    // the four row-factor loads are older than the 12 prologue loads just issued (if any): in-order return
+    if (next < ntiles) asm volatile("s_waitcnt vmcnt(12)" : "+v"(rsc[0]), "+v"(rsc[1]), "+v"(rsc[2]), "+v"(rsc[3]) :: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rsc[0]), "+v"(rsc[1]), "+v"(rsc[2]), "+v"(rsc[3]) :: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rsc[i] *= p.scale;
+  }
   // fp32 outputs: 16 rows per pass (16 x 272 B per wave); fp16 outputs fit whole 32-row slabs (32 x 144 B)
   constexpr bool F32OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32;
   constexpr int EROWS = F32OUT ? 16 : 32;
-  gemm_epilogue_staged<EPI, 2, 4, false, EROWS>(p, acc, mbase, nbase, lane, gemm_smem + 114688 + wave * 4608);
+  gemm_epilogue_staged<EPI, 2, 4, false, EROWS>(p, acc, mbase, nbase, lane, gemm_smem + 114688 + wave * 4608, rsc);
   if (next >= ntiles) break;
   tile = next;
   __syncthreads();   // staging rows are read before the next tile's DMA wraps around to W1 | stage 1

@@ -4,8 +4,12 @@
 #include "common.h"
 
 // hf: modeling_t5.py:644,678 (embed_tokens): hidden[t][:] = (fp32) E[ids[t]][:]; no scaling, dropout = identity.
+// Folded-norm form of the encoder (xraw != nullptr): the row also goes out as fp16 x xs (A operand of the first QKV GEMM)
+// with its RMSNorm row factor rsqrt(mean(x^2) + eps) / xs (GemmArgs::rowscale).
 __global__ __launch_bounds__(256) void embed_gather_kernel(const int* __restrict__ ids, const half_t* __restrict__ table,
-                                                           float* __restrict__ out, int n_rows, int d, int vocab) {
+                                                           float* __restrict__ out, int n_rows, int d, int vocab,
+                                                           half_t* __restrict__ xraw, float* __restrict__ rowscale,
+                                                           float xs, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= n_rows) return;
@@ -13,13 +17,41 @@ __global__ __launch_bounds__(256) void embed_gather_kernel(const int* __restrict
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // host validates; clamp keeps a bad id from faulting
   const half_t* src = table + (size_t)id * d;
   float* dst = out + (size_t)row * d;
+  float ss = 0.f;
   for (int c = lane * 8; c < d; c += 64 * 8) {
     const half8 v = *(const half8*)(src + c);
     f32x4 a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
     f32x4 b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
     *(f32x4*)(dst + c) = a;
     *(f32x4*)(dst + c + 4) = b;
+    if (xraw) {
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float x = (float)v[j]; ss += x * x; o[j] = f2h_sat(x * xs); }
+      *(half8*)(xraw + (size_t)row * d + c) = o;
+    }
   }
+  if (xraw) {
+    ss = wave_sum(ss);
+    if (lane == 0) rowscale[row] = rsqrtf(ss / (float)d + eps) / xs;
+  }
+}
+
+// Folded RMSNorm, statistics step: the fp32-residual GEMM epilogue left the sums of squares of every new row per
+// 64-column block in ssq [n_rows, nb] (gemm.h); rowscale[m] = rsqrt(sum_j ssq[m][j] / d + eps) / xs, blocks added in
+// increasing order.  hf: modeling_t5.py:59-72 computes the same fp32 mean of squares.
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ ssq, float* __restrict__ rowscale,
+                                                       int n_rows, int nb, int d, float eps, float xs) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= n_rows) return;
+  const float* src = ssq + (size_t)row * nb;
+  float s = 0.f;
+  if ((nb & 3) == 0) {
+    for (int j = 0; j < nb; j += 4) { const f32x4 v = *(const f32x4*)(src + j); s += v[0]; s += v[1]; s += v[2]; s += v[3]; }
+  } else {
+    for (int j = 0; j < nb; ++j) s += src[j];
+  }
+  rowscale[row] = rsqrtf(s / (float)d + eps) / xs;
 }
 
 // hf: modeling_t5.py:59-72 (T5LayerNorm): y = w * x * rsqrt(mean(x^2) + eps); fp32 statistics, fp16 result

@@ -7,6 +7,8 @@
 //
 // gfx950 only; no CPU fallback, no CUDA/HIP dual paths.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is dlopen'ed on first use (rk_comm_*), never linked
 
 #include <algorithm>
 #include <cmath>
@@ -40,7 +42,10 @@ struct HostTensor {
   std::vector<int64_t> shape;
 };
 
-struct EncLayerW { half_t *qkv = nullptr, *o = nullptr, *ffn_in = nullptr, *ffn_out = nullptr; float *ln0 = nullptr, *ln1 = nullptr; };
+struct EncLayerW {
+  half_t *qkv = nullptr, *o = nullptr, *ffn_in = nullptr, *ffn_out = nullptr; float *ln0 = nullptr, *ln1 = nullptr;
+  half_t *qkv_f = nullptr, *ffn_in_f = nullptr;   // the same with the RMSNorm weight folded into the columns (W[n][k] * ln[k])
+};
 struct DecLayerW {
   half_t *qkv = nullptr, *o = nullptr, *cq = nullptr, *co = nullptr, *ffn_in = nullptr, *ffn_out = nullptr;
   half_t* ckT = nullptr;    // cross-attention W_k regrouped per head and transposed: [H][d_model][64] (direct path)
@@ -61,6 +66,7 @@ struct ProfRec { hipEvent_t a, b; int cls; };
 struct Slot {
   hipStream_t se = nullptr, sd = nullptr;   // this slot's encoder chain (MFMA-bound) | decoder chain (latency-bound)
   float* hidden = nullptr; half_t *xn = nullptr, *qkv = nullptr, *ctx = nullptr, *ffh = nullptr, *enc_out = nullptr;
+  half_t* xraw = nullptr; float *ssq = nullptr, *rowscale = nullptr;   // folded RMSNorm: fp16 stream x RK_XRAW_SCALE, block sums of squares, row factors
   int* d_tokens = nullptr; int* d_seq_off = nullptr;
   int n_seq = 0, T = 0, maxL = 0; bool staged = false; int last_n_out = 0;
   half_t* cross_kv = nullptr;                                  // [n_dec][max_tokens][2I] encoder -> decoder hand-off
@@ -91,12 +97,16 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x1F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1;
+  int opt_glds = 1, opt_skinny = 0x1F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1;
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
   double prof_flops[PC_COUNT] = {0}, prof_bytes[PC_COUNT] = {0}; int64_t prof_n[PC_COUNT] = {0};
+  // score collection across GPUs (K9): one RCCL communicator per engine = per process = per GPU
+  ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;
+  float* d_gather[RK_SLOTS] = {nullptr}; float* h_gather[RK_SLOTS] = {nullptr}; size_t gather_cap = 0;
+  hipEvent_t ev_gather[RK_SLOTS] = {nullptr}; bool gather_pending[RK_SLOTS] = {false}; int gather_n[RK_SLOTS] = {0};
 };
 
 namespace {
@@ -182,16 +192,16 @@ void launch_v2(hipStream_t st, const GemmArgs& a) {
   hipLaunchKernelGGL((gemm_v2_kernel<EPI, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), smem, st, a);
 }
 
-template <int EPI, int KO = 0>
+template <int EPI, int KO = 0, bool RS = false>
 void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
   constexpr int smem = 2 * 4 * 128 * 64 * 2 + 32768;   // 8 half-tile buffers + 32 KiB epilogue staging = all 160 KiB
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void*)gemm_pp2_kernel<EPI, KO>, smem, attr_done);
+  ensure_dynamic_lds((const void*)gemm_pp2_kernel<EPI, KO, RS>, smem, attr_done);
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   // persistent: one workgroup per CU walks the tiles (max_wgs = CUs rounded down to a multiple of 8 keeps the tile -> XCD
   // association); max_wgs <= 0: one workgroup per tile
   const int grid = max_wgs > 0 && tiles > max_wgs ? max_wgs : tiles;
-  hipLaunchKernelGGL((gemm_pp2_kernel<EPI, KO>), dim3(grid), dim3(512), smem, st, a);
+  hipLaunchKernelGGL((gemm_pp2_kernel<EPI, KO, RS>), dim3(grid), dim3(512), smem, st, a);
 }
 
 // Tile-shape choice.  variant: 0 = auto, 1 = 128x128 (v1, two workgroups per CU), 2 = 256x256, 3 = 256x192,
@@ -199,13 +209,13 @@ void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
 // time ~ rounds over the resident slots x the variant's time for one round of K = 1024 (us, MI355X, tools/gemm_bench.py
 // at M = 736 .. 23552, profiles/r01c_gemm_bench.txt, r01e_gemm_pingpong.txt).  All variants sum K in the same order, so
 // the choice never changes a result bit.  GEGLU pairs gate/up inside 64-row wave tiles: no 192-wide tile for it.
-int choose_variant(const rk_engine* e, int epi, int M, int N, int K) {
-  if (e->opt_gemm_variant) return (e->opt_gemm_variant == 3 && epi == EPI_GEGLU_F16) ? 2 : e->opt_gemm_variant;
+int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_producer = false) {
+  if (e->opt_gemm_variant) return (e->opt_gemm_variant == 3 && (epi == EPI_GEGLU_F16 || fold_producer)) ? 2 : e->opt_gemm_variant;
   struct V { int id, bm, bn, slots; double round_us; };
   static const V vs[5] = {{5, 256, 256, 256, 25.5}, {2, 256, 256, 256, 29.8}, {3, 256, 192, 256, 24.7}, {4, 256, 128, 256, 19.0}, {1, 128, 128, 512, 17.3}};
   double best = 1e30; int bv = 1;
   for (const V& v : vs) {
-    if (v.id == 3 && epi == EPI_GEGLU_F16) continue;
+    if (v.id == 3 && (epi == EPI_GEGLU_F16 || fold_producer)) continue;   // (the folded-norm producer needs 64-column wave tiles)
     if (v.id == 5 && K < 128) continue;
     const long tiles = (long)((M + v.bm - 1) / v.bm) * ((N + v.bn - 1) / v.bn);
     const double cost = (double)((tiles + v.slots - 1) / v.slots) * v.round_us;
@@ -216,7 +226,8 @@ int choose_variant(const rk_engine* e, int epi, int M, int N, int K) {
 
 template <int EPI>
 void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
-  int variant = choose_variant(e, EPI, a.M, a.N, a.K);
+  int variant = choose_variant(e, EPI, a.M, a.N, a.K, a.xraw != nullptr);
+#ifdef RK_MEASURE
   if constexpr (EPI == EPI_STORE_F16) {                              // timing-only knock-outs (gemm_variant 80 + mask)
     if (variant > 80 && variant < 88 && a.K >= 128) {
       switch (variant - 80) {
@@ -229,9 +240,17 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
       }
     }
   }
+#endif
   if (variant > 5) variant = 5;
   if (variant == 5 && a.K < 128) variant = 2;                       // the ping-pong kernel needs two K tiles
-  if (variant == 5) { launch_pp2<EPI>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return; }
+  if (variant == 5) {
+    const int wgs = e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7);
+    if constexpr (EPI == EPI_STORE_F16 || EPI == EPI_GEGLU_F16 || EPI == EPI_RELU_F16) {
+      if (a.rowscale) { launch_pp2<EPI, 0, true>(st, a, wgs); return; }   // consumer side of the folded RMSNorm
+    }
+    launch_pp2<EPI>(st, a, wgs);
+    return;
+  }
   if (variant == 2) { launch_v2<EPI, 2, 4, 4, 2>(st, a); return; }
   if (variant == 3 && EPI != EPI_GEGLU_F16) { launch_v2<EPI, 4, 2, 2, 3>(st, a); return; }
   if (variant == 4) { launch_v2<EPI, 4, 2, 2, 2>(st, a); return; }
@@ -243,11 +262,17 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
     hipLaunchKernelGGL((gemm_f16_kernel<EPI, false>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);
 }
 
+// Folded RMSNorm hooks of one GEMM launch (GemmArgs): consumer side = rowscale, producer side = xraw + ssq.
+#define RK_XRAW_SCALE 0.0625f   // the fp16 copy of the fp32 residual stream is stored x 2^-4: head-room for the outlier
+                                // channels of real T5 checkpoints (fp16 max 65504 -> 1.0e6), exact (power of two)
+struct GemmFold { const float* rowscale = nullptr; half_t* xraw = nullptr; float* ssq = nullptr; };
+
 void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int lda, const half_t* W, int ldw, void* C,
           int ldc, int M, int N, int K, int n_split = 0, long split_stride = 0, float scale = 1.f,
-          int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0, bool weight_streaming = false) {
+          int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0, bool weight_streaming = false, GemmFold fold = GemmFold()) {
   if (M <= 0) return;
   GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale, bsA, bsW, bsC};
+  a.rowscale = fold.rowscale; a.xraw = fold.xraw; a.ssq = fold.ssq; a.ldx = N; a.nb = (N + 63) / 64; a.xs = RK_XRAW_SCALE;
   const double flops = 2.0 * M * (double)N * K * batch;
   const double out_elems = (epi == EPI_GEGLU_F16) ? (double)M * N / 2 : (double)M * N;
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
@@ -289,11 +314,19 @@ void rmsnorm(rk_engine* e, hipStream_t st, const float* x, const float* w, half_
   else hipLaunchKernelGGL(rmsnorm_kernel<16>, g, b, 0, st, x, w, out, row_map, rows, dm, e->d.eps, scale);
 }
 
-void embed(rk_engine* e, hipStream_t st, const int* ids, float* out, int rows) {
+void embed(rk_engine* e, hipStream_t st, const int* ids, float* out, int rows, half_t* xraw = nullptr, float* rowscale = nullptr) {
   if (rows <= 0) return;
   Bracket br(e, st, PC_EMBED, 0, (double)rows * e->d.d_model * 6.0);
   hipLaunchKernelGGL(embed_gather_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, ids, e->emb, out, rows,
-                     e->d.d_model, e->d.vocab);
+                     e->d.d_model, e->d.vocab, xraw, rowscale, RK_XRAW_SCALE, e->d.eps);
+}
+
+// folded RMSNorm: block sums of squares (left by the residual GEMM epilogue) -> row factors
+void rowscale(rk_engine* e, hipStream_t st, const float* ssq, float* out, int rows) {
+  if (rows <= 0) return;
+  const int nb = (e->d.d_model + 63) / 64;
+  Bracket br(e, st, PC_NORM, 0, (double)rows * (nb + 1) * 4.0);
+  hipLaunchKernelGGL(rowscale_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, ssq, out, rows, nb, e->d.d_model, e->d.eps, RK_XRAW_SCALE);
 }
 
 // ---- relative position bucket (hf: modeling_t5.py:216-262), float32 like torch ------------------------------
@@ -334,6 +367,11 @@ int set_device(rk_engine* e) {
 int upload_small(rk_engine* e, Slot& sl, hipStream_t st, std::vector<int>* cache, int* dptr, int pin_slot, const int* src, int n) {
   if ((int)cache->size() == n && (n == 0 || memcmp(cache->data(), src, n * sizeof(int)) == 0)) return RK_OK;
   HIPCHK(e, hipStreamSynchronize(st));   // the pinned slot may still be in flight
+  if (n > 8192) {                        // larger than a pinned slot: plain synchronous copy
+    HIPCHK(e, hipMemcpy(dptr, src, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    cache->assign(src, src + n);
+    return RK_OK;
+  }
   int* pin = sl.h_small + pin_slot * 8192;
   memcpy(pin, src, n * sizeof(int));
   HIPCHK(e, hipMemcpyAsync(dptr, pin, n * sizeof(int), hipMemcpyHostToDevice, st));
@@ -344,24 +382,38 @@ int upload_small(rk_engine* e, Slot& sl, hipStream_t st, std::vector<int>* cache
 // ---- forward passes -----------------------------------------------------------------------------------------
 // hf: modeling_t5.py:663-750 (T5Stack.forward, encoder) over the slot's staged ragged batch, then the stacked
 // cross-attention K/V projections of all decoder layers (:325-326 with key_value_states = encoder output).
-#define XA_MAX_ROWS 512     // decoder rows (sequences x positions) the direct cross-attention path handles
-#define XA_MAX_CHUNKS 4096  // rows x 64-key chunks of partial-sum workspace
+#define XA_MAX_ROWS 512     // decoder rows (sequences x positions) per pass of the direct cross-attention path
+#define XA_MAX_CHUNKS 4096  // rows x 64-key chunks of partial-sum workspace per pass
+#define XA_MAX_LD 16        // decoder positions per sequence up to which the query-side form is used
 
-// query-side cross-attention (attention.h) applies when the decoder has at most XA_MAX_ROWS rows in every step
-bool use_xattn_direct(const rk_engine* e, const Slot& sl, int max_ld) {
-  const long rows = (long)sl.n_seq * max_ld;
-  return e->opt_xattn_direct && rows <= XA_MAX_ROWS && rows * ((sl.maxL + 63) / 64) <= XA_MAX_CHUNKS;
+// Query-side cross-attention (attention.h) or materialised K/V: the two round at different points, so the choice must
+// not depend on what else shares the call (a row's logits have to be the same in any batch, on any rank): it is made
+// from the decoder LENGTH of the call alone (the query-side form costs L_d x L x H x d flops per sequence against
+// L x 2I x d for the projections: cheaper up to L_d ~ 64, and far fewer bytes below 16).  More rows than the workspace
+// holds are taken in passes (run_decoder).
+bool use_xattn_direct(const rk_engine* e, const Slot&, int max_ld) {
+  return e->opt_xattn_direct && max_ld <= XA_MAX_LD;
 }
 
 int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
   const rk_model_desc& d = e->d;
   hipStream_t st = enc_stream(e, sl);
   const int T = sl.T, I = e->inner, dm = d.d_model, F = d.d_ff;
-  embed(e, st, sl.d_tokens, sl.hidden, T);
+  // Folded RMSNorm (default): the GEMMs that follow a norm read the un-normalised stream as fp16 (written by the
+  // producer of the stream: embedding / residual epilogue), their weights carry the norm weight, and their epilogue
+  // applies the row factor - the two norm kernels per layer (re-reading the fp32 stream) are gone.
+  const bool fold = e->opt_fold_norm != 0;
+  GemmFold cons, prod;
+  if (fold) { cons.rowscale = sl.rowscale; prod.xraw = sl.xraw; prod.ssq = sl.ssq; }
+  embed(e, st, sl.d_tokens, sl.hidden, T, fold ? sl.xraw : nullptr, fold ? sl.rowscale : nullptr);
   for (int l = 0; l < d.n_enc_layers; ++l) {
     const EncLayerW& w = e->enc[l];
-    rmsnorm(e, st, sl.hidden, w.ln0, sl.xn, nullptr, T);
-    gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xn, dm, w.qkv, dm, sl.qkv, 3 * I, T, 3 * I, dm);
+    if (fold) {
+      gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xraw, dm, w.qkv_f, dm, sl.qkv, 3 * I, T, 3 * I, dm, 0, 0, 1.f, 1, 0, 0, 0, false, cons);
+    } else {
+      rmsnorm(e, st, sl.hidden, w.ln0, sl.xn, nullptr, T);
+      gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xn, dm, w.qkv, dm, sl.qkv, 3 * I, T, 3 * I, dm);
+    }
     {
       // L <= 192: pair kernel - a workgroup runs two heads of a sequence side by side and walks `ppw` head pairs, sized so
       // that the launch has at least one workgroup per CU; the per-(sequence, head) arithmetic does not depend on it.
@@ -387,6 +439,18 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
       }
       else
         hipLaunchKernelGGL(attn_enc_kernel, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
+    }
+    if (fold) {
+      gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, I, w.o, I, sl.hidden, dm, T, dm, I, 0, 0, 1.f, 1, 0, 0, 0, false, prod);
+      rowscale(e, st, sl.ssq, sl.rowscale, T);
+      if (d.gated_gelu)
+        gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_GEGLU_F16, sl.xraw, dm, w.ffn_in_f, dm, sl.ffh, F, T, 2 * F, dm, 0, 0, 1.f, 1, 0, 0, 0, false, cons);
+      else
+        gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_RELU_F16, sl.xraw, dm, w.ffn_in_f, dm, sl.ffh, F, T, F, dm, 0, 0, 1.f, 1, 0, 0, 0, false, cons);
+      const bool last = l + 1 == d.n_enc_layers;   // the final norm reads the fp32 stream itself
+      gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, sl.ffh, F, w.ffn_out, F, sl.hidden, dm, T, dm, F, 0, 0, 1.f, 1, 0, 0, 0, false, last ? GemmFold() : prod);
+      if (!last) rowscale(e, st, sl.ssq, sl.rowscale, T);
+      continue;
     }
     gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, I, w.o, I, sl.hidden, dm, T, dm, I);
     rmsnorm(e, st, sl.hidden, w.ln1, sl.xn, nullptr, T);
@@ -437,18 +501,22 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
       // query-side cross-attention: qk = W_k^T q per head; scores/softmax/weighted sum over the raw encoder states;
       // ctx = W_v (.) per head  (attention.h: XAttnArgs)
       const int H = d.n_heads, nch = (sl.maxL + 63) / 64;
-      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dq, I, w.ckT, 64, sl.xqk, H * dm, M, dm, 64, 0, 0, 1.f, H, 64, (long)dm * 64, dm);
-      XAttnArgs xa{sl.xqk, sl.enc_out, sl.d_seq_off, sl.xpart, sl.xstat, sl.xctx, Ld, H, dm, nch};
-      {
-        Bracket br(e, st, PC_DEC_ATTN, 4.0 * M * (double)sl.maxL * H * dm, (double)sl.T * dm * 2.0 * 2);
-        if ((long)nch * M * ((H + 15) / 16) >= 2 * e->n_cu)
-          hipLaunchKernelGGL(xattn_part_kernel<16>, dim3(nch, M, (H + 15) / 16), dim3(256), 0, st, xa);
-        else
-          hipLaunchKernelGGL(xattn_part_kernel<4>, dim3(nch, M, (H + 3) / 4), dim3(256), 0, st, xa);
-        hipLaunchKernelGGL(xattn_combine_kernel, dim3(H, M), dim3(256), 0, st, xa);
-      }
+      const int blk = std::max(1, std::min(XA_MAX_ROWS, XA_MAX_CHUNKS / nch));
       const half_t* wv = e->cross_kv_w + ((size_t)l * 2 * I + I) * dm;
-      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.xctx, H * dm, wv, dm, sl.dctx, I, M, 64, dm, 0, 0, 1.f, H, dm, (long)64 * dm, 64);
+      for (int r0 = 0; r0 < M; r0 += blk) {
+        const int nr = std::min(blk, M - r0);
+        gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dq + (size_t)r0 * I, I, w.ckT, 64, sl.xqk, H * dm, nr, dm, 64, 0, 0, 1.f, H, 64, (long)dm * 64, dm);
+        XAttnArgs xa{sl.xqk, sl.enc_out, sl.d_seq_off, sl.xpart, sl.xstat, sl.xctx, Ld, H, dm, nch, r0};
+        {
+          Bracket br(e, st, PC_DEC_ATTN, 4.0 * nr * (double)sl.maxL * H * dm, (double)sl.T * dm * 2.0 * 2);
+          if ((long)nch * nr * ((H + 15) / 16) >= 2 * e->n_cu)
+            hipLaunchKernelGGL(xattn_part_kernel<16>, dim3(nch, nr, (H + 15) / 16), dim3(256), 0, st, xa);
+          else
+            hipLaunchKernelGGL(xattn_part_kernel<4>, dim3(nch, nr, (H + 3) / 4), dim3(256), 0, st, xa);
+          hipLaunchKernelGGL(xattn_combine_kernel, dim3(H, nr), dim3(256), 0, st, xa);
+        }
+        gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.xctx, H * dm, wv, dm, sl.dctx + (size_t)r0 * I, I, nr, 64, dm, 0, 0, 1.f, H, dm, (long)64 * dm, 64);
+      }
     } else {
       const half_t* kv = sl.cross_kv + (size_t)l * d.max_tokens * 2 * I;
       AttnDecArgs a{sl.dq, I, kv, kv + I, 2 * I, sl.d_seq_off, sl.dctx, I, nullptr, Ld, 0, sl.maxL};
@@ -578,14 +646,16 @@ int score_slot(rk_engine* e, int slot, const int32_t* dec_prefix, int dec_len, c
   if ((rc = check_ids(e, dec_prefix, dec_len, "decoder")) || (rc = check_ids(e, out_token_ids, n_out, "output"))) return rc;
   hipStream_t sd = dec_stream(e, sl);
   if ((rc = upload_dec_ids_shared(e, sl, dec_prefix, dec_len))) return rc;
-  if ((rc = upload_small(e, sl, sd, &sl.cache_out, sl.d_out_ids, 1, out_token_ids, n_out))) return rc;
+  if ((rc = upload_small(e, sl, sd, &sl.cache_out, sl.d_out_ids, 1, out_token_ids, n_out))) return rc;   // n_out <= 64 (checked)
   std::vector<int> rows(sl.n_seq);
   for (int b = 0; b < sl.n_seq; ++b) rows[b] = b * dec_len + dec_len - 1;
   if ((rc = upload_small(e, sl, sd, &sl.cache_rows, sl.d_last_rows, 2, rows.data(), sl.n_seq))) return rc;
   if ((rc = encoder_then_handoff(e, sl, dec_len))) return rc;
-  static const bool skip_dec = getenv("RK_DEBUG_SKIP_DECODER") != nullptr;   // measurement only: encoder-chain floor
-  static bool warned = false;
-  if (skip_dec && !warned) { fprintf(stderr, "[rk_engine] RK_DEBUG_SKIP_DECODER is set: scores are GARBAGE (encoder-only timing run)\n"); warned = true; }
+#ifdef RK_MEASURE   // measurement builds only (never what build() ships): encoder-chain floor, scores are garbage
+  static const bool skip_dec = getenv("RK_DEBUG_SKIP_DECODER") != nullptr;
+#else
+  constexpr bool skip_dec = false;
+#endif
   if (!skip_dec && (rc = run_decoder(e, sl, dec_len))) return rc;
   rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, sl.n_seq, head_scale(e));
   {
@@ -597,6 +667,47 @@ int score_slot(rk_engine* e, int slot, const int32_t* dec_prefix, int dec_len, c
   HIPCHK(e, hipGetLastError());
   sl.last_n_out = n_out;
   return mark_decoder_done(e, sl);
+}
+
+
+// ---- RCCL, loaded on first use: a 1-GPU process never needs it, and when PyTorch is in the process the SONAME
+// librccl.so.1 resolves to the copy torch already mapped (one RCCL per process, like the HIP runtime) ----------------
+struct RcclApi {
+  void* h = nullptr; bool tried = false; std::string err;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl;
+
+const RcclApi* rccl_api() {
+  if (g_rccl.tried) return g_rccl.h ? &g_rccl : nullptr;
+  g_rccl.tried = true;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (g_rccl.h) break;
+  }
+  if (!g_rccl.h) { g_rccl.err = std::string("dlopen(librccl.so.1) failed: ") + (dlerror() ? dlerror() : "?"); return nullptr; }
+#define RK_SYM(field, sym)                                                              \
+  g_rccl.field = (decltype(g_rccl.field))dlsym(g_rccl.h, sym);                        \
+  if (!g_rccl.field) { g_rccl.err = std::string("librccl lacks ") + sym; dlclose(g_rccl.h); g_rccl.h = nullptr; return nullptr; }
+  RK_SYM(GetUniqueId, "ncclGetUniqueId") RK_SYM(CommInitRank, "ncclCommInitRank") RK_SYM(CommDestroy, "ncclCommDestroy")
+  RK_SYM(AllGather, "ncclAllGather") RK_SYM(GetErrorString, "ncclGetErrorString")
+#undef RK_SYM
+  return &g_rccl;
+}
+
+void comm_release(rk_engine* e) {
+  if (e->comm) { if (const RcclApi* r = rccl_api()) r->CommDestroy(e->comm); e->comm = nullptr; }
+  for (int i = 0; i < RK_SLOTS; ++i) {
+    if (e->d_gather[i]) { hipFree(e->d_gather[i]); e->d_gather[i] = nullptr; }
+    if (e->h_gather[i]) { hipHostFree(e->h_gather[i]); e->h_gather[i] = nullptr; }
+    if (e->ev_gather[i]) { hipEventDestroy(e->ev_gather[i]); e->ev_gather[i] = nullptr; }
+    e->gather_pending[i] = false;
+  }
+  e->gather_cap = 0; e->comm_world = 1; e->comm_rank = 0;
 }
 
 }  // namespace
@@ -667,6 +778,7 @@ void rk_engine_destroy(rk_engine* e) {
     if (sl.se) hipStreamSynchronize(sl.se);
     if (sl.sd) hipStreamSynchronize(sl.sd);
   }
+  comm_release(e);
   for (void* p : e->allocs) hipFree(p);
   if (e->logits) hipFree(e->logits);
   for (auto& sl : e->slots) {
@@ -802,6 +914,16 @@ int rk_engine_finalize(rk_engine* e) {
     RC(up_h(&w.ffn_out, H(p + ".1.DenseReluDense.wo.weight")));
     RC(up_f(&w.ln0, Fv(p + ".0.layer_norm.weight")));
     RC(up_f(&w.ln1, Fv(p + ".1.layer_norm.weight")));
+    // folded RMSNorm: W'[n][k] = fp16(W[n][k] * ln[k])  (the norm weight multiplies the GEMM's input channels)
+    auto folded = [&](const std::vector<half_t>& wm, const std::vector<float>& ln) {
+      std::vector<half_t> v(wm.size());
+      const size_t rows = wm.size() / dm;
+      for (size_t r = 0; r < rows; ++r)
+        for (int k = 0; k < dm; ++k) v[r * dm + k] = (half_t)((float)wm[r * dm + k] * ln[k]);
+      return v;
+    };
+    RC(up_h(&w.qkv_f, folded(cat3(p + ".0.SelfAttention."), Fv(p + ".0.layer_norm.weight"))));
+    RC(up_h(&w.ffn_in_f, folded(ffn_in(p + ".1.DenseReluDense"), Fv(p + ".1.layer_norm.weight"))));
   }
   e->dec.resize(d.n_dec_layers);
   std::vector<half_t> ckv;
@@ -859,6 +981,8 @@ int rk_engine_finalize(rk_engine* e) {
   for (Slot& sl : e->slots) {
     RC(dalloc(e, &sl.hidden, Tc * dm)); RC(dalloc(e, &sl.xn, Tc * dm)); RC(dalloc(e, &sl.qkv, Tc * 3 * I));
     RC(dalloc(e, &sl.ctx, Tc * I)); RC(dalloc(e, &sl.ffh, Tc * F)); RC(dalloc(e, &sl.enc_out, Tc * dm));
+    RC(dalloc(e, &sl.xraw, Tc * dm)); RC(dalloc(e, &sl.ssq, Tc * ((dm + 63) / 64))); RC(dalloc(e, &sl.rowscale, Tc + 512));   // padded: the ping-pong GEMM reads the row factors of a whole 256-row tile
+    HIPCHK(e, hipMemset(sl.rowscale, 0, (Tc + 512) * sizeof(float)));
     RC(dalloc(e, &sl.d_tokens, Tc)); RC(dalloc(e, &sl.d_seq_off, Bc + 1));
     RC(dalloc(e, &sl.cross_kv, (size_t)d.n_dec_layers * Tc * 2 * I));
     RC(dalloc(e, &sl.d_dec_ids, Mc)); RC(dalloc(e, &sl.d_last_rows, Bc)); RC(dalloc(e, &sl.d_out_ids, 8192));
@@ -1024,6 +1148,82 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
   return RK_OK;
 }
 
+// ---- K9: score collection across the GPUs of a node, RCCL over xGMI, straight from the slot's device score buffer --
+int rk_comm_unique_id(uint8_t* out_id, int n_bytes) {
+  if (!out_id || n_bytes != RK_COMM_ID_BYTES) return fail(nullptr, RK_ERR_INVALID, "unique id buffer must be %d bytes", RK_COMM_ID_BYTES);
+  static_assert(RK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "rk_engine.h and rccl.h disagree on the id size");
+  const RcclApi* r = rccl_api();
+  if (!r) return fail(nullptr, RK_ERR_HIP, "%s", g_rccl.err.c_str());
+  ncclUniqueId id;
+  const ncclResult_t rc = r->GetUniqueId(&id);
+  if (rc != ncclSuccess) return fail(nullptr, RK_ERR_HIP, "ncclGetUniqueId: %s", r->GetErrorString(rc));
+  memcpy(out_id, id.internal, RK_COMM_ID_BYTES);
+  return RK_OK;
+}
+
+int rk_comm_init(rk_engine* e, const uint8_t* id_bytes, int n_bytes, int rank, int world, int max_floats_per_rank) {
+  if (!e || !id_bytes || n_bytes != RK_COMM_ID_BYTES) return fail(e, RK_ERR_INVALID, "bad unique id");
+  if (world < 1 || rank < 0 || rank >= world || max_floats_per_rank <= 0) return fail(e, RK_ERR_INVALID, "bad rank %d / world %d / capacity %d", rank, world, max_floats_per_rank);
+  if ((size_t)max_floats_per_rank > e->scores_cap) return fail(e, RK_ERR_CAPACITY, "%d floats per rank exceed the score buffer (%zu)", max_floats_per_rank, e->scores_cap);
+  if (!e->finalized) return fail(e, RK_ERR_STATE, "engine not finalized");
+  int rc = set_device(e);
+  if (rc) return rc;
+  const RcclApi* r = rccl_api();
+  if (!r) return fail(e, RK_ERR_HIP, "%s", g_rccl.err.c_str());
+  comm_release(e);
+  ncclUniqueId id;
+  memcpy(id.internal, id_bytes, RK_COMM_ID_BYTES);
+  const ncclResult_t nrc = r->CommInitRank(&e->comm, world, id, rank);   // collective over all ranks
+  if (nrc != ncclSuccess) { e->comm = nullptr; return fail(e, RK_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, r->GetErrorString(nrc)); }
+  e->comm_rank = rank; e->comm_world = world; e->gather_cap = (size_t)max_floats_per_rank;
+  for (int i = 0; i < RK_SLOTS; ++i) {
+    HIPCHK(e, hipMalloc((void**)&e->d_gather[i], e->gather_cap * world * sizeof(float)));
+    HIPCHK(e, hipHostMalloc((void**)&e->h_gather[i], e->gather_cap * world * sizeof(float), hipHostMallocDefault));
+    HIPCHK(e, hipEventCreateWithFlags(&e->ev_gather[i], hipEventDisableTiming));
+  }
+  return RK_OK;
+}
+
+int rk_comm_world(const rk_engine* e, int* out_rank, int* out_world) {
+  if (!e) return RK_ERR_INVALID;
+  if (out_rank) *out_rank = e->comm ? e->comm_rank : 0;
+  if (out_world) *out_world = e->comm ? e->comm_world : 1;
+  return RK_OK;
+}
+
+int rk_comm_all_gather_slot(rk_engine* e, int slot, int n_floats) {
+  if (!e || slot < 0 || slot >= RK_SLOTS) return RK_ERR_INVALID;
+  if (!e->comm) return fail(e, RK_ERR_STATE, "rk_comm_init has not been called");
+  if (n_floats <= 0 || (size_t)n_floats > e->gather_cap) return fail(e, RK_ERR_CAPACITY, "n_floats %d out of range (capacity %zu)", n_floats, e->gather_cap);
+  int rc = set_device(e);
+  if (rc) return rc;
+  Slot& sl = e->slots[slot];
+  hipStream_t sd = dec_stream(e, sl);   // the stream the slot's scores are produced on: the gather simply follows them
+  if (e->gather_pending[slot]) { HIPCHK(e, hipEventSynchronize(e->ev_gather[slot])); e->gather_pending[slot] = false; }
+  const ncclResult_t nrc = rccl_api()->AllGather(sl.d_scores, e->d_gather[slot], (size_t)n_floats, ncclFloat, e->comm, sd);
+  if (nrc != ncclSuccess) return fail(e, RK_ERR_HIP, "ncclAllGather: %s", rccl_api()->GetErrorString(nrc));
+  HIPCHK(e, hipMemcpyAsync(e->h_gather[slot], e->d_gather[slot], (size_t)n_floats * e->comm_world * sizeof(float), hipMemcpyDeviceToHost, sd));
+  HIPCHK(e, hipEventRecord(e->ev_gather[slot], sd));
+  e->gather_pending[slot] = true; e->gather_n[slot] = n_floats;
+  return mark_decoder_done(e, sl);      // the slot's buffers stay busy until the gather has read them
+}
+
+int rk_comm_read_gathered_slot(rk_engine* e, int slot, float* out, int n_floats_total) {
+  if (!e || !out || slot < 0 || slot >= RK_SLOTS) return RK_ERR_INVALID;
+  if (!e->comm) return fail(e, RK_ERR_STATE, "rk_comm_init has not been called");
+  if (n_floats_total != e->gather_n[slot] * e->comm_world) return fail(e, RK_ERR_INVALID, "asked for %d floats, the last gather of slot %d holds %d", n_floats_total, slot, e->gather_n[slot] * e->comm_world);
+  if (e->gather_pending[slot]) { HIPCHK(e, hipEventSynchronize(e->ev_gather[slot])); e->gather_pending[slot] = false; }
+  memcpy(out, e->h_gather[slot], (size_t)n_floats_total * sizeof(float));
+  return RK_OK;
+}
+
+int rk_comm_destroy(rk_engine* e) {
+  if (!e) return RK_ERR_INVALID;
+  if (set_device(e) == RK_OK) sync_all(e);
+  comm_release(e);
+  return RK_OK;
+}
+
 int rk_timer_begin(rk_engine* e) {
   if (!e) return RK_ERR_INVALID;
   int rc = set_device(e);
@@ -1090,7 +1290,10 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x1F : value; return RK_OK; }   // bit per epilogue kind
   if (!strcmp(key, "gemm_persistent")) { e->opt_gemm_persistent = value; return RK_OK; }   // ping-pong GEMM: 1 = one workgroup per CU walks the tiles
+  if (!strcmp(key, "fold_norm")) { e->opt_fold_norm = value != 0; return RK_OK; }           // encoder RMSNorm folded into the GEMMs (1) or separate kernels (0)
+#ifdef RK_MEASURE
   if (!strcmp(key, "attn_ko")) { e->opt_attn_ko = value; return RK_OK; }   // timing-only knock-outs, see AttnEncArgs
+#endif
   if (!strcmp(key, "attn_heads_per_wg")) { e->opt_attn_heads_per_wg = value; return RK_OK; }   // 0 auto
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
   if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 1 pair kernel, 2 one-head kernel, 0 tiled

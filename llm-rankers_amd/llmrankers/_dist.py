@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import List, Sequence, Tuple
 
+import os
+
 import numpy as np
 
 
@@ -47,14 +49,33 @@ def all_gather_scores(local: np.ndarray, n_items: int, device=None) -> np.ndarra
         return np.asarray(local, dtype=np.float32)
     bounds = shard_bounds(n_items, ws)
     width = max(e - s for s, e in bounds)
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    if device is None:   # NCCL buffers live on this rank's GPU (LOCAL_RANK), whatever torch's current device is
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0") or 0)) if dist.get_backend() == "nccl" else torch.device("cpu")
     buf = torch.zeros(width, dtype=torch.float32, device=device)
     buf[:len(local)] = torch.as_tensor(np.asarray(local, dtype=np.float32), device=device)
     out = torch.empty(ws * width, dtype=torch.float32, device=device)
     dist.all_gather_into_tensor(out, buf)
     out = out.cpu().numpy().reshape(ws, width)
     return np.concatenate([out[r, :e - s] for r, (s, e) in enumerate(bounds)])
+
+
+def all_gather_flat(local: np.ndarray, width: int) -> np.ndarray:
+    """[world, width] float32: every rank's `local` (<= width values, zero padded) through ONE torch.distributed
+    all_gather on the process group's own backend — the host-side path used when the runtime has no engine-owned
+    RCCL communicator (CPU tests on gloo; a GPU run goes through rk_comm_all_gather_slot instead)."""
+    import torch
+    import torch.distributed as dist
+    rank, ws = world()
+    local = np.asarray(local, dtype=np.float32).reshape(-1)
+    if dist.get_backend() == "nccl":
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0") or 0))
+    else:
+        device = torch.device("cpu")
+    buf = torch.zeros(width, dtype=torch.float32, device=device)
+    buf[:len(local)] = torch.as_tensor(local, device=device)
+    out = torch.empty(ws * width, dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(out, buf)
+    return out.cpu().numpy().reshape(ws, width)
 
 
 def sharded_scores(score_fn, items: Sequence, device=None) -> np.ndarray:

@@ -51,6 +51,12 @@ ABI = {
     "rk_t5_read_scores_slot": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.c_int]),
     "rk_t5_read_scores": (C.c_int, [C.c_void_p, _f32p, C.c_int]),
     "rk_t5_scores_device_ptr": (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
+    "rk_comm_unique_id": (C.c_int, [_P(C.c_uint8), C.c_int]),
+    "rk_comm_init": (C.c_int, [C.c_void_p, _P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rk_comm_world": (C.c_int, [C.c_void_p, _i32p, _i32p]),
+    "rk_comm_all_gather_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rk_comm_read_gathered_slot": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.c_int]),
+    "rk_comm_destroy": (C.c_int, [C.c_void_p]),
     "rk_timer_begin": (C.c_int, [C.c_void_p]),
     "rk_timer_end": (C.c_int, [C.c_void_p, _f32p]),
     "rk_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -129,6 +135,7 @@ class RkEngine:
             raise RkError(rc, (self.lib.rk_last_error(None) or b"").decode())
         self.h = h
         self.device = device
+        self.comm_rank, self.comm_world = 0, 1
 
     # -- plumbing ------------------------------------------------------------------------------------
     def _chk(self, rc: int):
@@ -225,6 +232,40 @@ class RkEngine:
         p = C.c_void_p()
         self._chk(self.lib.rk_t5_scores_device_ptr(self.h, C.byref(p)))
         return int(p.value)
+
+    # -- multi-GPU score collection (RCCL inside the engine) -----------------------------------------------
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self) -> bytes:
+        """rank 0: the 128-byte RCCL id every rank needs for comm_init (ship it with any host-side channel)."""
+        buf = (C.c_uint8 * self.COMM_ID_BYTES)()
+        rc = self.lib.rk_comm_unique_id(buf, self.COMM_ID_BYTES)
+        if rc != 0:
+            raise RkError(rc, (self.lib.rk_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int, max_floats_per_rank: int):
+        """Collective over all ranks (one engine = one process = one GPU)."""
+        buf = (C.c_uint8 * self.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._chk(self.lib.rk_comm_init(self.h, buf, self.COMM_ID_BYTES, rank, world, max_floats_per_rank))
+        self.comm_rank, self.comm_world = rank, world
+
+    def comm_all_gather(self, n_floats: int, slot: int = 0):
+        """Enqueue ONE RCCL all_gather of the slot's device score buffer behind the work that fills it (no sync)."""
+        self._chk(self.lib.rk_comm_all_gather_slot(self.h, slot, n_floats))
+        self._gather_n = getattr(self, "_gather_n", {})
+        self._gather_n[slot] = n_floats
+
+    def comm_read_gathered(self, slot: int = 0) -> np.ndarray:
+        """[world, n_floats] float32 of the slot's last gather (waits for it)."""
+        n = self._gather_n[slot]
+        out = np.empty((self.comm_world, n), dtype=np.float32)
+        self._chk(self.lib.rk_comm_read_gathered_slot(self.h, slot, out.ctypes.data_as(_f32p), out.size))
+        return out
+
+    def comm_destroy(self):
+        self._chk(self.lib.rk_comm_destroy(self.h))
+        self.comm_world = 1
 
     # -- measurement -------------------------------------------------------------------------------------
     def timer_begin(self):

@@ -25,18 +25,36 @@ def parse_device(device) -> int:
     if s == "cpu":
         raise RuntimeError("the MI355X engine has no CPU path (device='cpu'); use the HuggingFace reference for CPU runs")
     if s in ("cuda", "hip", "gpu"):
-        return int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("RK_DEVICE_FROM_LOCAL_RANK") else 0
+        # one process per GPU under torchrun: 'cuda' means "this rank's GPU" (LOCAL_RANK), ordinal 0 otherwise
+        return int(os.environ.get("LOCAL_RANK", "0") or 0)
     for pre in ("cuda:", "hip:"):
         if s.startswith(pre):
             return int(s[len(pre):])
     raise ValueError(f"unrecognised device {device!r}")
 
 
+def resolve_checkpoint(model_name_or_path: str, cache_dir=None) -> str:
+    """A local HuggingFace-layout directory, or a hub id ('google/flan-t5-large', as the reference's README and
+    run.py use) resolved through huggingface_hub's cache (downloading when the machine is online) — the same lookup
+    from_pretrained does (ref: pointwise.py:15-24)."""
+    if os.path.isdir(model_name_or_path):
+        return model_name_or_path
+    try:
+        from huggingface_hub import snapshot_download
+        patterns = ["config.json", "*.safetensors", "*.safetensors.index.json", "pytorch_model*.bin", "pytorch_model.bin.index.json"]
+        try:
+            return snapshot_download(model_name_or_path, cache_dir=cache_dir, allow_patterns=patterns, local_files_only=True)
+        except Exception:
+            return snapshot_download(model_name_or_path, cache_dir=cache_dir, allow_patterns=patterns)
+    except Exception as exc:
+        raise FileNotFoundError(
+            f"{model_name_or_path!r} is neither a local checkpoint directory nor a hub model reachable from here ({exc})") from None
+
+
 def read_config(model_dir: str) -> dict:
     path = os.path.join(model_dir, "config.json")
     if not os.path.exists(path):
-        raise FileNotFoundError(
-            f"{path} not found: the engine loads local HuggingFace-layout checkpoints (no network in this build)")
+        raise FileNotFoundError(f"{path} not found: not a HuggingFace-layout checkpoint directory")
     with open(path) as f:
         return json.load(f)
 
@@ -51,7 +69,8 @@ def iter_checkpoint_tensors(model_dir: str) -> Iterator[Tuple[str, np.ndarray]]:
     elif os.path.exists(os.path.join(model_dir, "model.safetensors")):
         files = ["model.safetensors"]
     else:
-        raise FileNotFoundError(f"no model.safetensors[.index.json] in {model_dir} (pytorch_model.bin is not supported)")
+        yield from _iter_torch_bin(model_dir)
+        return
     for fn in files:
         path = os.path.join(model_dir, fn)
         try:
@@ -70,11 +89,34 @@ def iter_checkpoint_tensors(model_dir: str) -> Iterator[Tuple[str, np.ndarray]]:
                         yield k, t.float().numpy()
 
 
+def _iter_torch_bin(model_dir: str) -> Iterator[Tuple[str, np.ndarray]]:
+    """pytorch_model.bin checkpoints (e.g. castorini/monot5-*): read with torch.load — loader plumbing only."""
+    import torch
+    idx = os.path.join(model_dir, "pytorch_model.bin.index.json")
+    if os.path.exists(idx):
+        with open(idx) as f:
+            files = sorted(set(json.load(f)["weight_map"].values()))
+    elif os.path.exists(os.path.join(model_dir, "pytorch_model.bin")):
+        files = ["pytorch_model.bin"]
+    else:
+        raise FileNotFoundError(f"no model.safetensors[.index.json] or pytorch_model.bin[.index.json] in {model_dir}")
+    for fn in files:
+        sd = torch.load(os.path.join(model_dir, fn), map_location="cpu", weights_only=True)
+        for k, t in sd.items():
+            if t.dtype == torch.bfloat16:
+                yield k, t.contiguous().view(torch.int16).numpy().view(np.uint16)
+            elif t.dtype == torch.float16:
+                yield k, t.numpy()
+            else:
+                yield k, t.float().numpy()
+
+
 class T5Runtime:
     """Engine + chunking so a call may exceed the engine's token capacity (results are batch-independent)."""
 
     def __init__(self, model_name_or_path: str, device, max_tokens: int = 49152, max_seqs: int = 256,
-                 max_dec_len: int = 136):
+                 max_dec_len: int = 136, cache_dir=None):
+        model_name_or_path = resolve_checkpoint(model_name_or_path, cache_dir)
         cfg = read_config(model_name_or_path)
         self.model_type = cfg.get("model_type")
         if self.model_type != "t5":
@@ -85,6 +127,34 @@ class T5Runtime:
         self.max_tokens, self.max_seqs = max_tokens, max_seqs
         self.engine = RkEngine(self.dims, parse_device(device), max_tokens, max_seqs, max_dec_len)
         self.engine.load_state(iter_checkpoint_tensors(model_name_or_path))
+
+    @classmethod
+    def from_engine(cls, engine: RkEngine, dims=None) -> "T5Runtime":
+        """Wrap an engine that is already loaded (bench.py, tools/): no checkpoint directory involved."""
+        self = cls.__new__(cls)
+        self.dims = dims if dims is not None else engine.dims
+        self.config, self.model_type, self.decoder_start_token_id = self.dims.to_hf_config(), "t5", 0
+        self.max_tokens, self.max_seqs = int(engine.desc.max_tokens), int(engine.desc.max_seqs)
+        self.engine = engine
+        return self
+
+    # -- multi-GPU: scores are collected by the engine's own RCCL communicator (rk_comm_*) --------------------
+    def comm_ready(self) -> bool:
+        return getattr(self.engine, "comm_world", 1) > 1
+
+    def comm_init_from_process_group(self, max_floats_per_rank: int = 4096):
+        """One process per GPU under torchrun: take rank / world from the initialised torch.distributed group, use it
+        ONLY to hand rank 0's RCCL id to the other ranks, and build the engine's communicator."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ids = [self.engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        self.engine.comm_init(ids[0], rank, world, max_floats_per_rank)
+
+    def all_gather_last_scores(self, n_floats: int) -> np.ndarray:
+        """[world, n_floats]: the first n_floats of slot 0's device score buffer of every rank (one RCCL all_gather)."""
+        self.engine.comm_all_gather(n_floats, slot=0)
+        return self.engine.comm_read_gathered(0)
 
     def _chunks(self, seqs: Sequence[Sequence[int]]) -> Iterator[List[Sequence[int]]]:
         cur, tok = [], 0

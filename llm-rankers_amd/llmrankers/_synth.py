@@ -92,10 +92,13 @@ FLAN_T5_XL = T5Dims(vocab=32128, d_model=2048, n_heads=32, d_kv=64, d_ff=5120, n
 TOY_GATED_UNTIED = T5Dims(vocab=256, d_model=128, n_heads=3, d_kv=64, d_ff=256, n_enc=2, n_dec=2)
 TOY_RELU_TIED = T5Dims(vocab=256, d_model=128, n_heads=3, d_kv=64, d_ff=256, n_enc=2, n_dec=2,
                        gated=False, tied_head=True)
+# monoT5-like (T5 v1.0: relu, tied + scaled head) with a vocabulary that covers the fixed 'true' / 'false' token ids
+# 1176 / 6136 the reference hard-codes (ref: llmrankers/pointwise.py:177-178)
+TOY_MONOT5 = T5Dims(vocab=6144, d_model=128, n_heads=3, d_kv=64, d_ff=256, n_enc=2, n_dec=2, gated=False, tied_head=True)
 
 NAMED_DIMS = {
     "flan-t5-small": FLAN_T5_SMALL, "flan-t5-base": FLAN_T5_BASE, "flan-t5-large": FLAN_T5_LARGE,
-    "flan-t5-xl": FLAN_T5_XL, "toy-gated-untied": TOY_GATED_UNTIED, "toy-relu-tied": TOY_RELU_TIED,
+    "flan-t5-xl": FLAN_T5_XL, "toy-gated-untied": TOY_GATED_UNTIED, "toy-relu-tied": TOY_RELU_TIED, "toy-monot5": TOY_MONOT5,
 }
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)

@@ -29,19 +29,27 @@ def _softmax_first(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 class PointwiseLlmRanker(LlmRanker):
 
     def __init__(self, model_name_or_path, tokenizer_name_or_path, device, method="qlm", batch_size=1, cache_dir=None,
-                 _runtime=None, _tokenizer=None, shard_candidates=False):
-        # ref: pointwise.py:13-34.  `_runtime` / `_tokenizer` are test seams; production builds the HIP engine.
-        if _tokenizer is None:
-            from transformers import T5Tokenizer
-            _tokenizer = T5Tokenizer.from_pretrained(
-                tokenizer_name_or_path if tokenizer_name_or_path is not None else model_name_or_path,
-                cache_dir=cache_dir)
-        self.tokenizer = _tokenizer
-        if _runtime is None:
-            from ._runtime import T5Runtime
-            _runtime = T5Runtime(model_name_or_path, device)   # raises NotImplementedError for non-T5 models
-        self.llm = _runtime
-        self.config = getattr(_runtime, "config", None)
+                 shard_candidates=False):
+        # ref: pointwise.py:13-34: tokenizer + model from the checkpoint; here the model is the HIP engine
+        from transformers import T5Tokenizer
+        from ._runtime import T5Runtime
+        tokenizer = T5Tokenizer.from_pretrained(
+            tokenizer_name_or_path if tokenizer_name_or_path is not None else model_name_or_path, cache_dir=cache_dir)
+        runtime = T5Runtime(model_name_or_path, device, cache_dir=cache_dir)   # NotImplementedError for non-T5 models
+        self._setup(runtime, tokenizer, device, method, batch_size, shard_candidates)
+
+    @classmethod
+    def from_runtime(cls, runtime, tokenizer, device="cuda", method="qlm", batch_size=1, shard_candidates=False):
+        """Build the ranker around an existing runtime (an engine that is already loaded, or a test double) and
+        tokenizer instead of loading a checkpoint: several rankers can share one engine."""
+        self = cls.__new__(cls)
+        self._setup(runtime, tokenizer, device, method, batch_size, shard_candidates)
+        return self
+
+    def _setup(self, runtime, tokenizer, device, method, batch_size, shard_candidates):
+        self.tokenizer = tokenizer
+        self.llm = runtime
+        self.config = getattr(runtime, "config", None)
         self.device = device
         self.method = method
         self.batch_size = batch_size
@@ -58,39 +66,76 @@ class PointwiseLlmRanker(LlmRanker):
         self.total_completion_tokens = 0
         self.total_prompt_tokens = 0
 
-    def _scored_batches(self, prompts: List[str], dec_len: int):
-        """Yield (start, token lists) per batch while keeping the reference's counters."""
+    # -- what a method scores: prompts, the engine call shape, and how raw engine output becomes a score ---------
+    def _spec(self, query: str, docs: List[SearchResult]):
+        """-> (prompts, kind, arg, out_ids, dec_len, finish) or None for a method the reference ignores.
+        kind 'score': arg = decoder prefix, raw = logits [n, len(out_ids)];  kind 'qlm': arg = labels, raw = [n]."""
+        if self.method == "qlm":
+            # ref: pointwise.py:41-82 — score = -sum_t CE(label_t), labels = "<pad> {query}" without specials
+            labels = self.tokenizer.encode(f"<pad> {query}", add_special_tokens=False)
+            prompts = [QLM_PROMPT.format(text=doc.text) for doc in docs]
+            return prompts, "qlm", labels, None, len(labels), lambda raw: np.asarray(raw, dtype=np.float32).reshape(-1)
+        if self.method == "yes_no":
+            # ref: pointwise.py:84-127 — score = softmax([logit_yes, logit_no])[0] at the first decoder step
+            yes_id = self.tokenizer.encode("Yes", add_special_tokens=False)[0]
+            no_id = self.tokenizer.encode("No", add_special_tokens=False)[0]
+            prompts = [YES_NO_PROMPT.format(text=doc.text, query=query) for doc in docs]
+            return prompts, "score", [self.tokenizer.pad_token_id], [yes_id, no_id], 1, \
+                lambda raw: _softmax_first(raw[:, 0], raw[:, 1])
+        return None   # any other method: the reference silently leaves the scores untouched and still sorts (ref :129)
+
+    def _counted_batches(self, prompts: List[str], dec_len: int):
+        """Tokenise once, cut into the reference's batches and keep its counters (ref: pointwise.py:105-114)."""
         seqs = tokenize_prompts(self.tokenizer, prompts)
+        out = []
         for s, e in batches(len(seqs), self.batch_size):
             chunk = seqs[s:e]
             self.total_compare += 1
             self.total_prompt_tokens += padded_token_count(chunk)
             self.total_prompt_tokens += len(chunk) * dec_len     # decoder inputs count as prompt (ref :68,114)
-            yield s, chunk
+            out.append(chunk)
+        return out
+
+    def _raw(self, chunks, kind, arg, out_ids):
+        """Raw engine output for all batches of one query, concatenated in passage order."""
+        if not chunks:
+            return np.zeros((0, len(out_ids)) if kind == "score" else (0,), np.float32)
+        if kind == "qlm":
+            return np.concatenate([np.asarray(self.llm.qlm(c, arg), dtype=np.float32) for c in chunks])
+        if hasattr(self.llm, "score_batches"):                   # pipelined across the engine's batch slots
+            return np.concatenate(self.llm.score_batches(chunks, arg, out_ids), axis=0)
+        return np.concatenate([self.llm.score(c, arg, out_ids) for c in chunks], axis=0)
 
     def _rerank_sharded(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
+        """One process per GPU: this rank scores its contiguous chunk of the candidates, ONE all_gather collects the
+        raw engine outputs of all ranks (engine-owned RCCL when the runtime has a communicator, torch.distributed
+        otherwise - the CPU tests), every rank finishes and sorts identically."""
         from . import _dist
-
-        def score_chunk(chunk):
-            if not len(chunk):
-                return []
-            saved, self.shard_candidates = self.shard_candidates, False
-            try:
-                self.rerank(query, list(chunk))          # mutates the chunk's objects in place
-            finally:
-                self.shard_candidates = saved
-            return [d.score for d in chunk]
-
-        scores = _dist.sharded_scores(score_chunk, ranking)
+        rank, ws = _dist.world()
+        bounds = _dist.shard_bounds(len(ranking), ws)
+        s, e = bounds[rank]
+        width = max(b - a for a, b in bounds)
+        self._reset()
+        spec = self._spec(query, ranking[s:e])
+        if spec is None:
+            return sorted(ranking, key=lambda x: x.score, reverse=True)
+        prompts, kind, arg, out_ids, dec_len, finish = spec
+        chunks = self._counted_batches(prompts, dec_len)
+        k = len(out_ids) if kind == "score" else 1
+        if getattr(self.llm, "comm_ready", lambda: False)():
+            if e > s:                                            # the local chunk in ONE engine call on slot 0 ...
+                flat = [q for c in chunks for q in c]
+                local = self.llm.qlm(flat, arg) if kind == "qlm" else self.llm.score(flat, arg, out_ids)
+                assert len(local) == e - s
+            allv = self.llm.all_gather_last_scores(width * k).reshape(ws, width * k)   # ... gathered from its device buffer
+        else:
+            local = self._raw(chunks, kind, arg, out_ids).reshape(-1)
+            allv = _dist.all_gather_flat(local, width * k)
+        raw = np.concatenate([allv[r, :(b - a) * k] for r, (a, b) in enumerate(bounds)])
+        scores = finish(raw.reshape(-1, k) if kind == "score" else raw)
         for doc, sc in zip(ranking, scores):
             doc.score = float(sc)
         return sorted(ranking, key=lambda x: x.score, reverse=True)
-
-    def _score_all(self, chunks, dec, out_ids):
-        """All batches of one query through the engine; pipelined across its batch slots when the runtime can."""
-        if hasattr(self.llm, "score_batches"):
-            return self.llm.score_batches(chunks, dec, out_ids)
-        return [self.llm.score(c, dec, out_ids) for c in chunks]
 
     def rerank(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
         if self.shard_candidates:
@@ -98,26 +143,12 @@ class PointwiseLlmRanker(LlmRanker):
             if _dist.world()[1] > 1:
                 return self._rerank_sharded(query, ranking)
         self._reset()
-        if self.method == "qlm":
-            # ref: pointwise.py:41-82 — score = -sum_t CE(label_t), labels = "<pad> {query}" without specials
-            labels = self.tokenizer.encode(f"<pad> {query}", add_special_tokens=False)
-            prompts = [QLM_PROMPT.format(text=doc.text) for doc in ranking]
-            for s, chunk in self._scored_batches(prompts, len(labels)):
-                scores = self.llm.qlm(chunk, labels)
-                for i, sc in enumerate(scores):
-                    ranking[s + i].score = float(sc)
-        elif self.method == "yes_no":
-            # ref: pointwise.py:84-127 — score = softmax([logit_yes, logit_no])[0] at the first decoder step
-            yes_id = self.tokenizer.encode("Yes", add_special_tokens=False)[0]
-            no_id = self.tokenizer.encode("No", add_special_tokens=False)[0]
-            prompts = [YES_NO_PROMPT.format(text=doc.text, query=query) for doc in ranking]
-            dec = [self.tokenizer.pad_token_id]
-            todo = list(self._scored_batches(prompts, 1))
-            for (s, chunk), lg in zip(todo, self._score_all([c for _, c in todo], dec, [yes_id, no_id])):
-                p_yes = _softmax_first(lg[:, 0], lg[:, 1])
-                for i, sc in enumerate(p_yes):
-                    ranking[s + i].score = float(sc)
-        # any other method: the reference silently leaves the scores untouched and still sorts (ref :129)
+        spec = self._spec(query, ranking)
+        if spec is not None:
+            prompts, kind, arg, out_ids, dec_len, finish = spec
+            raw = self._raw(self._counted_batches(prompts, dec_len), kind, arg, out_ids)
+            for doc, sc in zip(ranking, finish(raw)):
+                doc.score = float(sc)
         return sorted(ranking, key=lambda x: x.score, reverse=True)
 
     def truncate(self, text, length):
@@ -125,16 +156,11 @@ class PointwiseLlmRanker(LlmRanker):
 
 
 class MonoT5LlmRanker(PointwiseLlmRanker):
-    """ref: pointwise.py:136-186 — softmax over the fixed ids of 'false'/'true', decoder start token as input."""
+    """ref: pointwise.py:136-186 — softmax over the fixed ids of 'false'/'true', decoder start token as input;
+    the reference's rerank ignores `method`."""
     FALSE_ID, TRUE_ID = 6136, 1176
 
-    def rerank(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
-        self._reset()
-        prompts = [MONOT5_PROMPT.format(query=query, document=doc.text) for doc in ranking]
-        dec = [self.llm.decoder_start_token_id]
-        todo = list(self._scored_batches(prompts, 1))
-        for (s, chunk), lg in zip(todo, self._score_all([c for _, c in todo], dec, [self.FALSE_ID, self.TRUE_ID])):
-            p_true = _softmax_first(lg[:, 1], lg[:, 0])
-            for i, sc in enumerate(p_true):
-                ranking[s + i].score = float(sc)
-        return sorted(ranking, key=lambda x: x.score, reverse=True)
+    def _spec(self, query: str, docs: List[SearchResult]):
+        prompts = [MONOT5_PROMPT.format(query=query, document=doc.text) for doc in docs]
+        return prompts, "score", [self.llm.decoder_start_token_id], [self.FALSE_ID, self.TRUE_ID], 1, \
+            lambda raw: _softmax_first(raw[:, 1], raw[:, 0])

@@ -29,25 +29,34 @@ class SetwiseLlmRanker(LlmRanker):
                   "M", "N", "O", "P", "Q", "R", "S", "T", "U", "V", "W"]
 
     def __init__(self, model_name_or_path, tokenizer_name_or_path, device, num_child=3, k=10, scoring='generation',
-                 method="heapsort", num_permutation=1, cache_dir=None, _runtime=None, _tokenizer=None):
+                 method="heapsort", num_permutation=1, cache_dir=None):
+        # ref: setwise.py:25-77
+        from transformers import T5Tokenizer
+        from ._runtime import T5Runtime
+        try:
+            runtime = T5Runtime(model_name_or_path, device, cache_dir=cache_dir)
+        except NotImplementedError as exc:   # same message shape as ref: setwise.py:71
+            raise NotImplementedError(f"{exc} (setwise)") from None
+        tokenizer = T5Tokenizer.from_pretrained(
+            tokenizer_name_or_path if tokenizer_name_or_path is not None else model_name_or_path, cache_dir=cache_dir)
+        self._setup(runtime, tokenizer, device, num_child, k, scoring, method, num_permutation)
+
+    @classmethod
+    def from_runtime(cls, runtime, tokenizer, device="cuda", num_child=3, k=10, scoring='generation', method="heapsort",
+                     num_permutation=1):
+        """Build the ranker around an existing runtime (a loaded engine, or a test double) and tokenizer."""
+        self = cls.__new__(cls)
+        self._setup(runtime, tokenizer, device, num_child, k, scoring, method, num_permutation)
+        return self
+
+    def _setup(self, runtime, tokenizer, device, num_child, k, scoring, method, num_permutation):
         self.device = device
         self.num_child = num_child
         self.num_permutation = num_permutation
         self.k = k
-        if _runtime is None:
-            from ._runtime import T5Runtime
-            try:
-                _runtime = T5Runtime(model_name_or_path, device)
-            except NotImplementedError as exc:   # same message shape as ref: setwise.py:71
-                raise NotImplementedError(f"{exc} (setwise)") from None
-        self.llm = _runtime
-        self.config = getattr(_runtime, "config", None)
-        if _tokenizer is None:
-            from transformers import T5Tokenizer
-            _tokenizer = T5Tokenizer.from_pretrained(
-                tokenizer_name_or_path if tokenizer_name_or_path is not None else model_name_or_path,
-                cache_dir=cache_dir)
-        self.tokenizer = _tokenizer
+        self.llm = runtime
+        self.config = getattr(runtime, "config", None)
+        self.tokenizer = tokenizer
         # decoder prompt "<pad> Passage" and the last token of "<pad> Passage {label}" (ref: setwise.py:51-59)
         self.decoder_input_ids = self.tokenizer.encode("<pad> Passage", add_special_tokens=False)
         self.target_token_ids = [self.tokenizer.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1]

@@ -41,9 +41,7 @@ def test_trec_round_trip_with_file_sources(runmod, tmp_path, ckpt_dirs, monkeypa
     ck = ckpt_dirs["ckpt_gated_untied"]
     dims, state = load_state(ck)
     tok = T5Tokenizer.from_pretrained(ck)
-    monkeypatch.setattr(runmod, "build_ranker", lambda args: PointwiseLlmRanker(
-        None, None, "cuda", method=args.pointwise.method, batch_size=args.pointwise.batch_size,
-        _runtime=OracleRuntime(dims, state), _tokenizer=tok))
+    monkeypatch.setattr(runmod, "build_ranker", lambda args: PointwiseLlmRanker.from_runtime(OracleRuntime(dims, state), tok, method=args.pointwise.method, batch_size=args.pointwise.batch_size))
     (tmp_path / "q.tsv").write_text("q1\tneural ranking model\nq2\twater river mountain\n")
     (tmp_path / "d.jsonl").write_text("\n".join(
         '{"docid": "d%d", "title": "topic", "text": "%s"}' % (i, w) for i, w in enumerate(

@@ -40,8 +40,7 @@ ck = sys.argv[5]
 dims, state = load_state(ck)
 case = json.load(open(sys.argv[6]))
 tok = T5Tokenizer.from_pretrained(ck)
-rk = PointwiseLlmRanker(None, None, "cuda", method=case["method"], batch_size=case["batch_size"],
-                        _runtime=OracleRuntime(dims, state), _tokenizer=tok, shard_candidates=True)
+rk = PointwiseLlmRanker.from_runtime(OracleRuntime(dims, state), tok, method=case["method"], batch_size=case["batch_size"], shard_candidates=True)
 ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
 res = rk.rerank(case["query"], ranking)
 print("RESULT " + json.dumps([[r.docid, r.score] for r in res]))

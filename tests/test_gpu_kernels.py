@@ -312,3 +312,133 @@ def test_qlm_flan_t5_small_vs_oracle():
     assert np.abs(got - want).max() / np.abs(want).max() < 5e-4
     np.testing.assert_array_equal(np.argsort(-got), np.argsort(-want))
     eng.close()
+
+
+def test_folded_rmsnorm_matches_separate_norm_kernels(toy):
+    """Default encoder path: the two RMSNorms of a layer are folded into the GEMMs (un-normalised fp16 stream as A,
+    norm weight in the GEMM weight, row factor in the epilogue).  It must agree with the separate-kernel path to well
+    inside the score tolerance, be as close to the fp32 oracle, and not depend on the GEMM tile shape."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle
+    dims, state, eng = toy["ckpt_gated_untied"]
+    seqs = _synth.synth_token_batch(9, 3, 190, dims.vocab, seed=77)
+    ids = [11, 12, 13, 14]
+    want = T5Oracle(dims, state).score_last(seqs, [0], ids)
+    try:
+        eng.set_option("fold_norm", 0)
+        plain = eng.score(seqs, [0], ids)
+        eng.set_option("fold_norm", 1)
+        fold = eng.score(seqs, [0], ids)
+        for v in (1, 2, 3, 4, 5):
+            eng.set_option("gemm_variant", v)
+            np.testing.assert_array_equal(eng.score(seqs, [0], ids), fold, err_msg=f"tile variant {v}")
+    finally:
+        eng.set_option("gemm_variant", 0)
+        eng.set_option("fold_norm", 1)
+    assert np.abs(fold - plain).max() < 5e-3, np.abs(fold - plain).max()
+    assert np.abs(fold - want).max() < LOGIT_TOL and np.abs(plain - want).max() < LOGIT_TOL
+    assert np.abs(_sigm(fold[:, 0] - fold[:, 1]) - _sigm(want[:, 0] - want[:, 1])).max() < SCORE_TOL
+    np.testing.assert_array_equal(eng.score(seqs[2:5], [0], ids), fold[2:5])       # batch independence holds for the folded path
+
+
+def test_comm_single_rank_gather_equals_local_scores(toy):
+    """rk_comm_*: RCCL communicator of ONE rank on this GPU; the all_gather of the slot's device score buffer returns
+    exactly what rk_t5_read_scores returns (the N > 1 path differs only in the number of ranks)."""
+    from llmrankers import _synth
+    dims, state, eng = toy["ckpt_gated_untied"]
+    seqs = _synth.synth_token_batch(7, 4, 60, dims.vocab, seed=5)
+    want = eng.score(seqs, [0], [21, 22])
+    eng.comm_init(eng.comm_unique_id(), 0, 1, 64)
+    try:
+        eng.stage(seqs, slot=1)
+        eng.score_staged([0], [21, 22], slot=1)
+        eng.comm_all_gather(7 * 2, slot=1)
+        got = eng.comm_read_gathered(1)
+        assert got.shape == (1, 14)
+        np.testing.assert_array_equal(got.reshape(7, 2), want)
+        np.testing.assert_array_equal(eng.read_scores(1), want)
+    finally:
+        eng.comm_destroy()
+
+
+TWO_RANK_WORKER = r'''
+import os, sys, json, time
+import numpy as np
+repo, rank, idfile = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+sys.path[:0] = [os.path.join(repo, "llm-rankers_amd"), repo]
+import torch
+from llmrankers import _synth
+from llmrankers._engine import RkEngine
+dims = _synth.TOY_GATED_UNTIED
+eng = RkEngine(dims, device=rank, max_tokens=2048, max_seqs=16, max_dec_len=8).load_state(_synth.synth_state_dict(dims, seed=11).items())
+if rank == 0:
+    with open(idfile + ".tmp", "wb") as f:
+        f.write(eng.comm_unique_id())
+    os.replace(idfile + ".tmp", idfile)
+else:
+    for _ in range(600):
+        if os.path.exists(idfile):
+            break
+        time.sleep(0.1)
+uid = open(idfile, "rb").read()
+eng.comm_init(uid, rank, 2, 64)
+seqs = _synth.synth_token_batch(13, 4, 60, dims.vocab, seed=5)
+lo, hi = (0, 7) if rank == 0 else (7, 13)
+local = eng.score(seqs[lo:hi], [0], [21, 22])
+eng.comm_all_gather(7 * 2, slot=0)
+allv = eng.comm_read_gathered(0)
+print("RESULT " + json.dumps({"local": local.tolist(), "all": allv.tolist()}))
+eng.comm_destroy(); eng.close()
+'''
+
+
+def test_comm_two_ranks_gather(tmp_path):
+    """Two processes, one GPU each: 13 candidates sharded 7 + 6, ONE engine-issued RCCL all_gather; both ranks end up
+    with both score blocks, equal to a single-GPU run.  Skipped on a 1-GPU box."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from conftest import REPO
+    w = tmp_path / "worker.py"
+    w.write_text(TWO_RANK_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(w), REPO, str(r), str(tmp_path / "uid.bin")], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(json.loads(next(l for l in out.splitlines() if l.startswith("RESULT "))[7:]))
+    a0, a1 = np.array(outs[0]["all"]), np.array(outs[1]["all"])
+    np.testing.assert_array_equal(a0, a1)
+    np.testing.assert_array_equal(a0[0].reshape(7, 2), np.array(outs[0]["local"]))
+    np.testing.assert_array_equal(a0[1][:12].reshape(6, 2), np.array(outs[1]["local"]))
+
+
+def test_qlm_flan_t5_xl_dims_vs_oracle_and_batch_independence():
+    """BASELINE.json configs[3] model shape (flan-t5-xl: d_model 2048, 32 heads, d_ff 5120, 24+24 layers), pointwise qlm:
+    3 ragged passages x 33 label positions vs the fp32 oracle (relative 5e-4 on sums of ~33 log-probs), then the call
+    shape of an 8-way shard of hits=100 (13 passages x 33 labels) for batch independence and permutation equivariance."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle
+    dims = _synth.FLAN_T5_XL
+    state = _synth.synth_state_dict(dims, seed=929, threads=32)
+    eng = _engine(dims, state, max_tokens=4096, max_seqs=16, max_dec_len=40)
+    labels = [0] + np.random.RandomState(6).randint(3, dims.vocab - 28, size=32).tolist()
+    ragged = _synth.synth_token_batch(3, 30, 150, dims.vocab, seed=41)
+    got = eng.qlm(ragged, labels)
+    want = T5Oracle(dims, state).qlm(ragged, labels)
+    assert np.abs(got - want).max() / np.abs(want).max() < 5e-4, (got, want)
+    shard = _synth.synth_token_batch(13, 100, 150, dims.vocab, seed=42)
+    full = eng.qlm(shard, labels)
+    assert np.isfinite(full).all()
+    perm = np.random.RandomState(2).permutation(13)
+    np.testing.assert_array_equal(eng.qlm([shard[i] for i in perm], labels), full[perm])
+    np.testing.assert_array_equal(eng.qlm(shard[4:6], labels), full[4:6])
+    # yes_no at the same width: 8 heads per workgroup pairs, rmsnorm_kernel<8>, 2048-wide rows in every kernel
+    sc = eng.score(ragged, [0], [2163, 465])
+    ref = T5Oracle(dims, state).score_last(ragged, [0], [2163, 465])
+    assert np.abs(_sigm(sc[:, 0] - sc[:, 1]) - _sigm(ref[:, 0] - ref[:, 1])).max() < SCORE_TOL
+    eng.close()

@@ -40,9 +40,9 @@ def _build(case, rt, tok):
     from llmrankers.pointwise import PointwiseLlmRanker
     from llmrankers.setwise import SetwiseLlmRanker
     if case["kind"] == "pointwise":
-        return PointwiseLlmRanker(None, None, "cuda", method=case["method"], batch_size=case["batch_size"], _runtime=rt, _tokenizer=tok)
-    return SetwiseLlmRanker(None, None, "cuda", num_child=case["num_child"], k=case["k"], scoring=case["scoring"],
-                            method=case["method"], num_permutation=case["num_permutation"], _runtime=rt, _tokenizer=tok)
+        return PointwiseLlmRanker.from_runtime(rt, tok, method=case["method"], batch_size=case["batch_size"])
+    return SetwiseLlmRanker.from_runtime(rt, tok, num_child=case["num_child"], k=case["k"], scoring=case["scoring"],
+                            method=case["method"], num_permutation=case["num_permutation"])
 
 
 def test_pointwise_cases(cases, stack):
@@ -68,24 +68,63 @@ def test_pointwise_cases(cases, stack):
     assert n >= 16
 
 
-def test_setwise_cases(cases, stack):
+def test_monot5_cases(stack):
+    """MonoT5LlmRanker on the engine vs the reference's MonoT5LlmRanker (relu FFN, tied + scaled head, ids 6136 / 1176)."""
+    from llmrankers.pointwise import MonoT5LlmRanker
     from llmrankers.rankers import SearchResult
-    n = 0
+    with open(os.path.join(GOLD, "monot5_cases.json")) as f:
+        mcases = json.load(f)["cases"]
+    rt, tok = stack["ckpt_monot5"]
+    for case in mcases:
+        rk = MonoT5LlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=case["batch_size"])
+        ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+        res = rk.rerank(case["query"], ranking)
+        want = dict((d, s) for d, s in case["result"])
+        got = np.array([r.score for r in res]); ref = np.array([want[r.docid] for r in res])
+        assert np.abs(got - ref).max() < SCORE_TOL, np.abs(got - ref).max()
+        ref_sorted = [s for _, s in case["result"]]
+        if len(ref_sorted) < 2 or min(a - b for a, b in zip(ref_sorted, ref_sorted[1:])) > 2 * SCORE_TOL:
+            assert [r.docid for r in res] == [d for d, _ in case["result"]]
+        assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"]
+    assert len(mcases) >= 6
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_setwise_cases(cases, stack, monkeypatch, batched):
+    """batched=True is what ships: the build phase of the heapsort submits the independent sift-downs of a tree level
+    in one engine call (SetwiseLlmRanker._build_heap_batched / _compare_many, incl. the multi-row greedy EOS trimming).
+    Compares are logged by wrapping the CLASS methods, so the ranker's own dispatch (_batched_ok) is untouched; the
+    level-wise order differs from the reference's inside a level, so the compare log is checked as a multiset there
+    and as an exact sequence with batching off."""
+    from llmrankers.rankers import SearchResult
+    from llmrankers.setwise import SetwiseLlmRanker
+    log, many_sizes = [], []
+    orig_compare, orig_many = SetwiseLlmRanker.compare, SetwiseLlmRanker._compare_many
+
+    def logged(self, query, docs):
+        out = orig_compare(self, query, docs)
+        log.append([[d.docid for d in docs], out])
+        return out
+
+    def logged_many(self, query, doc_lists):
+        outs = orig_many(self, query, doc_lists)
+        many_sizes.append(len(doc_lists))
+        for docs, out in zip(doc_lists, outs):
+            log.append([[d.docid for d in docs], out])
+        return outs
+
+    monkeypatch.setattr(SetwiseLlmRanker, "compare", logged)
+    monkeypatch.setattr(SetwiseLlmRanker, "_compare_many", logged_many)
+    n = n_batched_calls = 0
     for case in cases:
         if case["kind"] != "setwise":
             continue
         rt, tok = stack[case["ckpt"]]
         ranker = _build(case, rt, tok)
+        ranker.batch_independent_compares = batched
+        assert ranker._batched_ok() == (batched and case["num_permutation"] == 1)
         ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
-        log = []
-        orig = ranker.compare
-
-        def logged(query, docs, _o=orig, _l=log):
-            out = _o(query, docs)
-            _l.append([[d.docid for d in docs], out])
-            return out
-
-        ranker.compare = logged
+        del log[:], many_sizes[:]
         random.seed(929)
         sink = io.StringIO()
         tag = (case["ckpt"], case["scoring"], case["method"], case["num_child"], case["num_permutation"])
@@ -97,13 +136,19 @@ def test_setwise_cases(cases, stack):
             continue
         with contextlib.redirect_stdout(sink):
             res = ranker.rerank(case["query"], ranking)
-        assert log == case["compares"], f"{tag}: first differing compare " \
-            f"{next((i, a, b) for i, (a, b) in enumerate(zip(log + [None], case['compares'] + [None])) if a != b)}"
+        if many_sizes:
+            n_batched_calls += sum(1 for m in many_sizes if m > 1)
+            key = lambda c: (tuple(c[0]), c[1])
+            assert sorted(map(key, log)) == sorted(map(key, case["compares"])), tag
+        else:
+            assert log == case["compares"], f"{tag}: first differing compare " \
+                f"{next((i, a, b) for i, (a, b) in enumerate(zip(log + [None], case['compares'] + [None])) if a != b)}"
         assert [[r.docid, r.score] for r in res] == case["result"], tag          # identical docid rank order
         assert [r.docid for r in ranking] == case["caller_list_after"]
         assert [ranker.total_compare, ranker.total_prompt_tokens, ranker.total_completion_tokens] == case["counters"], tag
         n += 1
     assert n >= 16
+    assert (n_batched_calls > 0) == batched        # the level-batched path really ran (or really did not)
 
 
 def test_pipelined_batches_equal_blocking_calls(stack):

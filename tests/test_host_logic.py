@@ -38,10 +38,9 @@ def runtimes(ckpt_dirs):
 
 def build_ranker(case, rt, tok):
     if case["kind"] == "pointwise":
-        return PointwiseLlmRanker(None, None, "cuda", method=case["method"], batch_size=case["batch_size"],
-                                  _runtime=rt, _tokenizer=tok)
-    return SetwiseLlmRanker(None, None, "cuda", num_child=case["num_child"], k=case["k"], scoring=case["scoring"],
-                            method=case["method"], num_permutation=case["num_permutation"], _runtime=rt, _tokenizer=tok)
+        return PointwiseLlmRanker.from_runtime(rt, tok, method=case["method"], batch_size=case["batch_size"])
+    return SetwiseLlmRanker.from_runtime(rt, tok, num_child=case["num_child"], k=case["k"], scoring=case["scoring"],
+                            method=case["method"], num_permutation=case["num_permutation"])
 
 
 def check_case(case, ranker, score_tol):
@@ -83,7 +82,7 @@ def test_level_batched_build_heap_equals_one_by_one(runtimes, scoring):
     docs = [(f"d{i}", float(40 - i), " ".join(rs.choice(words) for _ in range(rs.randint(3, 9)))) for i in range(40)]
     outs = []
     for batched in (False, True):
-        rk = SetwiseLlmRanker(None, None, "cuda", num_child=3, k=5, scoring=scoring, method="heapsort", _runtime=rt, _tokenizer=tok)
+        rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=3, k=5, scoring=scoring, method="heapsort")
         rk.batch_independent_compares = batched
         calls = []
         many = rk._compare_many
@@ -97,10 +96,29 @@ def test_level_batched_build_heap_equals_one_by_one(runtimes, scoring):
     assert outs[0] == outs[1]
 
 
+def test_monot5_reference_cases_cpu(ckpt_dirs):
+    """MonoT5LlmRanker vs the reference's own class (ref: pointwise.py:136-186): 'Query: .. Document: .. Relevant:' prompt,
+    decoder_start_token_id as decoder input, softmax over the fixed ids (false 6136, true 1176) -> P(true), counters."""
+    from transformers import T5Tokenizer
+    with open(os.path.join(GOLD, "monot5_cases.json")) as f:
+        mcases = json.load(f)["cases"]
+    assert len(mcases) >= 6
+    dims, state = load_state(ckpt_dirs["ckpt_monot5"])
+    assert dims.tied_head and not dims.gated and dims.vocab > 6136
+    rt, tok = OracleRuntime(dims, state), T5Tokenizer.from_pretrained(ckpt_dirs["ckpt_monot5"])
+    for case in mcases:
+        rk = MonoT5LlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=case["batch_size"])
+        ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+        res = rk.rerank(case["query"], ranking)
+        assert [r.docid for r in res] == [d for d, _ in case["result"]]
+        np.testing.assert_allclose([r.score for r in res], [s for _, s in case["result"]], atol=2e-5, rtol=2e-5)
+        assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"]
+
+
 def test_truncate(cases, runtimes):
     rt, tok = runtimes["ckpt_gated_untied"]
-    pw = PointwiseLlmRanker(None, None, "cuda", method="yes_no", batch_size=2, _runtime=rt, _tokenizer=tok)
-    sw = SetwiseLlmRanker(None, None, "cuda", _runtime=rt, _tokenizer=tok)
+    pw = PointwiseLlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=2)
+    sw = SetwiseLlmRanker.from_runtime(rt, tok)
     for text, n, want in cases["truncate"]:
         assert pw.truncate(text, n) == want
         assert sw.truncate(text, n) == want
@@ -158,7 +176,7 @@ def test_api_surface():
 
 def test_unknown_sort_method_and_cpu_device(runtimes, ckpt_dirs):
     rt, tok = runtimes["ckpt_gated_untied"]
-    sw = SetwiseLlmRanker(None, None, "cuda", method="quicksort", _runtime=rt, _tokenizer=tok)
+    sw = SetwiseLlmRanker.from_runtime(rt, tok, method="quicksort")
     with pytest.raises(NotImplementedError):
         sw.rerank("q", [SearchResult("a", 1.0, "x"), SearchResult("b", 0.5, "y")])
     # no silent CPU fallback in the product path: device='cpu' must fail loudly

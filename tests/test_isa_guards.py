@@ -65,9 +65,10 @@ def test_attention_prefetch_registers_untouched_until_the_wait(isa):
     assert not any("scratch_" in l for l in body), "attention kernel spills"
 
 
-@pytest.mark.parametrize("epi", range(5))
-def test_pingpong_gemm_k_loop_keeps_loads_in_flight(isa, epi):
-    body = kernel_body(isa, f"_Z15gemm_pp2_kernelILi{epi}ELi0EEv8GemmArgs")
+# (epilogue kind, folded-RMSNorm row factors): every product instantiation of the ping-pong kernel
+@pytest.mark.parametrize("epi,rs", [(0, 0), (0, 1), (1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (4, 0)])
+def test_pingpong_gemm_k_loop_keeps_loads_in_flight(isa, epi, rs):
+    body = kernel_body(isa, f"_Z15gemm_pp2_kernelILi{epi}ELi0ELb{rs}EEv8GemmArgs")
     assert not any("scratch_" in l for l in body), "ping-pong GEMM spills"
     # the K loop = the innermost loop that holds MFMAs
     heads = [i for i, l in enumerate(body) if "Inner Loop Header" in l]

@@ -72,8 +72,8 @@ def main():
         rt.margins = []
         ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
         if case["kind"] == "setwise":
-            rk = SetwiseLlmRanker(None, None, "cuda", num_child=case["num_child"], k=case["k"], scoring=case["scoring"],
-                                  method=case["method"], num_permutation=case["num_permutation"], _runtime=rt, _tokenizer=tok)
+            rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=case["num_child"], k=case["k"], scoring=case["scoring"],
+                                  method=case["method"], num_permutation=case["num_permutation"])
             random.seed(929)
             with contextlib.redirect_stdout(io.StringIO()):
                 try:

@@ -28,7 +28,7 @@ def main():
     rt.max_tokens, rt.max_seqs = 8192, 32
     rt.engine = RkEngine(dims, 0, max_tokens=8192, max_seqs=32, max_dec_len=4)
     rt.engine.load_state(_synth.synth_tensors(dims, seed=929, threads=min(32, os.cpu_count() or 8)))
-    ranker = PointwiseLlmRanker(None, None, "cuda", method="yes_no", batch_size=32, _runtime=rt, _tokenizer=tok)
+    ranker = PointwiseLlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=32)
     words = "neural ranking model search engine index retrieval document answer question relevant topic passage".split()
     rs = np.random.RandomState(0)
     query = " ".join(rs.choice(words, 30))

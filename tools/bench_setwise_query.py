@@ -49,7 +49,7 @@ def main():
     out = {}
     for scoring in ("likelihood", "generation"):
         for batched in (False, True):
-            rk = SetwiseLlmRanker(None, None, "cuda", num_child=10, k=10, scoring=scoring, method="heapsort", _runtime=rt, _tokenizer=tok)
+            rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring=scoring, method="heapsort")
             rk.batch_independent_compares = batched
             best, res0 = None, None
             for rep in range(3):

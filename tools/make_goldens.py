@@ -255,8 +255,8 @@ def rerank_goldens(ref_rankers, ref_pointwise, ref_setwise, ckpts):
                     cases.append({"kind": "pointwise", "ckpt": ck, "method": method, "batch_size": bs, "query": q,
                                   "input": inp, "result": [[r.docid, r.score] for r in res],
                                   "counters": [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens]})
-    # monoT5 (ref: pointwise.py:136-186) — fixed token ids 6136/1176 exceed the toy vocab, so golden only
-    # the relu/tied forward via yes_no above; MonoT5 ids are exercised with a vocab-mapped variant in tests.
+    # monoT5 (ref: pointwise.py:136-186): its fixed token ids 6136/1176 exceed the toy vocabulary, so it has its own
+    # checkpoint and fixture file (monot5_goldens below)
 
     # setwise (ref: setwise.py:79-313)
     for ck, scoring, method, c, k, nperm, n in (
@@ -310,6 +310,50 @@ def rerank_goldens(ref_rankers, ref_pointwise, ref_setwise, ckpts):
     print(f"[rerank_cases] {len(cases)} cases; reference printed 'Unexpected output' {n_unexp}x")
 
 
+def monot5_goldens(ref_rankers, ref_pointwise, ckpt_dir):
+    """The reference's MonoT5LlmRanker (ref: pointwise.py:136-186) on a relu / tied-head checkpoint whose vocabulary
+    covers the hard-coded 'false' / 'true' ids 6136 / 1176: prompt, decoder_start_token_id input, false/true ordering,
+    counters, stable sort.  -> tests/golden/monot5_cases.json"""
+    rs = np.random.RandomState(91)
+    queries = [rand_text(rs, 3, 8) for _ in range(2)]
+    doc_pool = [rand_text(rs, 8, 40) for _ in range(30)]
+    cases = []
+    sink = io.StringIO()
+    for bs, n in ((4, 13), (32, 9), (1, 3)):
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            rk = ref_pointwise.MonoT5LlmRanker(ckpt_dir, ckpt_dir, device="cpu", method="yes_no", batch_size=bs)
+            for qi, q in enumerate(queries):
+                ranking = [ref_rankers.SearchResult(docid=f"M{7 * qi + i}", score=float(50 - i), text=doc_pool[(7 * qi + i) % 30])
+                           for i in range(n)]
+                inp = [[r.docid, r.score, r.text] for r in ranking]
+                res = rk.rerank(q, ranking)
+                cases.append({"kind": "monot5", "ckpt": "ckpt_monot5", "batch_size": bs, "query": q, "input": inp,
+                              "result": [[r.docid, r.score] for r in res],
+                              "counters": [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens]})
+    with open(os.path.join(GOLD, "monot5_cases.json"), "w") as f:
+        json.dump({"cases": cases}, f)
+    sc = [s for c in cases for _, s in c["result"]]
+    print(f"[monot5_cases] {len(cases)} cases, P(true) range {min(sc):.4f}..{max(sc):.4f}")
+
+
+def add_monot5():
+    """Incremental: adds the monoT5 checkpoint recipe and cases without regenerating the other fixtures."""
+    import tempfile
+    tok_dir = os.path.join(GOLD, "tok")
+    with open(os.path.join(GOLD, "ckpts.json")) as f:
+        specs = json.load(f)
+    spec = {"dims": "toy-monot5", "seed": 14, "gain": 1.0}
+    tmp = tempfile.mkdtemp(prefix="rk_goldens_")
+    ck = os.path.join(tmp, "ckpt_monot5")
+    spec["sha256"] = write_ckpt(ck, spec, tok_dir)
+    specs["ckpt_monot5"] = spec
+    with open(os.path.join(GOLD, "ckpts.json"), "w") as f:
+        json.dump(specs, f, indent=1)
+    ref_rankers, ref_pointwise, _ = import_reference()
+    monot5_goldens(ref_rankers, ref_pointwise, ck)
+    shutil.rmtree(tmp)
+
+
 def config1_golden(ref_rankers, ref_pointwise, tok_dir):
     """BASELINE.json configs[0]: flan-t5-small shape, pointwise yes_no, hits=20, batch_size=4, CPU HF reference.
     Weights come from the counter generator (regenerable on the GPU box); prompts are pre-tokenised ids."""
@@ -354,6 +398,8 @@ def config1_golden(ref_rankers, ref_pointwise, tok_dir):
 
 
 def main():
+    if "--only-monot5" in sys.argv:
+        return add_monot5()
     if os.path.isdir(GOLD):
         shutil.rmtree(GOLD)
     os.makedirs(GOLD)
@@ -382,6 +428,13 @@ def main():
     sort_trace_goldens(ref_rankers, ref_setwise)
     rerank_goldens(ref_rankers, ref_pointwise, ref_setwise, ckpts)
     config1_golden(ref_rankers, ref_pointwise, tok_dir)
+    spec = {"dims": "toy-monot5", "seed": 14, "gain": 1.0}
+    ck = os.path.join(tmp, "ckpt_monot5")
+    spec["sha256"] = write_ckpt(ck, spec, tok_dir)
+    specs["ckpt_monot5"] = spec
+    with open(os.path.join(GOLD, "ckpts.json"), "w") as f:
+        json.dump(specs, f, indent=1)
+    monot5_goldens(ref_rankers, ref_pointwise, ck)
     with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
         import transformers, torch
         json.dump({"generator": "tools/make_goldens.py", "reference": "ielab/llm-rankers @ /root/reference (2025-07-18)",
