@@ -226,6 +226,9 @@ def write_checkpoint(path: str, spec: dict, tokenizer_dir: str = None) -> None:
         w = sd[key].copy()
         ids = np.asarray(spec["boost_ids"], dtype=np.int64)
         w[ids] = _fp16_round(w[ids] * np.float32(spec["boost"]))
+        if spec.get("boost2_ids"):                      # a second group with its own factor (e.g. EOS a little below the labels)
+            ids2 = np.asarray(spec["boost2_ids"], dtype=np.int64)
+            w[ids2] = _fp16_round(w[ids2] * np.float32(spec["boost2"]))
         sd[key] = w
     save_file({k: np.ascontiguousarray(v) for k, v in sd.items()}, os.path.join(path, "model.safetensors"))
     with open(os.path.join(path, "config.json"), "w") as f:

@@ -11,6 +11,12 @@ path this build accelerates and are rejected with a clear message.  
 (ir_datasets / pyserini) are imported lazily; because neither exists offline, two plain-file sources are
 accepted as well:  --query_file (TSV `qid<TAB>text` or JSONL {"qid"|"query_id"|"_id", "text"|"query"}) and
 --doc_file (TSV `docid<TAB>text` or JSONL {"docid"|"doc_id"|"_id", "text"|"contents", ["title"]}).
+
+Long runs (the reference's Rank-R1 driver, ref: Rank-R1/run_setwise.py:79-87, 266-300): `--resume` appends each query's
+ranking to --save_path as soon as it is done and skips the qids already in the file when restarted;
+`--dataset_number_of_shards` / `--dataset_shard_index` cut the query list into contiguous shards (one process per GPU,
+replicas only - the right multi-GPU mode for setwise).  `--qrels` prints NDCG@10 of the input run and of the reranked
+run with a self-contained NDCG (trec_eval / pyserini are not available offline).
 """
 import argparse
 import json
@@ -44,12 +50,69 @@ def parse_args(parser, commands, argv=None):
     return args
 
 
-def write_run_file(path, results, tag):
-    # ref: run.py:41-49
-    with open(path, "w") as f:
+def write_run_file(path, results, tag, mode="w"):
+    # ref: run.py:41-49; mode "a" = the append-per-query form of ref: Rank-R1/run_setwise.py:79-87
+    with open(path, mode) as f:
         for qid, _, ranking in results:
             for rank, doc in enumerate(ranking, start=1):
                 f.write(f"{qid}\tQ0\t{doc.docid}\t{rank}\t{doc.score}\t{tag}\n")
+
+
+def read_run_qids(path):
+    """qids that already have lines in a (partial) run file, in file order."""
+    seen = []
+    try:
+        with open(path) as f:
+            for line in f:
+                parts = line.split()
+                if parts and (not seen or seen[-1] != parts[0]) and parts[0] not in seen:
+                    seen.append(parts[0])
+    except FileNotFoundError:
+        pass
+    return seen
+
+
+def split_into_shards(data, num_shards):
+    """Contiguous shards whose sizes differ by at most one (ref: Rank-R1/run_setwise.py:90-92)."""
+    base, extra = divmod(len(data), num_shards)
+    out, s = [], 0
+    for i in range(num_shards):
+        e = s + base + (1 if i < extra else 0)
+        out.append(data[s:e])
+        s = e
+    return out
+
+
+def read_qrels(path):
+    """TREC qrels: `qid iter docid rel` (or 3 columns) -> {qid: {docid: int rel}}."""
+    out = {}
+    with open(path) as f:
+        for line in f:
+            parts = line.split()
+            if len(parts) >= 4:
+                qid, docid, rel = parts[0], parts[2], parts[3]
+            elif len(parts) == 3:
+                qid, docid, rel = parts
+            else:
+                continue
+            out.setdefault(qid, {})[docid] = int(float(rel))
+    return out
+
+
+def ndcg_at_k(ranked_docids, rels, k=10):
+    """NDCG@k with trec_eval's ndcg_cut convention: gain = rel (linear), discount = 1 / log2(rank + 1), ideal ranking from
+    the judged documents of the query; 0 for a query without relevant documents."""
+    import math
+    dcg = sum(max(rels.get(d, 0), 0) / math.log2(i + 2) for i, d in enumerate(ranked_docids[:k]))
+    ideal = sorted((r for r in rels.values() if r > 0), reverse=True)[:k]
+    idcg = sum(r / math.log2(i + 2) for i, r in enumerate(ideal))
+    return dcg / idcg if idcg > 0 else 0.0
+
+
+def mean_ndcg(run, qrels, k=10):
+    """run: {qid: [docid, ...] best first}.  Mean over the queries that have qrels (trec_eval -c off)."""
+    vals = [ndcg_at_k(docs, qrels[q], k) for q, docs in run.items() if q in qrels]
+    return sum(vals) / len(vals) if vals else 0.0
 
 
 def _read_kv_file(path, id_keys, text_keys):
@@ -86,8 +149,15 @@ def build_ranker(args):
                                 device=args.run.device, cache_dir=args.run.cache_dir, num_child=args.setwise.num_child,
                                 scoring=args.run.scoring, method=args.setwise.method,
                                 num_permutation=args.setwise.num_permutation, k=args.setwise.k)
-    if args.pairwise or args.listwise:
-        raise NotImplementedError("pairwise / listwise rankers are outside the path this engine accelerates (DESIGN.md); use the reference")
+    if args.pairwise:
+        if args.run.openai_key or "duot5" in args.run.model_name_or_path:
+            raise NotImplementedError("OpenAI / duoT5 pairwise rankers are not part of this build; use the reference")
+        from llmrankers.pairwise import PairwiseLlmRanker
+        return PairwiseLlmRanker(model_name_or_path=args.run.model_name_or_path, tokenizer_name_or_path=args.run.tokenizer_name_or_path,
+                                 device=args.run.device, cache_dir=args.run.cache_dir, method=args.pairwise.method,
+                                 batch_size=args.pairwise.batch_size, k=args.pairwise.k)
+    if args.listwise:
+        raise NotImplementedError("listwise rankers are outside the path this engine accelerates (DESIGN.md); use the reference")
     raise ValueError("Must specify either --pointwise, --setwise, --pairwise or --listwise.")
 
 
@@ -139,9 +209,19 @@ def main(args):
         if cur_qid is not None:
             first_stage.append((cur_qid, query_map[cur_qid], cur[:args.run.hits]))
 
+    if getattr(args.run, "dataset_number_of_shards", 1) > 1:        # one process per GPU, each takes a contiguous shard of the queries
+        first_stage = split_into_shards(first_stage, args.run.dataset_number_of_shards)[args.run.dataset_shard_index]
+    resume = bool(getattr(args.run, "resume", False))
+    done = set(read_run_qids(args.run.save_path)) if resume else set()
+    if done:
+        print(f"{args.run.save_path} exists. Continue ranking ({len(done)} queries done)")
+    first_stage_order = {qid: [d.docid for d in ranking] for qid, _, ranking in first_stage}
+
     results, n_cmp, n_prompt, n_compl = [], 0, 0, 0
     tic = time.time()
     for qid, query, ranking in first_stage:
+        if qid in done:
+            continue
         if args.run.shuffle_ranking == "random":
             random.shuffle(ranking)
         elif args.run.shuffle_ranking == "inverse":
@@ -150,13 +230,25 @@ def main(args):
         n_cmp += ranker.total_compare
         n_prompt += ranker.total_prompt_tokens
         n_compl += ranker.total_completion_tokens
+        if resume:                                                   # durable after every query (ref: Rank-R1/run_setwise.py:79-87)
+            write_run_file(args.run.save_path, results[-1:], "LLMRankers", mode="a")
     toc = time.time()
     n = max(len(results), 1)
     print(f"Avg comparisons: {n_cmp / n}")
     print(f"Avg prompt tokens: {n_prompt / n}")
     print(f"Avg completion tokens: {n_compl / n}")
     print(f"Avg time per query: {(toc - tic) / n}")
-    write_run_file(args.run.save_path, results, "LLMRankers")
+    if not resume:
+        write_run_file(args.run.save_path, results, "LLMRankers")
+    if getattr(args.run, "qrels", None):
+        qrels = read_qrels(args.run.qrels)
+        reranked = {}
+        with open(args.run.save_path) as f:
+            for line in f:
+                parts = line.split()
+                reranked.setdefault(parts[0], []).append(parts[2])
+        print(f"NDCG@10 first stage: {mean_ndcg(first_stage_order, qrels):.4f}")
+        print(f"NDCG@10 reranked: {mean_ndcg(reranked, qrels):.4f}")
 
 
 def build_parser():
@@ -179,6 +271,10 @@ def build_parser():
     rp.add_argument("--openai_key", type=str, default=None)
     rp.add_argument("--scoring", type=str, default="generation", choices=["generation", "likelihood"])
     rp.add_argument("--shuffle_ranking", type=str, default=None, choices=["inverse", "random"])
+    rp.add_argument("--resume", action="store_true", help="append every query's ranking to --save_path at once and skip qids already there")
+    rp.add_argument("--dataset_number_of_shards", type=int, default=1)
+    rp.add_argument("--dataset_shard_index", type=int, default=0)
+    rp.add_argument("--qrels", type=str, default=None, help="TREC qrels file: print NDCG@10 of the input and the reranked run")
     pw = commands.add_parser("pointwise")
     pw.add_argument("--method", type=str, default="yes_no", choices=["qlm", "yes_no"])
     pw.add_argument("--batch_size", type=int, default=2)

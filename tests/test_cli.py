@@ -63,3 +63,73 @@ def test_trec_round_trip_with_file_sources(runmod, tmp_path, ckpt_dirs, monkeypa
     for q in ("q1", "q2"):
         sc = [float(l.split("\t")[4]) for l in out if l.startswith(q + "\t")]
         assert sc == sorted(sc, reverse=True)
+
+
+def test_ndcg_and_shards(runmod, tmp_path):
+    import math
+    rels = {"a": 3, "b": 0, "c": 1, "d": 2}
+    got = runmod.ndcg_at_k(["b", "a", "x", "c"], rels, k=10)
+    dcg = 3 / math.log2(3) + 1 / math.log2(5)
+    idcg = 3 / math.log2(2) + 2 / math.log2(3) + 1 / math.log2(4)
+    assert abs(got - dcg / idcg) < 1e-12
+    assert runmod.ndcg_at_k(["a", "d", "c"], rels) == 1.0 and runmod.ndcg_at_k(["x"], rels) == 0.0
+    assert runmod.ndcg_at_k(["a"], {"a": 0}) == 0.0                              # no relevant document: 0, not a division by zero
+    assert runmod.ndcg_at_k(list("abcd") * 5, rels, k=2) == runmod.ndcg_at_k(["a", "b"], rels, k=2)
+    (tmp_path / "q.rels").write_text("q1 0 a 3\nq1 0 b 0\nq2 0 c 1\nq3 0 z 1\n")
+    q = runmod.read_qrels(str(tmp_path / "q.rels"))
+    assert q == {"q1": {"a": 3, "b": 0}, "q2": {"c": 1}, "q3": {"z": 1}}
+    assert abs(runmod.mean_ndcg({"q1": ["a", "b"], "q2": ["x", "c"], "q9": ["a"]}, q) - (1.0 + 1 / math.log2(3)) / 2) < 1e-12
+    assert [len(x) for x in runmod.split_into_shards(list(range(10)), 4)] == [3, 3, 2, 2]
+    assert sum(runmod.split_into_shards(list(range(10)), 4), []) == list(range(10))
+
+
+def test_resume_appends_and_skips_done_queries(runmod, tmp_path, ckpt_dirs, monkeypatch):
+    """--resume: each query's lines are appended as soon as it is ranked; a restarted run skips the qids already in
+    the file and ends with the same file as an uninterrupted run (ref: Rank-R1/run_setwise.py:79-87, 284-291)."""
+    from conftest import load_state
+    from _stub import OracleRuntime
+    from transformers import T5Tokenizer
+    from llmrankers.pointwise import PointwiseLlmRanker
+    ck = ckpt_dirs["ckpt_gated_untied"]
+    dims, state = load_state(ck)
+    tok = T5Tokenizer.from_pretrained(ck)
+    calls = []
+
+    def make(args):
+        rk = PointwiseLlmRanker.from_runtime(OracleRuntime(dims, state), tok, method=args.pointwise.method, batch_size=args.pointwise.batch_size)
+        orig = rk.rerank
+        rk.rerank = lambda q, r: (calls.append(q), orig(q, r))[1]
+        return rk
+
+    monkeypatch.setattr(runmod, "build_ranker", make)
+    (tmp_path / "q.tsv").write_text("q1\tneural ranking model\nq2\twater river mountain\nq3\tmusic art film\n")
+    (tmp_path / "d.tsv").write_text("\n".join(f"d{i}\t{w}" for i, w in enumerate(
+        ["search engine index", "river water city", "music art film", "vaccine covid virus"])) + "\n")
+    lines = [f"{q} Q0 d{i} {r + 1} {10 - r} bm25" for q in ("q1", "q2", "q3") for r, i in enumerate([0, 1, 2, 3])]
+    (tmp_path / "in.trec").write_text("\n".join(lines) + "\n")
+    (tmp_path / "qrels").write_text("q1 0 d0 2\nq2 0 d1 1\nq3 0 d2 3\n")
+    parser, commands = runmod.build_parser()
+
+    def run(save, extra=()):
+        args = runmod.parse_args(parser, commands, ["run", "--model_name_or_path", ck, "--run_path", str(tmp_path / "in.trec"),
+                                                    "--save_path", str(save), "--query_file", str(tmp_path / "q.tsv"),
+                                                    "--doc_file", str(tmp_path / "d.tsv"), "--hits", "4", "--qrels", str(tmp_path / "qrels"),
+                                                    *extra, "pointwise", "--method", "yes_no", "--batch_size", "2"])
+        runmod.validate(args)
+        runmod.main(args)
+
+    run(tmp_path / "full.trec")
+    full = (tmp_path / "full.trec").read_text()
+    assert len(full.splitlines()) == 12 and len(calls) == 3
+    part = tmp_path / "part.trec"
+    part.write_text("".join(l + "\n" for l in full.splitlines()[:4]))          # q1 was finished before the "crash"
+    del calls[:]
+    run(part, ["--resume"])
+    assert part.read_text() == full and len(calls) == 2                          # only q2 and q3 were ranked again
+    del calls[:]
+    run(part, ["--resume"])
+    assert part.read_text() == full and calls == []                              # nothing left to do
+    # query shards: two processes, each its half, together the whole run
+    run(tmp_path / "s0.trec", ["--dataset_number_of_shards", "2", "--dataset_shard_index", "0"])
+    run(tmp_path / "s1.trec", ["--dataset_number_of_shards", "2", "--dataset_shard_index", "1"])
+    assert (tmp_path / "s0.trec").read_text() + (tmp_path / "s1.trec").read_text() == full

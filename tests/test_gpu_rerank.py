@@ -89,6 +89,26 @@ def test_monot5_cases(stack):
     assert len(mcases) >= 6
 
 
+def test_pairwise_cases(stack):
+    """PairwiseLlmRanker (PRP: two greedy generations per pair through rk_t5_greedy) vs the reference's PairwiseLlmRanker."""
+    from llmrankers.pairwise import PairwiseLlmRanker
+    from llmrankers.rankers import SearchResult
+    with open(os.path.join(GOLD, "pairwise_cases.json")) as f:
+        pcases = json.load(f)["cases"]
+    for case in pcases:
+        rt, tok = stack[case["ckpt"]]
+        rk = PairwiseLlmRanker.from_runtime(rt, tok, method=case["method"], batch_size=case["batch_size"], k=case["k"])
+        log, orig = [], rk.compare
+        rk.compare = lambda q, d, _o=orig, _l=log: (_l.append([list(d)]), _l[-1].append(list(_o(q, d))))[1] or _l[-1][1]
+        ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+        res = rk.rerank(case["query"], ranking)
+        tag = (case["ckpt"], case["method"], case["batch_size"], case["k"])
+        assert log == case["compares"], tag
+        assert [[r.docid, r.score] for r in res] == case["result"], tag
+        assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"], tag
+    assert len(pcases) >= 14
+
+
 @pytest.mark.parametrize("batched", [True, False])
 def test_setwise_cases(cases, stack, monkeypatch, batched):
     """batched=True is what ships: the build phase of the heapsort submits the independent sift-downs of a tree level

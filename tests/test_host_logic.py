@@ -115,6 +115,36 @@ def test_monot5_reference_cases_cpu(ckpt_dirs):
         assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"]
 
 
+def test_pairwise_reference_cases_cpu(ckpt_dirs):
+    """PairwiseLlmRanker (PRP) vs the reference's own class (ref: pairwise.py:29-295): allpair scoring incl. conflicts
+    and dict-order ties, the binary heapsort and the shortcut bubblesort, every compare's two decoded generations,
+    padded-shape prompt counters and batch-level completion counters."""
+    from transformers import T5Tokenizer
+    from llmrankers.pairwise import PairwiseLlmRanker
+    with open(os.path.join(GOLD, "pairwise_cases.json")) as f:
+        pcases = json.load(f)["cases"]
+    assert len(pcases) >= 14
+    rts = {}
+    for case in pcases:
+        if case["ckpt"] not in rts:
+            dims, state = load_state(ckpt_dirs[case["ckpt"]])
+            rts[case["ckpt"]] = (OracleRuntime(dims, state), T5Tokenizer.from_pretrained(ckpt_dirs[case["ckpt"]]))
+        rt, tok = rts[case["ckpt"]]
+        rk = PairwiseLlmRanker.from_runtime(rt, tok, method=case["method"], batch_size=case["batch_size"], k=case["k"])
+        log, orig = [], rk.compare
+        rk.compare = lambda q, d, _o=orig, _l=log: (_l.append([list(d)]), _l[-1].append(list(_o(q, d))))[1] or _l[-1][1]
+        ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+        res = rk.rerank(case["query"], ranking)
+        tag = (case["ckpt"], case["method"], case["batch_size"], case["k"])
+        assert log == case["compares"], tag
+        assert [[r.docid, r.score] for r in res] == case["result"], tag
+        assert [r.docid for r in ranking] == case["caller_list_after"], tag
+        assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"], tag
+        assert all(r.text is None for r in res)
+    with pytest.raises(NotImplementedError):
+        PairwiseLlmRanker.from_runtime(rt, tok, method="quicksort").rerank("q", [SearchResult("a", 1.0, "x")])
+
+
 def test_truncate(cases, runtimes):
     rt, tok = runtimes["ckpt_gated_untied"]
     pw = PointwiseLlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=2)

@@ -5,7 +5,8 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 64 --warmup 16 --no_cpu_baseline --no_profile --overlap 0"   # one stream: kernels run one at a time, so durations and counters belong to one kernel
+STEPS=${PROF_STEPS:-20}; WARM=${PROF_WARMUP:-5}
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARM --no_cpu_baseline --no_profile --no_per_query --overlap 0"   # one stream: kernels run one at a time, so durations and counters belong to one kernel
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- $CMD > $OUT/bench_stdout.txt 2> $OUT/bench_stderr.txt
 echo "rocprofv3 stats rc=$?"
@@ -14,7 +15,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT -o pmc_$tag -- $CMD > $OUT/pmc_${tag}_stdout.txt 2>&1
   echo "pmc $tag rc=$?"
 done
-python - <<'PY'
+PROF_STEPS=$STEPS PROF_WARMUP=$WARM python - <<'PY'
 import csv, glob, json, os, collections
 out = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/prof"
 summ = collections.defaultdict(dict)
@@ -30,7 +31,13 @@ f = out + "/bench_kernel_stats.csv"
 if os.path.exists(f):
     for r in csv.DictReader(open(f)):
         stats[r["Name"]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])}
-res = {"note": "FETCH_SIZE/WRITE_SIZE in KiB as reported; gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section)",
+import re, subprocess, sys
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
+steps = int(os.environ.get("PROF_STEPS", "20"))
+res = {"command": f"bench.py --steps {steps} --warmup {os.environ.get('PROF_WARMUP', '5')} --overlap 0 (one stream: kernels run one at a time)",
+       "tokens_per_launch": bench.auto_group(steps) * 32 * 184,
+       "note": "FETCH_SIZE/WRITE_SIZE in KiB as reported; gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section)",
        "kernels": {k: {"stats": stats.get(k), "pmc": v} for k, v in summ.items()}}
 json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1)
 for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["pct"])[:14]:

@@ -336,6 +336,71 @@ def monot5_goldens(ref_rankers, ref_pointwise, ckpt_dir):
     print(f"[monot5_cases] {len(cases)} cases, P(true) range {min(sc):.4f}..{max(sc):.4f}")
 
 
+def pairwise_goldens(ref_rankers, ref_pairwise, ckpts):
+    """The reference's PairwiseLlmRanker (ref: pairwise.py:29-295) — allpair / heapsort / bubblesort on the label-boosted
+    checkpoint (generations are 'Passage A' / 'Passage B') and on a plain one (mostly other tokens: the conflict and
+    'not a win' paths).  -> tests/golden/pairwise_cases.json"""
+    rs = np.random.RandomState(55)
+    queries = [rand_text(rs, 3, 8) for _ in range(2)]
+    doc_pool = [rand_text(rs, 8, 30) for _ in range(20)]
+    cases, sink = [], io.StringIO()
+    for ck, method, bs, k, n in (("ckpt_abboost", "allpair", 4, 3, 6), ("ckpt_abboost", "allpair", 3, 10, 5),
+                                 ("ckpt_abboost", "heapsort", 2, 3, 9), ("ckpt_abboost", "bubblesort", 2, 3, 8),
+                                 ("ckpt_gated_untied", "allpair", 4, 2, 5), ("ckpt_gated_untied", "heapsort", 2, 2, 6),
+                                 ("ckpt_gated_untied", "bubblesort", 2, 4, 6)):
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            rk = ref_pairwise.PairwiseLlmRanker(ckpts[ck], ckpts[ck], device="cpu", method=method, batch_size=bs, k=k)
+            log = []
+            orig = rk.compare
+
+            def logged(query, docs, _o=orig, _l=log):
+                out = _o(query, docs)
+                _l.append([list(docs), list(out)])
+                return out
+
+            rk.compare = logged
+            for qi, q in enumerate(queries):
+                ranking = [ref_rankers.SearchResult(docid=f"P{4 * qi + i}", score=float(30 - i), text=doc_pool[(4 * qi + i) % 20])
+                           for i in range(n)]
+                inp = [[r.docid, r.score, r.text] for r in ranking]
+                del log[:]
+                res = rk.rerank(q, ranking)
+                cases.append({"kind": "pairwise", "ckpt": ck, "method": method, "batch_size": bs, "k": k, "query": q,
+                              "input": inp, "result": [[r.docid, r.score] for r in res], "compares": list(log),
+                              "caller_list_after": [r.docid for r in ranking],
+                              "counters": [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens]})
+    with open(os.path.join(GOLD, "pairwise_cases.json"), "w") as f:
+        json.dump({"cases": cases}, f)
+    outs = [o for c in cases for _, out in c["compares"] for o in out]
+    print(f"[pairwise_cases] {len(cases)} cases, {len(outs)} logged generations, distinct: {sorted(set(outs))[:8]}")
+
+
+def add_pairwise():
+    """Incremental: pairwise fixtures on the existing checkpoint recipes, without regenerating the other fixtures."""
+    import tempfile
+    tok_dir = os.path.join(GOLD, "tok")
+    with open(os.path.join(GOLD, "ckpts.json")) as f:
+        specs = json.load(f)
+    tmp = tempfile.mkdtemp(prefix="rk_goldens_")
+    ckpts = {}
+    if "ckpt_abboost" not in specs:        # only 'A', 'B' and EOS boosted: generations are 'Passage A' / 'Passage B'
+        from transformers import T5Tokenizer
+        tok = T5Tokenizer.from_pretrained(tok_dir)
+        ab = [tok.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1] for c in "AB"]
+        specs["ckpt_abboost"] = {"dims": "toy-gated-untied", "seed": 31, "gain": 2.0, "boost_ids": ab, "boost": 8.0, "boost2_ids": [1], "boost2": 5.0}
+        specs["ckpt_abboost"]["sha256"] = write_ckpt(os.path.join(tmp, "ckpt_abboost"), specs["ckpt_abboost"], tok_dir)
+        with open(os.path.join(GOLD, "ckpts.json"), "w") as f:
+            json.dump(specs, f, indent=1)
+    for name in ("ckpt_abboost", "ckpt_gated_untied"):
+        ckpts[name] = os.path.join(tmp, name)
+        assert write_ckpt(ckpts[name], specs[name], tok_dir) == specs[name]["sha256"]
+    ref_rankers, _, _ = import_reference()
+    import llmrankers.pairwise as ref_pairwise
+    assert ref_pairwise.__file__.startswith(REF)
+    pairwise_goldens(ref_rankers, ref_pairwise, ckpts)
+    shutil.rmtree(tmp)
+
+
 def add_monot5():
     """Incremental: adds the monoT5 checkpoint recipe and cases without regenerating the other fixtures."""
     import tempfile
@@ -400,6 +465,8 @@ def config1_golden(ref_rankers, ref_pointwise, tok_dir):
 def main():
     if "--only-monot5" in sys.argv:
         return add_monot5()
+    if "--only-pairwise" in sys.argv:
+        return add_pairwise()
     if os.path.isdir(GOLD):
         shutil.rmtree(GOLD)
     os.makedirs(GOLD)
@@ -435,6 +502,15 @@ def main():
     with open(os.path.join(GOLD, "ckpts.json"), "w") as f:
         json.dump(specs, f, indent=1)
     monot5_goldens(ref_rankers, ref_pointwise, ck)
+    import llmrankers.pairwise as ref_pairwise
+    ab = [tok.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1] for c in "AB"]
+    spec = {"dims": "toy-gated-untied", "seed": 31, "gain": 2.0, "boost_ids": ab, "boost": 8.0, "boost2_ids": [1], "boost2": 5.0}
+    ckpts["ckpt_abboost"] = os.path.join(tmp, "ckpt_abboost")
+    spec["sha256"] = write_ckpt(ckpts["ckpt_abboost"], spec, tok_dir)
+    specs["ckpt_abboost"] = spec
+    with open(os.path.join(GOLD, "ckpts.json"), "w") as f:
+        json.dump(specs, f, indent=1)
+    pairwise_goldens(ref_rankers, ref_pairwise, ckpts)
     with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
         import transformers, torch
         json.dump({"generator": "tools/make_goldens.py", "reference": "ielab/llm-rankers @ /root/reference (2025-07-18)",
