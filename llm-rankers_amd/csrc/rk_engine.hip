@@ -103,6 +103,9 @@ struct rk_engine {
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
   double prof_flops[PC_COUNT] = {0}, prof_bytes[PC_COUNT] = {0}; int64_t prof_n[PC_COUNT] = {0};
+  // decoder chains as HIP graphs: key = everything the launch parameters of a chain depend on
+  struct GraphEntry { int seen = 0; bool failed = false; hipGraphExec_t exec = nullptr; };
+  std::map<std::vector<int>, GraphEntry> graphs; int opt_dec_graph = 1, opt_epoch = 0;
   // score collection across GPUs (K9): one RCCL communicator per engine = per process = per GPU
   ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;
   float* d_gather[RK_SLOTS] = {nullptr}; float* h_gather[RK_SLOTS] = {nullptr}; size_t gather_cap = 0;
@@ -635,6 +638,38 @@ int stage_slot(rk_engine* e, int slot, const int32_t* tokens, const int32_t* seq
   return RK_OK;
 }
 
+// The decoder chain of a call is ~300 dependent launches of kernels that run for a few microseconds each: issued eagerly
+// it is bound by the host's launch rate (about 10 us per launch end to end), replayed as ONE HIP graph by the GPU's own
+// dependent-kernel boundary (1-2 us).  `body` enqueues the chain on `st`; the second time a key is seen the chain is
+// captured, instantiated and cached, from then on it is replayed.  The key holds every value the launch parameters
+// depend on (shapes, options epoch); buffers are per-slot and never move.  Profiling runs stay eager (per-kernel events).
+template <class F>
+int run_graphed(rk_engine* e, hipStream_t st, std::vector<int> key, F&& body) {
+  key.push_back(e->opt_epoch);
+  if (!e->opt_dec_graph || e->prof_on) return body();
+  auto& g = e->graphs[key];
+  if (g.exec) { HIPCHK(e, hipGraphLaunch(g.exec, st)); return RK_OK; }
+  if (g.failed || g.seen++ == 0) return body();          // first sighting: eager (also does the one-off kernel attribute calls)
+  if (e->graphs.size() > 256) {                           // bounded cache: drop everything but this key's slot
+    for (auto& kv : e->graphs) if (kv.second.exec && &kv.second != &g) { hipGraphExecDestroy(kv.second.exec); kv.second.exec = nullptr; kv.second.seen = 0; }
+  }
+  hipGraph_t graph = nullptr;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); g.failed = true; return body(); }
+  const int rc = body();
+  const hipError_t ec = hipStreamEndCapture(st, &graph);
+  if (rc != RK_OK || ec != hipSuccess || !graph) {
+    (void)hipGetLastError();
+    if (graph) hipGraphDestroy(graph);
+    g.failed = true;
+    return rc != RK_OK ? rc : body();                     // nothing was executed during the capture: run it now
+  }
+  const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (ei != hipSuccess || !g.exec) { (void)hipGetLastError(); g.exec = nullptr; g.failed = true; return body(); }
+  HIPCHK(e, hipGraphLaunch(g.exec, st));
+  return RK_OK;
+}
+
 int score_slot(rk_engine* e, int slot, const int32_t* dec_prefix, int dec_len, const int32_t* out_token_ids, int n_out) {
   if (slot < 0 || slot >= RK_SLOTS) return fail(e, RK_ERR_INVALID, "slot %d out of range", slot);
   int rc = set_device(e);
@@ -656,13 +691,16 @@ int score_slot(rk_engine* e, int slot, const int32_t* dec_prefix, int dec_len, c
 #else
   constexpr bool skip_dec = false;
 #endif
-  if (!skip_dec && (rc = run_decoder(e, sl, dec_len))) return rc;
-  rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, sl.n_seq, head_scale(e));
-  {
+  rc = run_graphed(e, sd, {0, slot, sl.n_seq, dec_len, sl.have_cross_kv ? sl.maxL : (sl.maxL + 63) / 64, (int)sl.have_cross_kv, n_out, (int)skip_dec}, [&]() -> int {
+    int r = RK_OK;
+    if (!skip_dec && (r = run_decoder(e, sl, dec_len))) return r;
+    rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, sl.n_seq, head_scale(e));
     Bracket br(e, sd, PC_HEAD, 2.0 * sl.n_seq * n_out * e->d.d_model, 0);
     hipLaunchKernelGGL(head_rows_kernel, dim3((sl.n_seq * n_out + 3) / 4), dim3(256), 0, sd, sl.dlast, e->lm_head,
                        sl.d_out_ids, sl.d_scores, sl.n_seq, n_out, e->d.d_model);
-  }
+    return RK_OK;
+  });
+  if (rc) return rc;
   HIPCHK(e, hipMemcpyAsync(sl.h_scores, sl.d_scores, (size_t)sl.n_seq * n_out * sizeof(float), hipMemcpyDeviceToHost, sd));
   HIPCHK(e, hipGetLastError());
   sl.last_n_out = n_out;
@@ -779,6 +817,8 @@ void rk_engine_destroy(rk_engine* e) {
     if (sl.sd) hipStreamSynchronize(sl.sd);
   }
   comm_release(e);
+  for (auto& kv : e->graphs) if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+  e->graphs.clear();
   for (void* p : e->allocs) hipFree(p);
   if (e->logits) hipFree(e->logits);
   for (auto& sl : e->slots) {
@@ -1122,11 +1162,16 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
     HIPCHK(e, hipMemcpy(sl.d_dec_ids, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(sl.d_last_rows, rowmap.data(), n_seq * sizeof(int), hipMemcpyHostToDevice));
     sl.cache_dec.clear(); sl.cache_rows.clear();
-    if ((rc = run_decoder(e, sl, Ld))) return rc;
-    rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, n_seq, head_scale(e));
-    gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dlast, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, n_seq, e->d.vocab, e->d.d_model,
-         0, 0, 1.f, 1, 0, 0, 0, true);
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_seq), dim3(256), 0, sd, e->logits, e->d.vocab, e->d.vocab, sl.d_argmax);
+    rc = run_graphed(e, sd, {1, 0, n_seq, Ld, sl.have_cross_kv ? sl.maxL : (sl.maxL + 63) / 64, (int)sl.have_cross_kv, (int)(e->logits_cap / (size_t)e->d.vocab)}, [&]() -> int {
+      int r = run_decoder(e, sl, Ld);
+      if (r) return r;
+      rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, n_seq, head_scale(e));
+      gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dlast, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, n_seq, e->d.vocab, e->d.d_model,
+           0, 0, 1.f, 1, 0, 0, 0, true);
+      hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_seq), dim3(256), 0, sd, e->logits, e->d.vocab, e->d.vocab, sl.d_argmax);
+      return RK_OK;
+    });
+    if (rc) return rc;
     HIPCHK(e, hipMemcpyAsync(amax.data(), sl.d_argmax, n_seq * sizeof(int), hipMemcpyDeviceToHost, sd));
     HIPCHK(e, hipStreamSynchronize(sd));
     HIPCHK(e, hipGetLastError());
@@ -1287,6 +1332,8 @@ int rk_profile_get(rk_engine* e, int cls, double* total_ms, int64_t* launches, d
 
 int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!e || !key) return RK_ERR_INVALID;
+  e->opt_epoch++;                                             // cached decoder graphs were captured under the old options
+  if (!strcmp(key, "dec_graph")) { e->opt_dec_graph = value != 0; return RK_OK; }             // decoder chains replayed as HIP graphs (1) or launched eagerly (0)
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x1F : value; return RK_OK; }   // bit per epilogue kind
   if (!strcmp(key, "gemm_persistent")) { e->opt_gemm_persistent = value; return RK_OK; }   // ping-pong GEMM: 1 = one workgroup per CU walks the tiles

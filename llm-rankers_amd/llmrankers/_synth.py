@@ -96,9 +96,81 @@ TOY_RELU_TIED = T5Dims(vocab=256, d_model=128, n_heads=3, d_kv=64, d_ff=256, n_e
 # 1176 / 6136 the reference hard-codes (ref: llmrankers/pointwise.py:177-178)
 TOY_MONOT5 = T5Dims(vocab=6144, d_model=128, n_heads=3, d_kv=64, d_ff=256, n_enc=2, n_dec=2, gated=False, tied_head=True)
 
+@dataclass(frozen=True)
+class LlamaDims:
+    """Decoder-only Llama family (hf: models/llama/configuration_llama.py): RMSNorm, RoPE, grouped-query attention, SwiGLU."""
+    vocab: int
+    hidden: int
+    n_heads: int
+    n_kv_heads: int
+    head_dim: int
+    intermediate: int
+    n_layers: int
+    rope_theta: float = 500000.0
+    eps: float = 1e-5
+    tied_head: bool = False
+    bos_token_id: int = 1
+    eos_token_id: int = 2
+
+    def to_hf_config(self) -> dict:
+        return {
+            "architectures": ["LlamaForCausalLM"], "model_type": "llama", "vocab_size": self.vocab,
+            "hidden_size": self.hidden, "intermediate_size": self.intermediate, "num_hidden_layers": self.n_layers,
+            "num_attention_heads": self.n_heads, "num_key_value_heads": self.n_kv_heads, "head_dim": self.head_dim,
+            "hidden_act": "silu", "rms_norm_eps": self.eps, "rope_theta": self.rope_theta, "rope_scaling": None,
+            "max_position_embeddings": 8192, "attention_bias": False, "mlp_bias": False,
+            "tie_word_embeddings": bool(self.tied_head), "bos_token_id": self.bos_token_id, "eos_token_id": self.eos_token_id,
+            "use_cache": True,
+        }
+
+    @staticmethod
+    def from_hf_config(cfg: dict) -> "LlamaDims":
+        if cfg.get("hidden_act", "silu") != "silu" or cfg.get("attention_bias") or cfg.get("mlp_bias"):
+            raise NotImplementedError("only bias-free SwiGLU Llama configurations are supported by the MI355X engine")
+        rope = cfg.get("rope_parameters") or {}
+        scaling = cfg.get("rope_scaling") or ({k: v for k, v in rope.items() if k != "rope_theta"} if rope.get("rope_type", "default") != "default" else None)
+        if scaling and scaling.get("rope_type", scaling.get("type", "default")) != "default":
+            raise NotImplementedError(f"rope scaling {scaling} is not supported by the MI355X engine (Llama-3-8B uses plain RoPE)")
+        heads = cfg["num_attention_heads"]
+        eos = cfg.get("eos_token_id", 2)
+        return LlamaDims(vocab=cfg["vocab_size"], hidden=cfg["hidden_size"], n_heads=heads,
+                         n_kv_heads=cfg.get("num_key_value_heads") or heads,
+                         head_dim=cfg.get("head_dim") or cfg["hidden_size"] // heads,
+                         intermediate=cfg["intermediate_size"], n_layers=cfg["num_hidden_layers"],
+                         rope_theta=float(cfg.get("rope_theta") or rope.get("rope_theta") or 10000.0),
+                         eps=cfg.get("rms_norm_eps", 1e-6), tied_head=bool(cfg.get("tie_word_embeddings", False)),
+                         bos_token_id=cfg.get("bos_token_id", 1) or 1, eos_token_id=eos[0] if isinstance(eos, list) else eos)
+
+
+LLAMA_3_8B = LlamaDims(vocab=128256, hidden=4096, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, n_layers=32,
+                       bos_token_id=128000, eos_token_id=128001)
+# toy: kernel-friendly (head_dim 128 like every Llama-3), grouped-query (4 q heads on 2 kv heads), q width != hidden
+TOY_LLAMA = LlamaDims(vocab=256, hidden=256, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=512, n_layers=2)
+
+
+def llama_tensor_specs(d: "LlamaDims") -> Iterator[Tuple[str, Tuple[int, ...], float, bool]]:
+    """(hf_name, shape, std, is_norm_weight) of a LlamaForCausalLM checkpoint, in a fixed order."""
+    yield "model.embed_tokens.weight", (d.vocab, d.hidden), 1.0, False
+    for i in range(d.n_layers):
+        p = f"model.layers.{i}"
+        yield f"{p}.self_attn.q_proj.weight", (d.n_heads * d.head_dim, d.hidden), d.hidden ** -0.5, False
+        yield f"{p}.self_attn.k_proj.weight", (d.n_kv_heads * d.head_dim, d.hidden), d.hidden ** -0.5, False
+        yield f"{p}.self_attn.v_proj.weight", (d.n_kv_heads * d.head_dim, d.hidden), d.hidden ** -0.5, False
+        yield f"{p}.self_attn.o_proj.weight", (d.hidden, d.n_heads * d.head_dim), (d.n_heads * d.head_dim) ** -0.5, False
+        yield f"{p}.input_layernorm.weight", (d.hidden,), 0.1, True
+        yield f"{p}.mlp.gate_proj.weight", (d.intermediate, d.hidden), d.hidden ** -0.5, False
+        yield f"{p}.mlp.up_proj.weight", (d.intermediate, d.hidden), d.hidden ** -0.5, False
+        yield f"{p}.mlp.down_proj.weight", (d.hidden, d.intermediate), d.intermediate ** -0.5, False
+        yield f"{p}.post_attention_layernorm.weight", (d.hidden,), 0.1, True
+    yield "model.norm.weight", (d.hidden,), 0.1, True
+    if not d.tied_head:
+        yield "lm_head.weight", (d.vocab, d.hidden), d.hidden ** -0.5, False
+
+
 NAMED_DIMS = {
     "flan-t5-small": FLAN_T5_SMALL, "flan-t5-base": FLAN_T5_BASE, "flan-t5-large": FLAN_T5_LARGE,
     "flan-t5-xl": FLAN_T5_XL, "toy-gated-untied": TOY_GATED_UNTIED, "toy-relu-tied": TOY_RELU_TIED, "toy-monot5": TOY_MONOT5,
+    "llama-3-8b": LLAMA_3_8B, "toy-llama": TOY_LLAMA,
 }
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -179,11 +251,12 @@ def _make_tensor(args):
     return name, _fp16_round(out.reshape(shape))
 
 
-def synth_tensors(d: T5Dims, seed: int = 929, gain: float = 1.0, threads: int = 0) -> Iterator[Tuple[str, np.ndarray]]:
+def synth_tensors(d, seed: int = 929, gain: float = 1.0, threads: int = 0) -> Iterator[Tuple[str, np.ndarray]]:
     """Yield (hf_name, fp32 array with fp16-representable values).  A pure function of (dims, seed, gain):
     value i of tensor #s is Box-Muller(splitmix64 counters) — identical on every machine and thread count."""
+    specs = llama_tensor_specs(d) if isinstance(d, LlamaDims) else tensor_specs(d)
     jobs = [(stream, name, shape, std, is_norm, seed, gain)
-            for stream, (name, shape, std, is_norm) in enumerate(tensor_specs(d))]
+            for stream, (name, shape, std, is_norm) in enumerate(specs)]
     if threads <= 1:
         for j in jobs:
             yield _make_tensor(j)
@@ -194,7 +267,7 @@ def synth_tensors(d: T5Dims, seed: int = 929, gain: float = 1.0, threads: int = 
             yield res
 
 
-def synth_state_dict(d: T5Dims, seed: int = 929, gain: float = 1.0, threads: int = 0) -> Dict[str, np.ndarray]:
+def synth_state_dict(d, seed: int = 929, gain: float = 1.0, threads: int = 0) -> Dict[str, np.ndarray]:
     return dict(synth_tensors(d, seed, gain, threads))
 
 
@@ -222,7 +295,10 @@ def write_checkpoint(path: str, spec: dict, tokenizer_dir: str = None) -> None:
     os.makedirs(path, exist_ok=True)
     sd = synth_state_dict(dims, seed=spec["seed"], gain=spec.get("gain", 1.0))
     if spec.get("boost_ids"):
-        key = "shared.weight" if dims.tied_head else "lm_head.weight"
+        if isinstance(dims, LlamaDims):
+            key = "model.embed_tokens.weight" if dims.tied_head else "lm_head.weight"
+        else:
+            key = "shared.weight" if dims.tied_head else "lm_head.weight"
         w = sd[key].copy()
         ids = np.asarray(spec["boost_ids"], dtype=np.int64)
         w[ids] = _fp16_round(w[ids] * np.float32(spec["boost"]))

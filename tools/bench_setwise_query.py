@@ -41,7 +41,9 @@ def main():
     dims = _synth.FLAN_T5_LARGE
     eng = RkEngine(dims, 0, max_tokens=32768, max_seqs=16, max_dec_len=8)
     eng.load_state(_synth.synth_tensors(dims, seed=929, threads=min(32, os.cpu_count() or 8)))
+    eng.set_option("dec_graph", int(os.environ.get("RK_DEC_GRAPH", "1")))
     rt = EngineRuntime(eng, dims)
+    import bench
     rs = random.Random(3)
     vocab = [tok.convert_ids_to_tokens(i).replace("▁", "") for i in range(10, 200)]
     vocab = [w for w in vocab if w.isalpha()] or ["a", "b", "c"]
@@ -61,8 +63,11 @@ def main():
                 dt = time.perf_counter() - t0
                 best = dt if best is None else min(best, dt)
                 res0 = [r.docid for r in res][:10]
+            avg_len = rk.total_prompt_tokens / max(rk.total_compare, 1)
+            tf = rk.total_compare * bench.algorithmic_gflop_per_passage(dims, avg_len, 2) / 1e3 / best     # SURVEY 8d formula, L_d = 2
             out[f"{scoring}_{'batched' if batched else 'one_by_one'}"] = {
                 "ms_per_query": round(best * 1e3, 1), "compares": rk.total_compare,
+                "algorithmic_tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / 2500.0, 4),
                 "avg_prompt_tokens": round(rk.total_prompt_tokens / max(rk.total_compare, 1), 1), "top10": res0}
     for scoring in ("likelihood", "generation"):
         assert out[f"{scoring}_batched"]["top10"] == out[f"{scoring}_one_by_one"]["top10"], "batched build phase changed the ranking"
