@@ -100,6 +100,24 @@ int rk_t5_read_scores_slot(rk_engine* e, int slot, float* out_logits, int n_floa
 /* device address of the fp32 score buffer [n_seq][n_out] of the last rk_t5_score_staged (for RCCL gathers) */
 int rk_t5_scores_device_ptr(rk_engine* e, void** out_ptr);
 
+/* ---- decoder-only Llama family: the model call of the reference's setwise ranker for `model_type == 'llama'`
+ * (ref: llmrankers/setwise.py:60-69, 159-177): self.llm.generate(input_ids, do_sample=False, max_new_tokens=1) = prefill
+ * of the prompt + arg-max of the last position's logits.  hf: models/llama/modeling_llama.py (RMSNorm, RoPE with
+ * rope_theta, grouped-query causal attention with head_dim 128, SwiGLU).  Weights go through rk_engine_load_tensor with
+ * the HF Llama names ("model.layers.0.self_attn.q_proj.weight", ...) and rk_engine_finalize; rk_engine_destroy frees. */
+typedef struct rk_llama_desc {
+  int32_t vocab, hidden, n_heads, n_kv_heads, head_dim, intermediate, n_layers;
+  int32_t tied_head;                 /* tie_word_embeddings */
+  float eps, rope_theta;             /* rms_norm_eps, rope_theta (default rope type) */
+  int32_t max_tokens, max_seqs;      /* capacity: prompt tokens per call (sum), prompts per call */
+} rk_llama_desc;
+int rk_llama_create(const rk_llama_desc* desc, int device_ordinal, rk_engine** out);
+/* next token of every prompt: first arg-max over the whole vocabulary of the logits at its last position */
+int rk_llama_greedy1(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq, int32_t* out_tokens);
+/* the same logits for a few vocabulary rows only -> out_logits[n_seq][n_out] fp32 (label scoring, tests) */
+int rk_llama_last_logits(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq,
+                         const int32_t* out_token_ids, int n_out, float* out_logits);
+
 /* ---- score collection across the GPUs of one node: one process per GPU, one engine per process.
  * The reference has no counterpart (its multi-GPU mode is accelerate's layer placement, ref: pointwise.py:21); this
  * replaces the torch.distributed round trip of a data-parallel caller.  RCCL (librccl.so.1) is dlopen'ed on first use.

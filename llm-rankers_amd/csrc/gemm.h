@@ -19,7 +19,9 @@
 #include "common.h"
 #include <type_traits>
 
-enum GemmEpi { EPI_STORE_F16 = 0, EPI_RESID_F32 = 1, EPI_GEGLU_F16 = 2, EPI_RELU_F16 = 3, EPI_STORE_F32 = 4 };
+enum GemmEpi { EPI_STORE_F16 = 0, EPI_RESID_F32 = 1, EPI_GEGLU_F16 = 2, EPI_RELU_F16 = 3, EPI_STORE_F32 = 4, EPI_SWIGLU_F16 = 5 };
+// gated epilogues: gate / up rows interleaved in groups of 32 by the weight packer, out = act(gate) * up
+#define EPI_IS_GATED(E) ((E) == EPI_GEGLU_F16 || (E) == EPI_SWIGLU_F16)
 
 struct GemmArgs {
   const half_t* A;   // [M, K] activations, row stride lda (halfs)
@@ -53,6 +55,13 @@ __device__ __forceinline__ float gelu_new_f(float x) {
   // (the raw v_rcp_f32, 1 ulp: __frcp_rn expands to the ten-instruction IEEE division sequence on this target)
   return x * __builtin_amdgcn_rcpf(1.0f + __expf(u2));
 }
+
+__device__ __forceinline__ float silu_f(float x) {
+  // hf: activations.py SiLU (Llama's hidden_act): x * sigmoid(x), on the hardware exp2 / rcp like gelu_new_f
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+template <int EPI>
+__device__ __forceinline__ float gate_act(float x) { return EPI == EPI_SWIGLU_F16 ? silu_f(x) : gelu_new_f(x); }
 
 template <bool GLDS>
 __device__ __forceinline__ void gemm_stage_tile(half_t* s_tile, const half_t* g, int ld, int row0, int rows_total,
@@ -116,7 +125,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
   for (int mi = 0; mi < MI; ++mi) {
     const int m = mbase + mi * 32 + l31;
     if (m >= p.M) continue;
-    if (EPI == EPI_GEGLU_F16) {
+    if (EPI_IS_GATED(EPI)) {
       // acc[0] = gate rows, acc[1] = up rows of the same 32 output columns
       half_t* C = (half_t*)p.C;
 #pragma unroll
@@ -126,7 +135,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
         half4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          o[j] = f2h_sat(gelu_new_f(acc[0][mi][4 * q + j] * p.scale) * (acc[NI - 1][mi][4 * q + j] * p.scale));
+          o[j] = f2h_sat(gate_act<EPI>(acc[0][mi][4 * q + j] * p.scale) * (acc[NI - 1][mi][4 * q + j] * p.scale));
         *(half4*)(C + (size_t)m * p.ldc + col) = o;
       }
     } else {
@@ -206,7 +215,7 @@ template <int EPI, int NI, int MI, bool RESID_IN_ACC = false, int ROWS = 32, int
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase,
                                                      int lane, unsigned char* stage, const float (&rsc)[MI]) {
   const int l31 = lane & 31, hh = lane >> 5;
-  constexpr bool GEGLU = EPI == EPI_GEGLU_F16;
+  constexpr bool GEGLU = EPI_IS_GATED(EPI);
   constexpr bool F32 = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32;
   constexpr bool RMW = EPI == EPI_RESID_F32 && !RESID_IN_ACC;  // the old rows are read here (not pre-added by the caller)
   constexpr int COLS = GEGLU ? NI * 16 : NI * 32;            // output columns of this wave
@@ -267,7 +276,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
           half4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            o[j] = f2h_sat(gelu_new_f(acc[2 * g][mi][4 * q + j] * sc) * (acc[2 * g + 1][mi][4 * q + j] * sc));
+            o[j] = f2h_sat(gate_act<EPI>(acc[2 * g][mi][4 * q + j] * sc) * (acc[2 * g + 1][mi][4 * q + j] * sc));
           *(half4*)(myrow + (g * 32 + 8 * q + 4 * hh) * 2) = o;
         }
     } else {

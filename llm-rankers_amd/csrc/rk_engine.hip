@@ -23,6 +23,7 @@
 #include "../../include/rk_engine.h"
 #include "attention.h"
 #include "gemm.h"
+#include "llama_kernels.h"
 #include "misc_kernels.h"
 
 namespace {
@@ -52,6 +53,9 @@ struct DecLayerW {
   half_t* ov = nullptr;     // self-attention W_o W_v [d_model, d_model]: the whole sub-layer at L_d = 1
   float *ln0 = nullptr, *ln1 = nullptr, *ln2 = nullptr;
 };
+
+// Llama-family decoder layer (hf: modeling_llama.py:291-330): fused q|k|v and interleaved gate|up carry the RMSNorm weights
+struct LlamaLayerW { half_t *qkv_f = nullptr, *o = nullptr, *gu_f = nullptr, *down = nullptr; };
 
 struct ProfRec { hipEvent_t a, b; int cls; };
 
@@ -97,12 +101,16 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x1F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1;
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
   double prof_flops[PC_COUNT] = {0}, prof_bytes[PC_COUNT] = {0}; int64_t prof_n[PC_COUNT] = {0};
+  // decoder-only family (rk_llama_*): family 1 reuses `d` for the shared fields (vocab, d_model = hidden, d_ff =
+  // intermediate, eps, capacities) so that the helpers below serve both families
+  int family = 0; rk_llama_desc ld{};
+  std::vector<LlamaLayerW> ll; float *l_final_ln = nullptr, *rope_cos = nullptr, *rope_sin = nullptr; int* d_pos = nullptr;
   // decoder chains as HIP graphs: key = everything the launch parameters of a chain depend on
   struct GraphEntry { int seen = 0; bool failed = false; hipGraphExec_t exec = nullptr; };
   std::map<std::vector<int>, GraphEntry> graphs; int opt_dec_graph = 1, opt_epoch = 0;
@@ -213,12 +221,12 @@ void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
 // at M = 736 .. 23552, profiles/r01c_gemm_bench.txt, r01e_gemm_pingpong.txt).  All variants sum K in the same order, so
 // the choice never changes a result bit.  GEGLU pairs gate/up inside 64-row wave tiles: no 192-wide tile for it.
 int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_producer = false) {
-  if (e->opt_gemm_variant) return (e->opt_gemm_variant == 3 && (epi == EPI_GEGLU_F16 || fold_producer)) ? 2 : e->opt_gemm_variant;
+  if (e->opt_gemm_variant) return (e->opt_gemm_variant == 3 && (EPI_IS_GATED(epi) || fold_producer)) ? 2 : e->opt_gemm_variant;
   struct V { int id, bm, bn, slots; double round_us; };
   static const V vs[5] = {{5, 256, 256, 256, 25.5}, {2, 256, 256, 256, 29.8}, {3, 256, 192, 256, 24.7}, {4, 256, 128, 256, 19.0}, {1, 128, 128, 512, 17.3}};
   double best = 1e30; int bv = 1;
   for (const V& v : vs) {
-    if (v.id == 3 && (epi == EPI_GEGLU_F16 || fold_producer)) continue;   // (the folded-norm producer needs 64-column wave tiles)
+    if (v.id == 3 && (EPI_IS_GATED(epi) || fold_producer)) continue;   // (the folded-norm producer needs 64-column wave tiles)
     if (v.id == 5 && K < 128) continue;
     const long tiles = (long)((M + v.bm - 1) / v.bm) * ((N + v.bn - 1) / v.bn);
     const double cost = (double)((tiles + v.slots - 1) / v.slots) * v.round_us;
@@ -248,14 +256,14 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
   if (variant == 5 && a.K < 128) variant = 2;                       // the ping-pong kernel needs two K tiles
   if (variant == 5) {
     const int wgs = e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7);
-    if constexpr (EPI == EPI_STORE_F16 || EPI == EPI_GEGLU_F16 || EPI == EPI_RELU_F16) {
+    if constexpr (EPI == EPI_STORE_F16 || EPI_IS_GATED(EPI) || EPI == EPI_RELU_F16) {
       if (a.rowscale) { launch_pp2<EPI, 0, true>(st, a, wgs); return; }   // consumer side of the folded RMSNorm
     }
     launch_pp2<EPI>(st, a, wgs);
     return;
   }
   if (variant == 2) { launch_v2<EPI, 2, 4, 4, 2>(st, a); return; }
-  if (variant == 3 && EPI != EPI_GEGLU_F16) { launch_v2<EPI, 4, 2, 2, 3>(st, a); return; }
+  if constexpr (!EPI_IS_GATED(EPI)) { if (variant == 3) { launch_v2<EPI, 4, 2, 2, 3>(st, a); return; } }
   if (variant == 4) { launch_v2<EPI, 4, 2, 2, 2>(st, a); return; }
   // (a 16-wave 256x256 form, launch_v2<EPI, 4, 4, 2, 2>, measured 3-9 % slower than the 8-wave one: not instantiated)
   const int tiles = ((a.M + GEMM_BM - 1) / GEMM_BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
@@ -277,7 +285,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
   GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale, bsA, bsW, bsC};
   a.rowscale = fold.rowscale; a.xraw = fold.xraw; a.ssq = fold.ssq; a.ldx = N; a.nb = (N + 63) / 64; a.xs = RK_XRAW_SCALE;
   const double flops = 2.0 * M * (double)N * K * batch;
-  const double out_elems = (epi == EPI_GEGLU_F16) ? (double)M * N / 2 : (double)M * N;
+  const double out_elems = EPI_IS_GATED(epi) ? (double)M * N / 2 : (double)M * N;
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
                        out_elems * (epi == EPI_RESID_F32 ? 8.0 : (epi == EPI_STORE_F32 ? 4.0 : 2.0));
   Bracket br(e, st, cls, flops, bytes);
@@ -293,6 +301,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
       case EPI_STORE_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F16, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
       case EPI_RESID_F32: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RESID_F32, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
       case EPI_GEGLU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_GEGLU_F16, 2>), dim3((N + 63) / 64, gy, gz), b, 0, st, a); break;
+      case EPI_SWIGLU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_SWIGLU_F16, 2>), dim3((N + 63) / 64, gy, gz), b, 0, st, a); break;
       case EPI_RELU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RELU_F16, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
       default: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F32, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
     }
@@ -302,6 +311,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
     case EPI_STORE_F16: launch_gemm_epi<EPI_STORE_F16>(e, st, a); break;
     case EPI_RESID_F32: launch_gemm_epi<EPI_RESID_F32>(e, st, a); break;
     case EPI_GEGLU_F16: launch_gemm_epi<EPI_GEGLU_F16>(e, st, a); break;
+    case EPI_SWIGLU_F16: launch_gemm_epi<EPI_SWIGLU_F16>(e, st, a); break;
     case EPI_RELU_F16: launch_gemm_epi<EPI_RELU_F16>(e, st, a); break;
     default: launch_gemm_epi<EPI_STORE_F32>(e, st, a); break;
   }
@@ -624,6 +634,7 @@ int upload_dec_ids_shared(rk_engine* e, Slot& sl, const int32_t* prefix, int Ld)
 
 int stage_slot(rk_engine* e, int slot, const int32_t* tokens, const int32_t* seq_offsets, int n_seq) {
   if (slot < 0 || slot >= RK_SLOTS) return fail(e, RK_ERR_INVALID, "slot %d out of range", slot);
+  if (e->family != 0) return fail(e, RK_ERR_STATE, "T5 entry point called on a Llama engine (use rk_llama_*)");
   int rc = set_device(e);
   if (rc) return rc;
   Slot& sl = e->slots[slot];
@@ -866,11 +877,14 @@ int rk_engine_load_tensor(rk_engine* e, const char* hf_name, const void* data, i
   return RK_OK;
 }
 
+static int llama_finalize(rk_engine* e);
+
 int rk_engine_finalize(rk_engine* e) {
   if (!e) return RK_ERR_INVALID;
   if (e->finalized) return fail(e, RK_ERR_STATE, "already finalized");
   int rc = set_device(e);
   if (rc) return rc;
+  if (e->family == 1) return llama_finalize(e);
   const rk_model_desc& d = e->d;
   const int I = e->inner, dm = d.d_model, F = d.d_ff, V = d.vocab;
   std::string missing;
@@ -1046,7 +1060,7 @@ int rk_engine_finalize(rk_engine* e) {
 #define GEMM_ATTR(EPI)                                                                                              \
   (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES); \
   (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-  GEMM_ATTR(EPI_STORE_F16) GEMM_ATTR(EPI_RESID_F32) GEMM_ATTR(EPI_GEGLU_F16) GEMM_ATTR(EPI_RELU_F16) GEMM_ATTR(EPI_STORE_F32)
+  GEMM_ATTR(EPI_STORE_F16) GEMM_ATTR(EPI_RESID_F32) GEMM_ATTR(EPI_GEGLU_F16) GEMM_ATTR(EPI_RELU_F16) GEMM_ATTR(EPI_STORE_F32) GEMM_ATTR(EPI_SWIGLU_F16)
 #undef GEMM_ATTR
   (void)hipGetLastError();
   HIPCHK(e, hipDeviceSynchronize());
@@ -1193,6 +1207,198 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
   return RK_OK;
 }
 
+// =============================================== Llama family ================================================
+// Decoder-only setwise scoring (ref: llmrankers/setwise.py:60-69, 159-177): prefill of the whole prompt, then the
+// arg-max of the last position's logits (generate(max_new_tokens=1, do_sample=False)).  hf: models/llama/modeling_llama.py.
+int rk_llama_create(const rk_llama_desc* desc, int device_ordinal, rk_engine** out) {
+  if (!desc || !out) return fail(nullptr, RK_ERR_INVALID, "null argument");
+  *out = nullptr;
+  const rk_llama_desc& l = *desc;
+  if (l.head_dim != 128) return fail(nullptr, RK_ERR_INVALID, "head_dim=%d unsupported: the gfx950 causal attention kernel is built for head_dim=128", l.head_dim);
+  if (l.n_kv_heads <= 0 || l.n_heads % l.n_kv_heads) return fail(nullptr, RK_ERR_INVALID, "n_heads must be a multiple of n_kv_heads");
+  if (l.hidden % 64 || l.intermediate % 64 || l.vocab % 4 || l.hidden > 4096) return fail(nullptr, RK_ERR_INVALID, "hidden / intermediate must be multiples of 64 (hidden <= 4096), vocab of 4");
+  if (l.max_tokens <= 0 || l.max_seqs <= 0 || l.n_layers <= 0) return fail(nullptr, RK_ERR_INVALID, "capacities and layer count must be positive");
+  rk_model_desc d{};
+  d.vocab = l.vocab; d.d_model = l.hidden; d.n_heads = l.n_heads; d.d_kv = 64; d.d_ff = l.intermediate;   // d_kv only passes the T5 checks
+  d.n_enc_layers = l.n_layers; d.n_dec_layers = 1; d.n_buckets = 32; d.max_distance = 128; d.gated_gelu = 1; d.tied_head = l.tied_head;
+  d.eps = l.eps; d.max_tokens = l.max_tokens; d.max_seqs = l.max_seqs; d.max_dec_len = 1;
+  if ((long)d.n_heads * 64 % 64) return fail(nullptr, RK_ERR_INVALID, "bad head count");
+  int rc = rk_engine_create(&d, device_ordinal, out);
+  if (rc) return rc;
+  (*out)->family = 1; (*out)->ld = l; (*out)->inner = l.n_heads * l.head_dim;
+  return RK_OK;
+}
+
+static int llama_finalize(rk_engine* e) {
+  const rk_llama_desc& l = e->ld;
+  const int dm = l.hidden, Q = l.n_heads * 128, KV = l.n_kv_heads * 128, F = l.intermediate, V = l.vocab;
+  std::string missing;
+  auto N2 = [&](const std::string& n, int64_t r, int64_t c) { return need(e, n, r, c, &missing); };
+  auto N1 = [&](const std::string& n, int64_t r) { return need(e, n, r, -1, &missing); };
+  N2("model.embed_tokens.weight", V, dm);
+  if (!l.tied_head) N2("lm_head.weight", V, dm);
+  N1("model.norm.weight", dm);
+  for (int i = 0; i < l.n_layers; ++i) {
+    const std::string p = "model.layers." + std::to_string(i);
+    N2(p + ".self_attn.q_proj.weight", Q, dm); N2(p + ".self_attn.k_proj.weight", KV, dm); N2(p + ".self_attn.v_proj.weight", KV, dm);
+    N2(p + ".self_attn.o_proj.weight", dm, Q);
+    N2(p + ".mlp.gate_proj.weight", F, dm); N2(p + ".mlp.up_proj.weight", F, dm); N2(p + ".mlp.down_proj.weight", dm, F);
+    N1(p + ".input_layernorm.weight", dm); N1(p + ".post_attention_layernorm.weight", dm);
+  }
+  if (!missing.empty()) return fail(e, RK_ERR_MISSING, "missing or mis-shaped tensors: %s", missing.c_str());
+  auto H = [&](const std::string& n) -> const std::vector<half_t>& { return e->host[n].h; };
+  auto Fv = [&](const std::string& n) -> const std::vector<float>& { return e->host[n].f; };
+  int rc = RK_OK;
+#define RC(x) do { rc = (x); if (rc) return rc; } while (0)
+  RC(upload(e, &e->emb, H("model.embed_tokens.weight").data(), H("model.embed_tokens.weight").size()));
+  if (l.tied_head) e->lm_head = e->emb; else RC(upload(e, &e->lm_head, H("lm_head.weight").data(), H("lm_head.weight").size()));
+  RC(upload(e, &e->l_final_ln, Fv("model.norm.weight").data(), (size_t)dm));
+  e->ll.resize(l.n_layers);
+  std::vector<half_t> buf;
+  for (int i = 0; i < l.n_layers; ++i) {
+    const std::string p = "model.layers." + std::to_string(i);
+    LlamaLayerW& w = e->ll[i];
+    {   // q | k | v rows with the input RMSNorm weight folded into the columns
+      const auto& ln = Fv(p + ".input_layernorm.weight");
+      buf.resize((size_t)(Q + 2 * KV) * dm);
+      size_t r0 = 0;
+      for (const char* m : {"q_proj", "k_proj", "v_proj"}) {
+        const auto& src = H(p + ".self_attn." + m + ".weight");
+        const size_t rows = src.size() / dm;
+        for (size_t r = 0; r < rows; ++r)
+          for (int k = 0; k < dm; ++k) buf[(r0 + r) * dm + k] = (half_t)((float)src[r * dm + k] * ln[k]);
+        r0 += rows;
+      }
+      RC(upload(e, &w.qkv_f, buf.data(), buf.size()));
+    }
+    RC(upload(e, &w.o, H(p + ".self_attn.o_proj.weight").data(), (size_t)dm * Q));
+    {   // gate | up interleaved in groups of 32 rows (the SwiGLU epilogue pairs them in one lane), post-attention norm folded
+      const auto& ln = Fv(p + ".post_attention_layernorm.weight");
+      const auto& g = H(p + ".mlp.gate_proj.weight"); const auto& u = H(p + ".mlp.up_proj.weight");
+      buf.resize((size_t)2 * F * dm);
+      for (int blk = 0; blk < F / 32; ++blk)
+        for (int r = 0; r < 32; ++r)
+          for (int k = 0; k < dm; ++k) {
+            buf[((size_t)blk * 64 + r) * dm + k] = (half_t)((float)g[((size_t)blk * 32 + r) * dm + k] * ln[k]);
+            buf[((size_t)blk * 64 + 32 + r) * dm + k] = (half_t)((float)u[((size_t)blk * 32 + r) * dm + k] * ln[k]);
+          }
+      RC(upload(e, &w.gu_f, buf.data(), buf.size()));
+    }
+    RC(upload(e, &w.down, H(p + ".mlp.down_proj.weight").data(), (size_t)dm * F));
+  }
+  e->host.clear();
+  {   // rotary tables, float32 like hf: modeling_llama.py:94-127 (default rope type): freq_i = theta^(-2i/128)
+    const size_t Tc = l.max_tokens;
+    std::vector<float> c(Tc * 64), sn(Tc * 64);
+    for (int i = 0; i < 64; ++i) {
+      const float inv = 1.0f / powf(l.rope_theta, (float)(2 * i) / 128.0f);
+      for (size_t t = 0; t < Tc; ++t) { const float a = (float)t * inv; c[t * 64 + i] = cosf(a); sn[t * 64 + i] = sinf(a); }
+    }
+    RC(upload(e, &e->rope_cos, c.data(), c.size())); RC(upload(e, &e->rope_sin, sn.data(), sn.size()));
+  }
+  const size_t Tc = l.max_tokens, Bc = l.max_seqs;
+  Slot& sl = e->slots[0];
+  RC(dalloc(e, &sl.hidden, Tc * dm)); RC(dalloc(e, &sl.xraw, Tc * dm)); RC(dalloc(e, &sl.ssq, Tc * ((dm + 63) / 64)));
+  RC(dalloc(e, &sl.rowscale, Tc + 512)); HIPCHK(e, hipMemset(sl.rowscale, 0, (Tc + 512) * sizeof(float)));
+  RC(dalloc(e, &sl.qkv, Tc * (Q + 2 * KV))); RC(dalloc(e, &sl.ctx, Tc * Q)); RC(dalloc(e, &sl.ffh, Tc * F));
+  RC(dalloc(e, &sl.d_tokens, Tc)); RC(dalloc(e, &e->d_pos, Tc)); RC(dalloc(e, &sl.d_seq_off, Bc + 1));
+  RC(dalloc(e, &sl.d_last_rows, Bc)); RC(dalloc(e, &sl.d_out_ids, 8192)); RC(dalloc(e, &sl.d_argmax, Bc)); RC(dalloc(e, &sl.dlast, Bc * dm));
+  e->scores_cap = Bc * 64;
+  RC(dalloc(e, &sl.d_scores, e->scores_cap));
+  HIPCHK(e, hipHostMalloc((void**)&sl.h_scores, e->scores_cap * sizeof(float), hipHostMallocDefault));
+  HIPCHK(e, hipHostMalloc((void**)&sl.h_small, 4 * 8192 * sizeof(int), hipHostMallocDefault));
+#undef RC
+  HIPCHK(e, hipDeviceSynchronize());
+  e->finalized = true;
+  return RK_OK;
+}
+
+// prefill of the ragged batch; leaves the final-normed LAST hidden state of every sequence in sl.dlast [n_seq, hidden]
+static int llama_prefill(rk_engine* e, const int32_t* tokens, const int32_t* off, int n_seq) {
+  if (!e || e->family != 1) return fail(e, RK_ERR_STATE, "not a Llama engine");
+  int rc = set_device(e);
+  if (rc) return rc;
+  Slot& sl = e->slots[0];
+  if ((rc = check_batch(e, sl, tokens, off, n_seq))) return rc;
+  const rk_llama_desc& l = e->ld;
+  const int T = sl.T, dm = l.hidden, Q = l.n_heads * 128, KV = l.n_kv_heads * 128, F = l.intermediate, ldq = Q + 2 * KV;
+  hipStream_t st = sl.se;
+  HIPCHK(e, hipStreamSynchronize(st));
+  std::vector<int> pos(T), last(n_seq);
+  for (int b = 0; b < n_seq; ++b) {
+    for (int t = off[b]; t < off[b + 1]; ++t) pos[t] = t - off[b];
+    last[b] = off[b + 1] - 1;
+  }
+  HIPCHK(e, hipMemcpy(sl.d_tokens, tokens, (size_t)T * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(e->d_pos, pos.data(), (size_t)T * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(sl.d_seq_off, off, (size_t)(n_seq + 1) * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(sl.d_last_rows, last.data(), (size_t)n_seq * sizeof(int), hipMemcpyHostToDevice));
+  GemmFold cons, prod;
+  cons.rowscale = sl.rowscale; prod.xraw = sl.xraw; prod.ssq = sl.ssq;
+  embed(e, st, sl.d_tokens, sl.hidden, T, sl.xraw, sl.rowscale);
+  const float scale_log2e = (1.0f / std::sqrt(128.0f)) * 1.4426950408889634f;
+  for (int i = 0; i < l.n_layers; ++i) {
+    const LlamaLayerW& w = e->ll[i];
+    gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xraw, dm, w.qkv_f, dm, sl.qkv, ldq, T, ldq, dm, 0, 0, 1.f, 1, 0, 0, 0, false, cons);
+    {
+      Bracket br(e, st, PC_OTHER, 0, (double)T * (Q + KV) * 4.0);
+      hipLaunchKernelGGL(rope128_kernel, dim3(T), dim3(256), 0, st, sl.qkv, e->d_pos, e->rope_cos, e->rope_sin, ldq, l.n_heads + l.n_kv_heads);
+    }
+    {
+      AttnCausalArgs a{sl.qkv, sl.ctx, sl.d_seq_off, ldq, Q, l.n_heads, l.n_kv_heads, scale_log2e};
+      Bracket br(e, st, PC_ENC_ATTN, 2.0 * (double)sl.maxL * T * Q, (double)T * (2 * Q + 2 * KV) * 2.0);   // causal: half of 4 L T Q
+      hipLaunchKernelGGL(attn_causal128_kernel, dim3((sl.maxL + 127) / 128, l.n_heads, n_seq), dim3(256), 0, st, a);
+    }
+    gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, Q, w.o, Q, sl.hidden, dm, T, dm, Q, 0, 0, 1.f, 1, 0, 0, 0, false, prod);
+    rowscale(e, st, sl.ssq, sl.rowscale, T);
+    gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_SWIGLU_F16, sl.xraw, dm, w.gu_f, dm, sl.ffh, F, T, 2 * F, dm, 0, 0, 1.f, 1, 0, 0, 0, false, cons);
+    const bool lastl = i + 1 == l.n_layers;
+    gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, sl.ffh, F, w.down, F, sl.hidden, dm, T, dm, F, 0, 0, 1.f, 1, 0, 0, 0, false, lastl ? GemmFold() : prod);
+    if (!lastl) rowscale(e, st, sl.ssq, sl.rowscale, T);
+  }
+  rmsnorm(e, st, sl.hidden, e->l_final_ln, sl.dlast, sl.d_last_rows, n_seq);
+  HIPCHK(e, hipGetLastError());
+  return RK_OK;
+}
+
+int rk_llama_last_logits(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq,
+                         const int32_t* out_token_ids, int n_out, float* out_logits) {
+  if (!e || !out_logits) return RK_ERR_INVALID;
+  if (!out_token_ids || n_out <= 0 || n_out > 64) return fail(e, RK_ERR_INVALID, "n_out must be in 1..64 (got %d)", n_out);
+  int rc = check_ids(e, out_token_ids, n_out, "output");
+  if (rc) return rc;
+  if ((rc = llama_prefill(e, tokens, seq_offsets, n_seq))) return rc;
+  Slot& sl = e->slots[0];
+  hipStream_t st = sl.se;
+  HIPCHK(e, hipMemcpyAsync(sl.d_out_ids, out_token_ids, n_out * sizeof(int), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(head_rows_kernel, dim3((n_seq * n_out + 3) / 4), dim3(256), 0, st, sl.dlast, e->lm_head, sl.d_out_ids,
+                     sl.d_scores, n_seq, n_out, e->ld.hidden);
+  HIPCHK(e, hipMemcpyAsync(sl.h_scores, sl.d_scores, (size_t)n_seq * n_out * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIPCHK(e, hipStreamSynchronize(st));
+  HIPCHK(e, hipGetLastError());
+  memcpy(out_logits, sl.h_scores, (size_t)n_seq * n_out * sizeof(float));
+  return RK_OK;
+}
+
+int rk_llama_greedy1(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq, int32_t* out_tokens) {
+  if (!e || !out_tokens) return RK_ERR_INVALID;
+  int rc = llama_prefill(e, tokens, seq_offsets, n_seq);
+  if (rc) return rc;
+  if ((rc = ensure_logits(e, n_seq))) return rc;
+  Slot& sl = e->slots[0];
+  hipStream_t st = sl.se;
+  // full-vocabulary head on the n_seq last rows: weight-streaming GEMM, then the first arg-max (torch.argmax tie rule)
+  gemm(e, st, PC_HEAD, EPI_STORE_F32, sl.dlast, e->ld.hidden, e->lm_head, e->ld.hidden, e->logits, e->ld.vocab, n_seq, e->ld.vocab, e->ld.hidden,
+       0, 0, 1.f, 1, 0, 0, 0, true);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_seq), dim3(256), 0, st, e->logits, e->ld.vocab, e->ld.vocab, sl.d_argmax);
+  std::vector<int> amax(n_seq);
+  HIPCHK(e, hipMemcpyAsync(amax.data(), sl.d_argmax, n_seq * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(e, hipStreamSynchronize(st));
+  HIPCHK(e, hipGetLastError());
+  for (int b = 0; b < n_seq; ++b) out_tokens[b] = amax[b];
+  return RK_OK;
+}
+
 // ---- K9: score collection across the GPUs of a node, RCCL over xGMI, straight from the slot's device score buffer --
 int rk_comm_unique_id(uint8_t* out_id, int n_bytes) {
   if (!out_id || n_bytes != RK_COMM_ID_BYTES) return fail(nullptr, RK_ERR_INVALID, "unique id buffer must be %d bytes", RK_COMM_ID_BYTES);
@@ -1335,7 +1541,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   e->opt_epoch++;                                             // cached decoder graphs were captured under the old options
   if (!strcmp(key, "dec_graph")) { e->opt_dec_graph = value != 0; return RK_OK; }             // decoder chains replayed as HIP graphs (1) or launched eagerly (0)
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
-  if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x1F : value; return RK_OK; }   // bit per epilogue kind
+  if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x3F : value; return RK_OK; }   // bit per epilogue kind
   if (!strcmp(key, "gemm_persistent")) { e->opt_gemm_persistent = value; return RK_OK; }   // ping-pong GEMM: 1 = one workgroup per CU walks the tiles
   if (!strcmp(key, "fold_norm")) { e->opt_fold_norm = value != 0; return RK_OK; }           // encoder RMSNorm folded into the GEMMs (1) or separate kernels (0)
 #ifdef RK_MEASURE
@@ -1394,7 +1600,7 @@ int rk_debug_gemm_bench(rk_engine* e, int M, int N, int K, int epi, int iters, f
     HIPCHK(e, hipMemcpy(dW, h.data(), nw * 2, hipMemcpyHostToDevice));
     HIPCHK(e, hipMemset(dC, 0, nc * 4));
   }
-  const int ldc = (epi == EPI_GEGLU_F16) ? N / 2 : N;
+  const int ldc = EPI_IS_GATED(epi) ? N / 2 : N;
   for (int i = 0; i < 2; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, K, dW, K, dC, ldc, M, N, K);
   HIPCHK(e, hipEventRecord(e->t0, e->slots[0].se));
   for (int i = 0; i < iters; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, K, dW, K, dC, ldc, M, N, K);

@@ -30,6 +30,12 @@ class RkModelDesc(C.Structure):
                [("eps", C.c_float)] + [(n, C.c_int32) for n in ("max_tokens", "max_seqs", "max_dec_len")]
 
 
+class RkLlamaDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab", "hidden", "n_heads", "n_kv_heads", "head_dim", "intermediate", "n_layers",
+                                         "tied_head")] + [("eps", C.c_float), ("rope_theta", C.c_float)] + \
+               [(n, C.c_int32) for n in ("max_tokens", "max_seqs")]
+
+
 # name -> (restype, argtypes); this table is also what tests check against include/rk_engine.h
 _P = C.POINTER
 _i32p, _f32p = _P(C.c_int32), _P(C.c_float)
@@ -51,6 +57,9 @@ ABI = {
     "rk_t5_read_scores_slot": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.c_int]),
     "rk_t5_read_scores": (C.c_int, [C.c_void_p, _f32p, C.c_int]),
     "rk_t5_scores_device_ptr": (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
+    "rk_llama_create": (C.c_int, [_P(RkLlamaDesc), C.c_int, _P(C.c_void_p)]),
+    "rk_llama_greedy1": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, _i32p]),
+    "rk_llama_last_logits": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, _i32p, C.c_int, _f32p]),
     "rk_comm_unique_id": (C.c_int, [_P(C.c_uint8), C.c_int]),
     "rk_comm_init": (C.c_int, [C.c_void_p, _P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int]),
     "rk_comm_world": (C.c_int, [C.c_void_p, _i32p, _i32p]),
@@ -318,6 +327,41 @@ class RkEngine:
         if got < 0:
             self._chk(int(got))
         return out[:got]
+
+
+class RkLlamaEngine(RkEngine):
+    """Decoder-only engine (rk_llama_*): prefill + last-position logits.  Shares weight loading, options, profiling and
+    lifetime with RkEngine; the T5 entry points refuse it."""
+
+    def __init__(self, dims, device: int = 0, max_tokens: int = 16384, max_seqs: int = 16):
+        self.lib = load_library()
+        self.dims = dims
+        self.desc = RkLlamaDesc(vocab=dims.vocab, hidden=dims.hidden, n_heads=dims.n_heads, n_kv_heads=dims.n_kv_heads,
+                                head_dim=dims.head_dim, intermediate=dims.intermediate, n_layers=dims.n_layers,
+                                tied_head=int(dims.tied_head), eps=dims.eps, rope_theta=dims.rope_theta,
+                                max_tokens=max_tokens, max_seqs=max_seqs)
+        h = C.c_void_p()
+        rc = self.lib.rk_llama_create(C.byref(self.desc), device, C.byref(h))
+        if rc != 0:
+            raise RkError(rc, (self.lib.rk_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+        self.comm_rank, self.comm_world = 0, 1
+
+    def greedy1(self, seqs: Sequence[Sequence[int]]) -> np.ndarray:
+        tok, off = pack_ragged(seqs)
+        out = np.empty(len(seqs), dtype=np.int32)
+        self._chk(self.lib.rk_llama_greedy1(self.h, tok.ctypes.data_as(_i32p), off.ctypes.data_as(_i32p), len(seqs),
+                                            out.ctypes.data_as(_i32p)))
+        return out
+
+    def last_logits(self, seqs: Sequence[Sequence[int]], out_ids: Sequence[int]) -> np.ndarray:
+        tok, off = pack_ragged(seqs)
+        oi = _i32(out_ids)
+        out = np.empty((len(seqs), len(oi)), dtype=np.float32)
+        self._chk(self.lib.rk_llama_last_logits(self.h, tok.ctypes.data_as(_i32p), off.ctypes.data_as(_i32p), len(seqs),
+                                                oi.ctypes.data_as(_i32p), len(oi), out.ctypes.data_as(_f32p)))
+        return out
 
 
 def rel_bucket(rel: int, bidirectional: bool, num_buckets: int = 32, max_distance: int = 128) -> int:

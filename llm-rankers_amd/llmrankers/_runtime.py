@@ -14,7 +14,7 @@ from typing import Iterator, List, Sequence, Tuple
 import numpy as np
 
 from . import _synth
-from ._engine import RkEngine
+from ._engine import RkEngine, RkLlamaEngine
 
 
 def parse_device(device) -> int:
@@ -213,3 +213,50 @@ class T5Runtime:
             toks[:, steps:] = -1
             parts.append(toks)
         return np.concatenate(parts, axis=0)
+
+
+class LlamaRuntime:
+    """Decoder-only (Llama family) counterpart of T5Runtime: checkpoint directory -> rk_llama_* engine.  Replaces
+    `AutoModelForCausalLM.from_pretrained(..., device_map='auto', torch_dtype=fp16)` of ref: llmrankers/setwise.py:65-69."""
+
+    def __init__(self, model_name_or_path: str, device, max_tokens: int = 32768, max_seqs: int = 16, cache_dir=None):
+        model_name_or_path = resolve_checkpoint(model_name_or_path, cache_dir)
+        cfg = read_config(model_name_or_path)
+        self.model_type = cfg.get("model_type")
+        if self.model_type != "llama":
+            raise NotImplementedError(f"Model type {self.model_type} is not supported yet by the MI355X engine")
+        self.config = cfg
+        self.dims = _synth.LlamaDims.from_hf_config(cfg)
+        self.max_tokens, self.max_seqs = max_tokens, max_seqs
+        self.engine = RkLlamaEngine(self.dims, parse_device(device), max_tokens, max_seqs)
+        self.engine.load_state(iter_checkpoint_tensors(model_name_or_path))
+
+    @classmethod
+    def from_engine(cls, engine: RkLlamaEngine, dims=None) -> "LlamaRuntime":
+        self = cls.__new__(cls)
+        self.dims = dims if dims is not None else engine.dims
+        self.config, self.model_type = self.dims.to_hf_config(), "llama"
+        self.max_tokens, self.max_seqs = int(engine.desc.max_tokens), int(engine.desc.max_seqs)
+        self.engine = engine
+        return self
+
+    _chunks = T5Runtime._chunks
+
+    def greedy1(self, seqs) -> np.ndarray:
+        """next token (first arg-max of the last position's logits) of every prompt"""
+        return np.concatenate([self.engine.greedy1(c) for c in self._chunks(seqs)], axis=0)
+
+    def last_logits(self, seqs, out_ids) -> np.ndarray:
+        return np.concatenate([self.engine.last_logits(c, out_ids) for c in self._chunks(seqs)], axis=0)
+
+
+def load_runtime(model_name_or_path: str, device, cache_dir=None):
+    """T5Runtime or LlamaRuntime by the checkpoint's config.model_type (ref: setwise.py:40-71 dispatches the same way);
+    anything else raises NotImplementedError like the reference."""
+    path = resolve_checkpoint(model_name_or_path, cache_dir)
+    mt = read_config(path).get("model_type")
+    if mt == "t5":
+        return T5Runtime(path, device, cache_dir=cache_dir)
+    if mt == "llama":
+        return LlamaRuntime(path, device, cache_dir=cache_dir)
+    raise NotImplementedError(f"Model type {mt} is not supported yet by the MI355X engine")

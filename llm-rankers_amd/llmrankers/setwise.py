@@ -4,8 +4,8 @@ Drop-in for ref: llmrankers/setwise.py:21-316 (SetwiseLlmRanker) — same constr
 counters, fallbacks for malformed model output and result assembly.  Each compare is one encoder pass over a
 single long prompt plus either two greedy decoder steps (`scoring='generation'`, engine call rk_t5_greedy) or
 one label-row read at decoder position 1 (`scoring='likelihood'`, rk_t5_score with the 23 label ids).
-Llama-family models (ref: setwise.py:60-69,159-177) are not built yet: NotImplementedError, as the reference
-raises for unknown model types.
+Llama-family models (ref: setwise.py:60-69,159-177): chat-template prompt + " Passage:", prefill and ONE greedy token
+(rk_llama_greedy1); `likelihood` scoring raises NotImplementedError for them exactly as in the reference.
 """
 import copy
 import random
@@ -19,6 +19,16 @@ from .rankers import LlmRanker, SearchResult
 
 random.seed(929)   # same import-time seeding as the reference (ref: setwise.py:18): permutation voting depends on it
 
+# the chat template the reference installs for vicuna-v1.5 checkpoints (ref: setwise.py:63-64) — data, quoted as is
+VICUNA_TEMPLATE = ("{% if messages[0]['role'] == 'system' %}{% set loop_messages = messages[1:] %}{% set system_message = messages[0]['content'] %}"
+                   "{% else %}{% set loop_messages = messages %}{% set system_message = 'A chat between a curious user and an artificial intelligence "
+                   "assistant. The assistant gives helpful, detailed, and polite answers to the user\\'s questions.' %}{% endif %}"
+                   "{% for message in loop_messages %}{% if (message['role'] == 'user') != (loop.index0 % 2 == 0) %}"
+                   "{{ raise_exception('Conversation roles must alternate user/assistant/user/assistant/...') }}{% endif %}"
+                   "{% if loop.index0 == 0 %}{{ system_message }}{% endif %}{% if message['role'] == 'user' %}{{ ' USER: ' + message['content'].strip() }}"
+                   "{% elif message['role'] == 'assistant' %}{{ ' ASSISTANT: ' + message['content'].strip() + eos_token }}{% endif %}{% endfor %}"
+                   "{% if add_generation_prompt %}{{ ' ASSISTANT:' }}{% endif %}")
+
 QUESTION = 'Given a query "{query}", which of the following passages is the most relevant one to the query?\n\n'
 INSTRUCTION = '\n\nOutput only the passage label of the most relevant passage:'
 
@@ -30,15 +40,22 @@ class SetwiseLlmRanker(LlmRanker):
 
     def __init__(self, model_name_or_path, tokenizer_name_or_path, device, num_child=3, k=10, scoring='generation',
                  method="heapsort", num_permutation=1, cache_dir=None):
-        # ref: setwise.py:25-77
-        from transformers import T5Tokenizer
-        from ._runtime import T5Runtime
+        # ref: setwise.py:25-77: T5 or Llama family by config.model_type, NotImplementedError otherwise
+        from ._runtime import load_runtime
         try:
-            runtime = T5Runtime(model_name_or_path, device, cache_dir=cache_dir)
+            runtime = load_runtime(model_name_or_path, device, cache_dir=cache_dir)
         except NotImplementedError as exc:   # same message shape as ref: setwise.py:71
             raise NotImplementedError(f"{exc} (setwise)") from None
-        tokenizer = T5Tokenizer.from_pretrained(
-            tokenizer_name_or_path if tokenizer_name_or_path is not None else model_name_or_path, cache_dir=cache_dir)
+        if runtime.model_type == "llama":
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(model_name_or_path, cache_dir=cache_dir)   # (the reference ignores tokenizer_name_or_path here)
+            tokenizer.use_default_system_prompt = False
+            if 'v1.5' in model_name_or_path:       # the reference's `'vicuna' and 'v1.5' in name` (ref :63)
+                tokenizer.chat_template = VICUNA_TEMPLATE
+        else:
+            from transformers import T5Tokenizer
+            tokenizer = T5Tokenizer.from_pretrained(
+                tokenizer_name_or_path if tokenizer_name_or_path is not None else model_name_or_path, cache_dir=cache_dir)
         self._setup(runtime, tokenizer, device, num_child, k, scoring, method, num_permutation)
 
     @classmethod
@@ -57,10 +74,12 @@ class SetwiseLlmRanker(LlmRanker):
         self.llm = runtime
         self.config = getattr(runtime, "config", None)
         self.tokenizer = tokenizer
-        # decoder prompt "<pad> Passage" and the last token of "<pad> Passage {label}" (ref: setwise.py:51-59)
-        self.decoder_input_ids = self.tokenizer.encode("<pad> Passage", add_special_tokens=False)
-        self.target_token_ids = [self.tokenizer.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1]
-                                 for c in self.CHARACTERS]
+        self.model_type = getattr(runtime, "model_type", "t5")
+        if self.model_type == "t5":
+            # decoder prompt "<pad> Passage" and the last token of "<pad> Passage {label}" (ref: setwise.py:51-59)
+            self.decoder_input_ids = self.tokenizer.encode("<pad> Passage", add_special_tokens=False)
+            self.target_token_ids = [self.tokenizer.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1]
+                                     for c in self.CHARACTERS]
         self.scoring = scoring
         self.method = method
         # heapsort build phase: advance the independent sift-downs of a tree level in one engine call each (same
@@ -89,6 +108,20 @@ class SetwiseLlmRanker(LlmRanker):
         # ref: setwise.py:79-198
         self.total_compare += 1 if self.num_permutation == 1 else self.num_permutation
         n = len(docs)
+        if self.model_type == "llama":
+            # ref: setwise.py:159-177 — generation only; num_permutation is ignored (it only entered total_compare above)
+            if self.scoring != 'generation':
+                if self.scoring == 'likelihood':
+                    raise NotImplementedError
+                raise UnboundLocalError("local variable 'output' referenced before assignment")
+            ids = self._llama_prompt_ids(self._prompt(query, self.CHARACTERS[:n], [d.text for d in docs]))
+            self.total_prompt_tokens += len(ids)
+            tok = int(self.llm.greedy1([ids])[0])
+            self.total_completion_tokens += len(ids) + 1        # generate() returns prompt + new token for a decoder-only model
+            output = self.tokenizer.decode([tok], skip_special_tokens=True).strip().upper()
+            if not (len(output) == 1 and output in self.CHARACTERS):
+                print(f"Unexpected output: {output}")
+            return output
         if self.scoring == 'generation':
             if self.num_permutation == 1:
                 text = self._prompt(query, self.CHARACTERS[:n], [d.text for d in docs])
@@ -146,6 +179,11 @@ class SetwiseLlmRanker(LlmRanker):
             print(f"Unexpected output: {output}")
         return output
 
+    def _llama_prompt_ids(self, input_text: str) -> List[int]:
+        """chat template + " Passage:" -> token ids, as ref: setwise.py:160-165 builds them"""
+        prompt = self.tokenizer.apply_chat_template([{"role": "user", "content": input_text}], tokenize=False, add_generation_prompt=True)
+        return list(self.tokenizer(prompt + " Passage:")["input_ids"])
+
     def _compare_many(self, query: str, doc_lists: List[List]) -> List[str]:
         """Independent compares in ONE engine call.  Same outputs and counters as `compare()` on each window in turn
         (num_permutation == 1 only: no random draws are involved); the engine's results do not depend on which
@@ -153,6 +191,20 @@ class SetwiseLlmRanker(LlmRanker):
         assert self.num_permutation == 1
         self.total_compare += len(doc_lists)
         texts = [self._prompt(query, self.CHARACTERS[:len(docs)], [d.text for d in docs]) for docs in doc_lists]
+        if self.model_type == "llama":
+            if self.scoring != 'generation':
+                raise NotImplementedError
+            ids = [self._llama_prompt_ids(t) for t in texts]
+            toks = self.llm.greedy1(ids)
+            outs = []
+            for seq, tok in zip(ids, toks):
+                self.total_prompt_tokens += len(seq)
+                self.total_completion_tokens += len(seq) + 1
+                outs.append(self.tokenizer.decode([int(tok)], skip_special_tokens=True).strip().upper())
+            for output in outs:
+                if not (len(output) == 1 and output in self.CHARACTERS):
+                    print(f"Unexpected output: {output}")
+            return outs
         ids = tokenize_prompts(self.tokenizer, texts)
         self.total_prompt_tokens += sum(len(i) for i in ids)
         outs = []

@@ -7,6 +7,8 @@ from oracle.t5_numpy import T5Oracle
 
 
 class OracleRuntime:
+    model_type = "t5"
+
     def __init__(self, dims, state):
         self.dims = dims
         self.orc = T5Oracle(dims, state)
@@ -29,3 +31,18 @@ class OracleRuntime:
         steps = max(done_at)
         toks[:, steps:] = -1
         return toks
+
+
+class OracleLlamaRuntime:
+    """Llama counterpart: the numpy oracle behind LlamaRuntime's interface (greedy1 / last_logits)."""
+    model_type = "llama"
+
+    def __init__(self, dims, state):
+        from oracle.llama_numpy import LlamaOracle
+        self.dims, self.orc, self.config = dims, LlamaOracle(dims, state), dims.to_hf_config()
+
+    def greedy1(self, seqs):
+        return self.orc.greedy1(seqs)
+
+    def last_logits(self, seqs, out_ids):
+        return self.orc.last_logits(seqs, out_ids)

@@ -34,7 +34,7 @@ def ckpt_dirs(tmp_path_factory):
     out = {}
     for name, spec in specs.items():
         path = str(root / name)
-        _synth.write_checkpoint(path, spec, os.path.join(GOLD, "tok"))
+        _synth.write_checkpoint(path, spec, os.path.join(GOLD, spec.get("tokenizer", "tok")))
         assert _synth.checkpoint_sha256(path) == spec["sha256"], f"{name}: regenerated weights differ from goldens"
         out[name] = path
     return out
@@ -44,5 +44,6 @@ def load_state(path):
     from safetensors.numpy import load_file
     from llmrankers import _synth
     with open(os.path.join(path, "config.json")) as f:
-        dims = _synth.T5Dims.from_hf_config(json.load(f))
+        cfg = json.load(f)
+    dims = _synth.LlamaDims.from_hf_config(cfg) if cfg.get("model_type") == "llama" else _synth.T5Dims.from_hf_config(cfg)
     return dims, load_file(os.path.join(path, "model.safetensors"))

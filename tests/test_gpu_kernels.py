@@ -442,3 +442,111 @@ def test_qlm_flan_t5_xl_dims_vs_oracle_and_batch_independence():
     ref = T5Oracle(dims, state).score_last(ragged, [0], [2163, 465])
     assert np.abs(_sigm(sc[:, 0] - sc[:, 1]) - _sigm(ref[:, 0] - ref[:, 1])).max() < SCORE_TOL
     eng.close()
+
+
+def _llama_state(spec):
+    from llmrankers import _synth
+    dims = _synth.NAMED_DIMS[spec["dims"]]
+    state = _synth.synth_state_dict(dims, seed=spec["seed"], gain=spec.get("gain", 1.0))
+    if spec.get("boost_ids"):
+        w = state["lm_head.weight"].copy()
+        ids = np.asarray(spec["boost_ids"], dtype=np.int64)
+        w[ids] = (w[ids] * np.float32(spec["boost"])).astype(np.float16).astype(np.float32)
+        state["lm_head.weight"] = w
+    return dims, state
+
+
+def test_llama_toy_vs_hf_golden_and_reference_cases(ckpt_dirs):
+    """Llama family (rk_llama_*: RoPE, grouped-query causal attention with head_dim 128, SwiGLU, folded RMSNorm) through
+    the product path (checkpoint directory -> LlamaRuntime -> C ABI): last-position logits vs HF's LlamaForCausalLM,
+    batch independence, and every compare of the reference's SetwiseLlmRanker cases (greedy token = the oracle's
+    wherever its margin is above the fp16 noise floor; trajectory follows the recorded one)."""
+    import contextlib, io, random
+    from transformers import AutoTokenizer
+    from llmrankers._runtime import LlamaRuntime
+    from llmrankers.rankers import SearchResult
+    from llmrankers.setwise import SetwiseLlmRanker
+    from oracle.llama_numpy import LlamaOracle
+    g = np.load(os.path.join(GOLD, "model_llama.npz"))
+    rt = LlamaRuntime(ckpt_dirs["ckpt_llama"], "cuda", max_tokens=8192, max_seqs=16)
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    seqs = [g["tokens"][off[i]:off[i + 1]].astype(np.int32) for i in range(len(g["lens"]))]
+    scale = float(np.abs(g["last_logits"]).max())
+    cols = list(range(0, 256, 4))
+    got = rt.last_logits(seqs, cols)
+    err = np.abs(got - g["last_logits"][:, cols]).max()
+    assert err < 6e-3 * scale, (err, scale)                       # hot (gain 2) toy weights, logits up to ~35
+    for b, s in enumerate(seqs):                                  # one prompt at a time == all together (ragged batch)
+        np.testing.assert_array_equal(rt.last_logits([s], cols)[0], got[b])
+    tok_want = np.argmax(g["last_logits"], axis=-1)
+    top2 = np.sort(g["last_logits"], axis=-1)[:, -2:]
+    tok_got = rt.greedy1(seqs)
+    for b in range(len(seqs)):
+        if top2[b, 1] - top2[b, 0] > 0.02 * scale:
+            assert tok_got[b] == tok_want[b]
+    # ---- the reference's setwise cases: engine checked against the oracle on every compare ----
+    with open(os.path.join(GOLD, "llama_cases.json")) as f:
+        gold = json.load(f)
+    with open(os.path.join(GOLD, "ckpts.json")) as f:
+        dims, state = _llama_state(json.load(f)["ckpt_llama"])
+    orc = LlamaOracle(dims, state)
+    tok = AutoTokenizer.from_pretrained(ckpt_dirs["ckpt_llama"])
+    stats = {"calls": 0, "decided": 0}
+
+    class Checked:
+        model_type, config = "llama", rt.config
+
+        def greedy1(self, prompts):
+            want = orc.last_logits(prompts)
+            got_tok = rt.greedy1(prompts)
+            for b in range(len(prompts)):
+                two = np.sort(want[b])[-2:]
+                stats["calls"] += 1
+                if two[1] - two[0] > 0.02 * scale:
+                    stats["decided"] += 1
+                    assert got_tok[b] == int(np.argmax(want[b]))
+            return np.argmax(want, axis=-1).astype(np.int32)
+
+    for case in gold["cases"]:
+        rk = SetwiseLlmRanker.from_runtime(Checked(), tok, num_child=case["num_child"], k=case["k"], scoring=case["scoring"],
+                                           method=case["method"], num_permutation=case["num_permutation"])
+        ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+        random.seed(929)
+        if case["raises"]:
+            with pytest.raises({"IndexError": IndexError, "NotImplementedError": NotImplementedError}[case["raises"]]), contextlib.redirect_stdout(io.StringIO()):
+                rk.rerank(case["query"], ranking)
+            continue
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = rk.rerank(case["query"], ranking)
+        assert [[r.docid, r.score] for r in res] == case["result"]
+        assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"]
+    assert stats["calls"] >= 40 and stats["decided"] >= 0.7 * stats["calls"], stats
+    rt.engine.close()
+
+
+def test_llama_3_8b_widths_one_compare_vs_oracle():
+    """BASELINE.json configs[4] shapes: Llama-3-8B widths (hidden 4096, 32 query / 8 kv heads x 128, SwiGLU 14336, vocabulary
+    128256, rope_theta 5e5) with two layers (the oracle runs on the host): one ~700-token setwise-sized prompt and a short
+    one in the same call; label logits vs the fp32 oracle, same greedy token, batch independence."""
+    from llmrankers import _synth
+    from llmrankers._engine import RkLlamaEngine
+    from oracle.llama_numpy import LlamaOracle
+    dims = _synth.LlamaDims(vocab=128256, hidden=4096, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, n_layers=2,
+                            bos_token_id=128000, eos_token_id=128001)
+    state = _synth.synth_state_dict(dims, seed=929, threads=32)
+    eng = RkLlamaEngine(dims, device=0, max_tokens=4096, max_seqs=8).load_state(state.items())
+    seqs = [s for n in (700, 45) for s in _synth.synth_token_batch(1, n, n, dims.vocab, seed=100 + n)]
+    labels = list(range(32, 32 + 23))
+    orc = LlamaOracle(dims, state)
+    want_full = orc.last_logits(seqs)
+    got = eng.last_logits(seqs, labels)
+    scale = float(np.abs(want_full).max())
+    assert np.abs(got - want_full[:, labels]).max() < 4e-3 * scale, (np.abs(got - want_full[:, labels]).max(), scale)
+    toks = eng.greedy1(seqs)
+    for b in range(2):
+        two = np.sort(want_full[b])[-2:]
+        if two[1] - two[0] > 0.02 * scale:
+            assert toks[b] == int(np.argmax(want_full[b]))
+    np.testing.assert_array_equal(eng.last_logits(seqs[:1], labels)[0], got[0])
+    np.testing.assert_array_equal(eng.last_logits(seqs[1:], labels)[0], got[1])
+    eng.close()

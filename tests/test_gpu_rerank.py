@@ -32,6 +32,9 @@ def stack(ckpt_dirs):
     from llmrankers._runtime import T5Runtime
     out = {}
     for name, path in ckpt_dirs.items():
+        with open(os.path.join(path, "config.json")) as f:
+            if json.load(f).get("model_type") != "t5":
+                continue                                   # the Llama checkpoint has its own tests (test_gpu_kernels.py)
         out[name] = (T5Runtime(path, "cuda", max_tokens=8192, max_seqs=64, max_dec_len=40), T5Tokenizer.from_pretrained(path))
     return out
 
@@ -181,3 +184,67 @@ def test_pipelined_batches_equal_blocking_calls(stack):
     assert len(got) == len(want)
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
+
+
+def test_config3_full_size_setwise_query_flan_t5_large():
+    """BASELINE.json configs[2] at full size: flan-t5-large dimensions, ONE heapsort query with hits=100, num_child=10, k=10
+    (11 passages of ~120 tokens per prompt, ~1.45k tokens), both scorings.  tests/golden/setwise_large.json holds the run of
+    the same ranker on the fp32 oracle (tools/make_setwise_large_golden.py: every compare with its label logits / greedy
+    tokens and its decision margin).  (1) every recorded compare is replayed on the engine: label logits within tolerance,
+    same decision wherever the recorded margin is above the floor; (2) the whole query runs through the shipped, level-batched
+    driver and must give the recorded ranking, caller-list order and counters."""
+    from transformers import T5Tokenizer
+    from llmrankers import _synth
+    from llmrankers._engine import RkEngine
+    from llmrankers._runtime import T5Runtime
+    from llmrankers.rankers import SearchResult
+    from llmrankers.setwise import SetwiseLlmRanker
+    with open(os.path.join(GOLD, "setwise_large.json")) as f:
+        gold = json.load(f)
+    w = gold["weights"]
+    dims = _synth.NAMED_DIMS[w["dims"]]
+    state = _synth.synth_state_dict(dims, seed=w["seed"], threads=32)
+    head = state["lm_head.weight"].copy()
+    ids = np.asarray(w["boost_ids"], dtype=np.int64)
+    head[ids] = (head[ids] * np.float32(w["boost"])).astype(np.float16).astype(np.float32)
+    state["lm_head.weight"] = head
+    eng = RkEngine(dims, 0, max_tokens=32768, max_seqs=16, max_dec_len=8).load_state(state.items())
+    rt = T5Runtime.from_engine(eng, dims)
+    tok = T5Tokenizer.from_pretrained(os.path.join(GOLD, "tok"))
+    text = {d: t for d, t in gold["docs"]}
+    floor = gold["floor"]
+    for scoring in ("likelihood", "generation"):
+        run = gold["runs"][scoring]
+        rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=gold["num_child"], k=gold["k"], scoring=scoring, method="heapsort")
+        worst, decided = 0.0, 0
+        for docids, out, rec in run["compares"]:
+            window = [SearchResult(docid=d, score=0.0, text=text[d]) for d in docids]
+            with contextlib.redirect_stdout(io.StringIO()):
+                got = rk.compare(gold["query"], window)
+            if scoring == "likelihood":
+                prompt = tokenize_ids(rk, gold["query"], window)
+                lg = rt.score([prompt], rk.decoder_input_ids, rk.target_token_ids[:len(window)])[0]
+                worst = max(worst, float(np.abs(lg - np.array(rec["logits"])).max()))
+            if rec["margin"] > floor:
+                decided += 1
+                assert got == out, (scoring, docids, got, out, rec["margin"])
+        assert decided >= 0.8 * len(run["compares"]), (scoring, decided)
+        if scoring == "likelihood":
+            assert worst < floor / 2, worst        # label logits (lm_head rows boosted x6) vs the fp32 oracle
+        # the whole query through the shipped driver (build phase level-batched)
+        rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=gold["num_child"], k=gold["k"], scoring=scoring, method="heapsort")
+        assert rk._batched_ok()
+        ranking = [SearchResult(docid=d, score=float(100 - i), text=t) for i, (d, t) in enumerate(gold["docs"])]
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = rk.rerank(gold["query"], ranking)
+        assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens][:2] == run["counters"][:2], scoring
+        if run["min_margin"] > floor:
+            assert [[r.docid, r.score] for r in res] == run["result"], scoring
+            assert [r.docid for r in ranking] == run["caller_list_after"], scoring
+            assert rk.total_completion_tokens == run["counters"][2]
+    eng.close()
+
+
+def tokenize_ids(rk, query, window):
+    from llmrankers._batching import tokenize_prompts
+    return tokenize_prompts(rk.tokenizer, [rk._prompt(query, rk.CHARACTERS[:len(window)], [d.text for d in window])])[0]

@@ -32,7 +32,8 @@ def runtimes(ckpt_dirs):
     out = {}
     for name, path in ckpt_dirs.items():
         dims, state = load_state(path)
-        out[name] = (OracleRuntime(dims, state), T5Tokenizer.from_pretrained(path))
+        if hasattr(dims, "n_enc"):                      # the T5-family fixtures (the Llama one has its own test below)
+            out[name] = (OracleRuntime(dims, state), T5Tokenizer.from_pretrained(path))
     return out
 
 
@@ -143,6 +144,53 @@ def test_pairwise_reference_cases_cpu(ckpt_dirs):
         assert all(r.text is None for r in res)
     with pytest.raises(NotImplementedError):
         PairwiseLlmRanker.from_runtime(rt, tok, method="quicksort").rerank("q", [SearchResult("a", 1.0, "x")])
+
+
+def test_llama_setwise_reference_cases_cpu(ckpt_dirs):
+    """SetwiseLlmRanker on a Llama-family checkpoint vs the reference's own class (ref: setwise.py:60-69, 159-177): chat
+    template + " Passage:" prompt ids, one greedy token decoded / stripped / upper-cased, prompt + 1 completion tokens,
+    num_permutation only counted, likelihood -> NotImplementedError, the bubblesort IndexError of an out-of-window label."""
+    from transformers import AutoTokenizer
+    from _stub import OracleLlamaRuntime
+    with open(os.path.join(GOLD, "llama_cases.json")) as f:
+        gold = json.load(f)
+    dims, state = load_state(ckpt_dirs["ckpt_llama"])
+    tok = AutoTokenizer.from_pretrained(ckpt_dirs["ckpt_llama"])
+    rt = OracleLlamaRuntime(dims, state)
+    probe = SetwiseLlmRanker.from_runtime(rt, tok)
+    assert probe._llama_prompt_ids("hello world") == gold["prompt_probe"]["ids"]
+    n = 0
+    for case in gold["cases"]:
+        rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=case["num_child"], k=case["k"], scoring=case["scoring"],
+                                           method=case["method"], num_permutation=case["num_permutation"])
+        rk.batch_independent_compares = False
+        log, orig = [], rk.compare
+        rk.compare = lambda q, d, _o=orig, _l=log: (_l.append([[x.docid for x in d]]), _l[-1].append(_o(q, d)))[1] or _l[-1][1]
+        ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+        random.seed(929)
+        sink = io.StringIO()
+        if case["raises"]:
+            with pytest.raises({"IndexError": IndexError, "NotImplementedError": NotImplementedError}[case["raises"]]), contextlib.redirect_stdout(sink):
+                rk.rerank(case["query"], ranking)
+            assert [c for c in log if len(c) == 2] == case["compares"]
+        else:
+            with contextlib.redirect_stdout(sink):
+                res = rk.rerank(case["query"], ranking)
+            assert log == case["compares"]
+            assert [[r.docid, r.score] for r in res] == case["result"]
+            assert [r.docid for r in ranking] == case["caller_list_after"]
+        assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"], case["scoring"]
+        n += 1
+    assert n >= 10
+    # the level-batched build phase gives the same result for a Llama model too
+    case = next(c for c in gold["cases"] if c["method"] == "heapsort" and c["num_child"] == 3 and not c["raises"])
+    rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=3, k=case["k"], scoring="generation", method="heapsort")
+    assert rk._batched_ok()
+    ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = rk.rerank(case["query"], ranking)
+    assert [[r.docid, r.score] for r in res] == case["result"]
+    assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"]
 
 
 def test_truncate(cases, runtimes):

@@ -90,3 +90,29 @@ def test_config1_flan_t5_small_logits():
     np.testing.assert_allclose(got, g["logits"][sub], atol=5e-5, rtol=1e-5)
     full = orc.score_last([seqs[0]], [0])[0]
     np.testing.assert_allclose(full, g["full_logits_seq0"], atol=5e-5, rtol=1e-5)
+
+
+def test_llama_oracle_matches_hf_llama_logits():
+    """oracle/llama_numpy.py vs HF LlamaForCausalLM (tools/make_goldens.py --only-llama): last-position logits of five
+    ragged prompts and the full logits of one, toy GQA / RoPE / SwiGLU checkpoint with hot (gain 2) weights."""
+    import json
+    from llmrankers import _synth
+    from oracle.llama_numpy import LlamaOracle
+    g = np.load(os.path.join(GOLD, "model_llama.npz"))
+    with open(os.path.join(GOLD, "ckpts.json")) as f:
+        spec = json.load(f)["ckpt_llama"]
+    dims = _synth.NAMED_DIMS[spec["dims"]]
+    state = _synth.synth_state_dict(dims, seed=spec["seed"], gain=spec["gain"])
+    w = state["lm_head.weight"].copy()
+    ids = np.asarray(spec["boost_ids"], dtype=np.int64)
+    w[ids] = (w[ids] * np.float32(spec["boost"])).astype(np.float16).astype(np.float32)
+    state["lm_head.weight"] = w
+    orc = LlamaOracle(dims, state)
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    seqs = [g["tokens"][off[i]:off[i + 1]] for i in range(len(g["lens"]))]
+    got = orc.last_logits(seqs)
+    assert np.abs(got - g["last_logits"]).max() < 2e-4 * max(1.0, np.abs(g["last_logits"]).max())
+    head = orc.w["lm_head.weight"]
+    full = orc.hidden_states(seqs[1]) @ head.T
+    assert np.abs(full - g["full_logits_seq1"]).max() < 2e-4 * max(1.0, np.abs(g["full_logits_seq1"]).max())
+    np.testing.assert_array_equal(orc.greedy1(seqs), np.argmax(g["last_logits"], axis=-1))

@@ -401,6 +401,118 @@ def add_pairwise():
     shutil.rmtree(tmp)
 
 
+LLAMA_CHAT_TEMPLATE = ("{{ bos_token }}{% for message in messages %}{{ '<|start_header_id|>' + message['role'] + '<|end_header_id|>\n\n' "
+                       "+ message['content'] | trim + '<|eot_id|>' }}{% endfor %}"
+                       "{% if add_generation_prompt %}{{ '<|start_header_id|>assistant<|end_header_id|>\n\n' }}{% endif %}")
+
+
+def make_llama_tokenizer(path):
+    """A synthetic Llama-3-style tokenizer (no real vocabulary exists offline): Unigram pieces of the T5 fixture plus the
+    chat special tokens, BOS prepended by the post-processor, Llama-3's chat template."""
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    specials = ["<|begin_of_text|>", "<|end_of_text|>", "<|start_header_id|>", "<|end_header_id|>", "<|eot_id|>", "<unk>"]
+    pieces = [(t, 0.0) for t in specials] + [p for p in build_vocab() if p[0] not in ("<pad>", "</s>", "<unk>")]
+    assert len(pieces) <= 256, len(pieces)
+    tk = Tokenizer(models.Unigram(pieces, unk_id=5, byte_fallback=False))
+    tk.pre_tokenizer = pre_tokenizers.Metaspace(replacement="\u2581", prepend_scheme="always")
+    tk.decoder = decoders.Metaspace(replacement="\u2581", prepend_scheme="always")
+    tk.post_processor = processors.TemplateProcessing(single="<|begin_of_text|> $A", special_tokens=[("<|begin_of_text|>", 0)])
+    tk.add_special_tokens(specials)
+    fast = PreTrainedTokenizerFast(tokenizer_object=tk, bos_token="<|begin_of_text|>", eos_token="<|end_of_text|>", unk_token="<unk>",
+                                   additional_special_tokens=["<|start_header_id|>", "<|end_header_id|>", "<|eot_id|>"])
+    fast.chat_template = LLAMA_CHAT_TEMPLATE
+    os.makedirs(path, exist_ok=True)
+    fast.save_pretrained(path)
+    return fast
+
+
+def llama_goldens(ref_rankers, ref_setwise, ckpt_dir):
+    """HF LlamaForCausalLM logits (oracle pin) and the reference's SetwiseLlmRanker on a Llama checkpoint
+    (ref: setwise.py:60-69, 159-177): chat-template prompt + " Passage:", one greedy token, counters.
+    -> tests/golden/model_llama.npz, tests/golden/llama_cases.json"""
+    import torch
+    from transformers import AutoModelForCausalLM, AutoTokenizer
+    model = AutoModelForCausalLM.from_pretrained(ckpt_dir, torch_dtype=torch.float32).eval()
+    tok = AutoTokenizer.from_pretrained(ckpt_dir)
+    rs = np.random.RandomState(808)
+    lens = [9, 33, 1, 140, 64]
+    seqs = [rs.randint(6, model.config.vocab_size, size=n).astype(np.int64) for n in lens]
+    out = {"lens": np.array(lens), "tokens": np.concatenate(seqs)}
+    last = []
+    with torch.no_grad():
+        for i, s_ in enumerate(seqs):
+            lg = model(input_ids=torch.tensor(s_)[None]).logits[0].numpy()
+            last.append(lg[-1])
+            if i == 1:
+                out["full_logits_seq1"] = lg
+    out["last_logits"] = np.stack(last)
+    np.savez_compressed(os.path.join(GOLD, "model_llama.npz"), **out)
+    print(f"[model_llama] last-position logits range {out['last_logits'].min():.3f}..{out['last_logits'].max():.3f}")
+
+    rs = np.random.RandomState(99)
+    queries = [rand_text(rs, 3, 8) for _ in range(2)]
+    doc_pool = [rand_text(rs, 8, 40) for _ in range(40)]
+    cases, sink = [], io.StringIO()
+    for scoring, method, c, k, nperm, n in (("generation", "heapsort", 3, 5, 1, 20), ("generation", "bubblesort", 4, 4, 1, 14),
+                                            ("generation", "heapsort", 10, 10, 1, 30), ("generation", "heapsort", 2, 3, 3, 12),
+                                            ("likelihood", "heapsort", 3, 5, 1, 8)):
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            rk = ref_setwise.SetwiseLlmRanker(ckpt_dir, ckpt_dir, device="cpu", num_child=c, k=k, scoring=scoring, method=method,
+                                              num_permutation=nperm)
+            log, orig = [], rk.compare
+
+            def logged(query, docs, _o=orig, _l=log):
+                out_ = _o(query, docs)
+                _l.append([[d.docid for d in docs], out_])
+                return out_
+
+            rk.compare = logged
+            for qi, q in enumerate(queries):
+                ranking = [ref_rankers.SearchResult(docid=f"Q{3 * qi + i}", score=float(100 - i), text=doc_pool[(3 * qi + i) % 40]) for i in range(n)]
+                inp = [[r.docid, r.score, r.text] for r in ranking]
+                random.seed(929)
+                del log[:]
+                raises = None
+                try:
+                    res = rk.rerank(q, ranking)
+                except NotImplementedError:
+                    raises, res = "NotImplementedError", []
+                except IndexError:
+                    raises, res = "IndexError", []
+                cases.append({"kind": "setwise-llama", "ckpt": "ckpt_llama", "scoring": scoring, "method": method, "num_child": c, "k": k,
+                              "num_permutation": nperm, "query": q, "input": inp, "raises": raises,
+                              "result": [[r.docid, r.score] for r in res], "compares": list(log),
+                              "caller_list_after": [r.docid for r in ranking],
+                              "counters": [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens]})
+    prompt = tok.apply_chat_template([{"role": "user", "content": "hello world"}], tokenize=False, add_generation_prompt=True) + " Passage:"
+    with open(os.path.join(GOLD, "llama_cases.json"), "w") as f:
+        json.dump({"cases": cases, "prompt_probe": {"text": prompt, "ids": tok(prompt)["input_ids"]}}, f)
+    outs = sorted({o for c_ in cases for _, o in c_["compares"]})
+    print(f"[llama_cases] {len(cases)} cases, outputs seen: {outs[:12]}; reference printed 'Unexpected output' {sink.getvalue().count('Unexpected output')}x")
+
+
+def add_llama():
+    """Incremental: Llama tokenizer, checkpoint recipe, HF logits and reference setwise cases."""
+    import tempfile
+    tok_dir = os.path.join(GOLD, "tok_llama")
+    tok = make_llama_tokenizer(tok_dir)
+    label_ids = [tok.encode(" Passage: " + c, add_special_tokens=False)[-1] for c in LABELS]
+    assert len(set(label_ids)) == 23, label_ids
+    with open(os.path.join(GOLD, "ckpts.json")) as f:
+        specs = json.load(f)
+    spec = {"dims": "toy-llama", "seed": 21, "gain": 2.0, "boost_ids": label_ids, "boost": 6.0, "tokenizer": "tok_llama"}
+    tmp = tempfile.mkdtemp(prefix="rk_goldens_")
+    ck = os.path.join(tmp, "ckpt_llama")
+    spec["sha256"] = write_ckpt(ck, spec, tok_dir)
+    specs["ckpt_llama"] = spec
+    with open(os.path.join(GOLD, "ckpts.json"), "w") as f:
+        json.dump(specs, f, indent=1)
+    ref_rankers, _, ref_setwise = import_reference()
+    llama_goldens(ref_rankers, ref_setwise, ck)
+    shutil.rmtree(tmp)
+
+
 def add_monot5():
     """Incremental: adds the monoT5 checkpoint recipe and cases without regenerating the other fixtures."""
     import tempfile
@@ -467,6 +579,8 @@ def main():
         return add_monot5()
     if "--only-pairwise" in sys.argv:
         return add_pairwise()
+    if "--only-llama" in sys.argv:
+        return add_llama()
     if os.path.isdir(GOLD):
         shutil.rmtree(GOLD)
     os.makedirs(GOLD)
