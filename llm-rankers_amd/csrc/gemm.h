@@ -435,6 +435,68 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
   }
 }
 
+// ================================= small-M variant: 64x64 tiles ===============================================
+// One setwise prompt is M ~ 1.5k rows: 256- or 128-row tiles give the O / FFN-out projections 24 - 96 workgroups for 256
+// CUs.  This kernel cuts the output into 64x64 tiles (2 waves, each 32 rows x 64 columns = two MFMA 32x32 fragments) with
+// the same LDS image, swizzle, DMA staging, K order and epilogues as the 128x128 kernel - so a row's result is bit-identical
+// whichever variant runs - at 32 KiB of LDS per workgroup (five per CU).  Latency-bound by design: the point is 16x more
+// workgroups in flight, not MFMA rate.
+template <int EPI>
+__global__ __launch_bounds__(128, 4) void gemm_s64_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+  half_t* smem = (half_t*)gemm_smem;
+  constexpr int TILE = 64 * 64;                         // halfs per operand tile (8 KiB)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int tiles_m = (p.M + 63) >> 6, tiles_n = (p.N + 63) >> 6;
+  int tm, tn;
+  gemm_tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * 64, n0 = tn * 64;
+  // DMA staging: a 64-row tile is 512 16-byte slots; wave w owns slots [w*256, w*256+256): 4 instructions of 64 lanes
+  auto stage = [&](half_t* s_tile, const half_t* g, int ld, int row0, int rows_total, int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pslot = (wave * 4 + i) * 64 + lane;
+      const int r = pslot >> 3, c = pslot & 7;
+      int grow = row0 + r;
+      grow = grow < rows_total ? grow : rows_total - 1;
+      const half_t* src = g + (size_t)grow * ld + k0 + ((c ^ ((r >> 1) & 7)) << 3);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(s_tile + (wave * 4 + i) * 512), 16, 0, 0);
+    }
+  };
+  f32x16 acc[2][1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+  const int nk = p.K >> 6;
+  stage(smem, p.A, p.lda, m0, p.M, 0);
+  stage(smem + TILE, p.W, p.ldw, n0, p.N, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    half_t* sA = smem + (kt & 1) * 2 * TILE;
+    half_t* sW = sA + TILE;
+    __syncthreads();   // stage kt landed (the barrier's vmcnt(0) drains this wave's DMA); the other stage is free
+    if (kt + 1 < nk) {
+      half_t* nA = smem + ((kt + 1) & 1) * 2 * TILE;
+      stage(nA, p.A, p.lda, m0, p.M, (kt + 1) * 64);
+      stage(nA + TILE, p.W, p.ldw, n0, p.N, (kt + 1) * 64);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cc = ks * 2 + hh;
+      const half8 af = gemm_frag(sA, wave * 32 + l31, cc);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+        acc[ni][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gemm_frag(sW, ni * 32 + l31, cc), af, acc[ni][0], 0, 0, 0);
+    }
+  }
+  __syncthreads();     // every wave is done reading the last stage: LDS becomes the epilogue staging area
+  float rsc[1];
+  gemm_row_factors<1>(p, m0 + wave * 32, l31, rsc);
+  gemm_epilogue_staged<EPI, 2, 1>(p, acc, m0 + wave * 32, n0, lane, gemm_smem + wave * (32 * (64 * 4 + 16)), rsc);
+}
+
 // ---- skinny GEMM: few rows (the single-step decoder: M = sequences in the batch; 32 rows per blockIdx.z) --------
 // Weight-streaming regime: every weight element is used once, so W is never staged in LDS.  One 512-thread workgroup
 // owns NT consecutive 32-row weight tiles (NT = 2 for GEGLU: gate + up); its 8 waves take the K dimension in
@@ -442,6 +504,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
 // lane, 4 steps in flight) and reads the tiny activation matrix (L2-resident) as the B fragment.  Partial
 // accumulators are combined through LDS by a FIXED binary tree (bitwise reproducible, unlike an atomic split-K)
 // that needs only 16*NT KiB, so these workgroups still fit on a CU next to two resident encoder GEMM workgroups.
+// (Tried and dropped: fusing the decoder's RMSNorms into this kernel's activation loads - every workgroup recomputing the
+// row factors of its 32 rows and converting fp32 rows on the fly - removed three launches per layer but made the GEMMs
+// slower by more than the norm kernels cost: pointwise -1.7 %, a setwise compare 6.83 -> 6.98 ms.)
 #define SKINNY_THREADS 512
 template <int EPI, int NT>
 __global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p) {

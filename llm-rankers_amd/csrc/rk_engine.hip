@@ -101,7 +101,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2;
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
@@ -224,6 +224,10 @@ int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_p
   if (e->opt_gemm_variant) return (e->opt_gemm_variant == 3 && (EPI_IS_GATED(epi) || fold_producer)) ? 2 : e->opt_gemm_variant;
   struct V { int id, bm, bn, slots; double round_us; };
   static const V vs[5] = {{5, 256, 256, 256, 25.5}, {2, 256, 256, 256, 29.8}, {3, 256, 192, 256, 24.7}, {4, 256, 128, 256, 19.0}, {1, 128, 128, 512, 17.3}};
+  // 64x64 tiles (variant 6) win only while the larger tiles leave most of the chip idle (tools/gemm_bench.py, r02: O / FFN-out
+  // of one or two setwise prompts, M = 1450 / 2900: 12.7 / 15.0 us against 15.7 / 17.4 us on 128x128 tiles; from M = 5888 on,
+  // or for the wide QKV / FFN-in outputs, they lose): at most 192 tiles of 128x128
+  if ((long)((M + 127) / 128) * ((N + 127) / 128) <= 192 && K >= 64) return 6;
   double best = 1e30; int bv = 1;
   for (const V& v : vs) {
     if (v.id == 3 && (EPI_IS_GATED(epi) || fold_producer)) continue;   // (the folded-norm producer needs 64-column wave tiles)
@@ -252,7 +256,14 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
     }
   }
 #endif
-  if (variant > 5) variant = 5;
+  if (variant == 6) {
+    static std::atomic<uint64_t> attr_done{0};
+    ensure_dynamic_lds((const void*)gemm_s64_kernel<EPI>, 32768, attr_done);
+    const int tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+    hipLaunchKernelGGL((gemm_s64_kernel<EPI>), dim3(tiles), dim3(128), 32768, st, a);
+    return;
+  }
+  if (variant > 6) variant = 5;
   if (variant == 5 && a.K < 128) variant = 2;                       // the ping-pong kernel needs two K tiles
   if (variant == 5) {
     const int wgs = e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7);
@@ -450,8 +461,12 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
         a.heads_per_wg = 1;
         hipLaunchKernelGGL(attn_enc_short_kernel<4>, dim3(d.n_heads, sl.n_seq, (sl.maxL + 127) / 128), dim3(256), 0, st, a);
       }
+      else if (e->opt_attn_tiled_occ >= 3)
+        hipLaunchKernelGGL(attn_enc_kernel<3>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
+      else if (e->opt_attn_tiled_occ == 2)
+        hipLaunchKernelGGL(attn_enc_kernel<2>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
       else
-        hipLaunchKernelGGL(attn_enc_kernel, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(attn_enc_kernel<1>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
     }
     if (fold) {
       gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, I, w.o, I, sl.hidden, dm, T, dm, I, 0, 0, 1.f, 1, 0, 0, 0, false, prod);
@@ -607,7 +622,7 @@ int check_batch(rk_engine* e, Slot& sl, const int32_t* tokens, const int32_t* of
   if (T > e->d.max_tokens) return fail(e, RK_ERR_CAPACITY, "%d tokens > max_tokens %d", T, e->d.max_tokens);
   for (int t = 0; t < T; ++t)
     if (tokens[t] < 0 || tokens[t] >= e->d.vocab) return fail(e, RK_ERR_INVALID, "token id %d out of range at %d", tokens[t], t);
-  if ((64 + 256 + 8 + (size_t)maxL) * sizeof(float) > 160 * 1024)
+  if ((64 + 256 + 8 + (size_t)maxL) * sizeof(float) > 160 * 1024 || maxL > 65536)
     return fail(e, RK_ERR_CAPACITY, "sequence of %d tokens exceeds the cross-attention LDS budget", maxL);
   sl.maxL = maxL; sl.T = T; sl.n_seq = n_seq;
   return RK_OK;
@@ -1543,6 +1558,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x3F : value; return RK_OK; }   // bit per epilogue kind
   if (!strcmp(key, "gemm_persistent")) { e->opt_gemm_persistent = value; return RK_OK; }   // ping-pong GEMM: 1 = one workgroup per CU walks the tiles
+  if (!strcmp(key, "attn_tiled_occ")) { e->opt_attn_tiled_occ = value; return RK_OK; }   // tiled encoder attention: register budget for 1 / 2 / 3 waves per SIMD
   if (!strcmp(key, "fold_norm")) { e->opt_fold_norm = value != 0; return RK_OK; }           // encoder RMSNorm folded into the GEMMs (1) or separate kernels (0)
 #ifdef RK_MEASURE
   if (!strcmp(key, "attn_ko")) { e->opt_attn_ko = value; return RK_OK; }   // timing-only knock-outs, see AttnEncArgs
@@ -1625,7 +1641,7 @@ int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_fl
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_pair_kernel<1>, 384, ATTP_GROUP_LDS); out[1] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f16_kernel<EPI_STORE_F16, true>, 256, GEMM_LDS_BYTES); out[2] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_pp2_kernel<EPI_STORE_F16, 0>, 512, 163840); out[3] = (float)n;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_kernel, 256, 0); out[4] = (float)n;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_kernel<1>, 256, 0); out[4] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rmsnorm_kernel<4>, 256, 0); out[5] = (float)n;
     return 6;
   }

@@ -40,8 +40,8 @@ def toy(ckpt_dirs):
 
 
 # variant: 1 = 128x128 tile kernel (glds / register staging), 2..4 = 256x{256,192,128} kernels, 5 = 256x256 ping-pong
-# (falls back to variant 2 for a single K tile)
-@pytest.mark.parametrize("variant,glds", [(1, True), (1, False), (2, True), (3, True), (4, True), (5, True)])
+# (falls back to variant 2 for a single K tile), 6 = 64x64 small-M kernel
+@pytest.mark.parametrize("variant,glds", [(1, True), (1, False), (2, True), (3, True), (4, True), (5, True), (6, True)])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (200, 192, 128), (70, 576, 192), (1, 4, 64), (333, 260, 1024),
                                     (5888, 1024, 2816), (777, 516, 384), (256, 256, 128)])
 def test_gemm_vs_numpy(toy, shape, variant, glds):
@@ -60,7 +60,7 @@ def test_gemm_vs_numpy(toy, shape, variant, glds):
         eng.set_option("gemm_variant", 0)
     want = a.astype(np.float32) @ w.astype(np.float32).T
     err = np.abs(got - want)
-    if variant == 5:                                     # every tile shape / schedule sums K in the same order
+    if variant in (5, 6):                                # every tile shape / schedule sums K in the same order
         eng.set_option("gemm_variant", 2)
         try:
             np.testing.assert_array_equal(got, eng.debug_gemm(a, w, use_glds=True))
@@ -233,8 +233,11 @@ def test_flan_t5_large_dims_vs_oracle_and_properties():
     v1_glds = eng.score(batch, [0], ids)
     eng.set_option("gemm_variant", 5)
     v5 = eng.score(batch, [0], ids)
+    eng.set_option("gemm_variant", 6)
+    v6 = eng.score(batch[:8], [0], ids)
     eng.set_option("gemm_variant", 0)
     np.testing.assert_array_equal(v5, full)              # ping-pong schedule: same arithmetic again
+    np.testing.assert_array_equal(v6, full[:8])          # 64x64 small-M tiles: and again
     np.testing.assert_array_equal(v1_regs, v1_glds)      # DMA and register staging run the same arithmetic
     np.testing.assert_array_equal(v1_glds, full)         # ... and so do all tile shapes (same K order per output)
     eng.set_option("attn_short", 0)                      # tiled attention kernel instead of the whole-KV-in-LDS one
@@ -329,7 +332,7 @@ def test_folded_rmsnorm_matches_separate_norm_kernels(toy):
         plain = eng.score(seqs, [0], ids)
         eng.set_option("fold_norm", 1)
         fold = eng.score(seqs, [0], ids)
-        for v in (1, 2, 3, 4, 5):
+        for v in (1, 2, 3, 4, 5, 6):
             eng.set_option("gemm_variant", v)
             np.testing.assert_array_equal(eng.score(seqs, [0], ids), fold, err_msg=f"tile variant {v}")
     finally:

@@ -30,7 +30,7 @@ def main():
     dims = _synth.TOY_GATED_UNTIED
     eng = RkEngine(dims, 0, max_tokens=256, max_seqs=4, max_dec_len=4).load_state(_synth.synth_state_dict(dims, 1).items())
     out = {}
-    variants = [int(v) for v in os.environ.get("RK_GEMM_VARIANTS", "0,1,2,3,4,5").split(",")]
+    variants = [int(v) for v in os.environ.get("RK_GEMM_VARIANTS", "0,1,2,3,4,5,6").split(",")]
     for name, m, n, k, epi in SHAPES:
         if only and name not in only:
             continue
