@@ -1,5 +1,7 @@
-"""Multi-GPU candidate sharding: one process per GPU, `torch.distributed` (backend 'nccl' = RCCL over xGMI on
-the GPU box, 'gloo' in CPU tests).
+"""Multi-GPU candidate sharding: one process per GPU.  On the GPU box the scores are collected by the ENGINE's own RCCL
+communicator (rk_comm_*, llmrankers/_runtime.py); `torch.distributed` only launches the ranks and carries the RCCL id.
+The helpers here are the partitioning and the host-side gather used when the runtime has no communicator (CPU tests on
+'gloo').
 
 The reference has no data parallelism at all (multi-GPU there = accelerate's device_map='auto' layer placement,
 ref: llmrankers/pointwise.py:21; README.md:357).  Here the passages of one query are independent given the
@@ -10,7 +12,7 @@ and sorts identically.  Setwise heapsort is a dependency chain of compares: repl
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Tuple
 
 import os
 
@@ -39,26 +41,6 @@ def shard_bounds(n_items: int, world_size: int) -> List[Tuple[int, int]]:
     return out
 
 
-def all_gather_scores(local: np.ndarray, n_items: int, device=None) -> np.ndarray:
-    """Collect per-rank score chunks (float32 [n_local]) into the full [n_items] vector on every rank with a
-    single fixed-size all_gather (chunks padded to the largest)."""
-    import torch
-    import torch.distributed as dist
-    rank, ws = world()
-    if ws == 1:
-        return np.asarray(local, dtype=np.float32)
-    bounds = shard_bounds(n_items, ws)
-    width = max(e - s for s, e in bounds)
-    if device is None:   # NCCL buffers live on this rank's GPU (LOCAL_RANK), whatever torch's current device is
-        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0") or 0)) if dist.get_backend() == "nccl" else torch.device("cpu")
-    buf = torch.zeros(width, dtype=torch.float32, device=device)
-    buf[:len(local)] = torch.as_tensor(np.asarray(local, dtype=np.float32), device=device)
-    out = torch.empty(ws * width, dtype=torch.float32, device=device)
-    dist.all_gather_into_tensor(out, buf)
-    out = out.cpu().numpy().reshape(ws, width)
-    return np.concatenate([out[r, :e - s] for r, (s, e) in enumerate(bounds)])
-
-
 def all_gather_flat(local: np.ndarray, width: int) -> np.ndarray:
     """[world, width] float32: every rank's `local` (<= width values, zero padded) through ONE torch.distributed
     all_gather on the process group's own backend — the host-side path used when the runtime has no engine-owned
@@ -76,13 +58,3 @@ def all_gather_flat(local: np.ndarray, width: int) -> np.ndarray:
     out = torch.empty(ws * width, dtype=torch.float32, device=device)
     dist.all_gather_into_tensor(out, buf)
     return out.cpu().numpy().reshape(ws, width)
-
-
-def sharded_scores(score_fn, items: Sequence, device=None) -> np.ndarray:
-    """score_fn(chunk) -> float32 [len(chunk)] is run on this rank's chunk only; returns all scores in item order."""
-    rank, ws = world()
-    if ws == 1:
-        return np.asarray(score_fn(items), dtype=np.float32)
-    s, e = shard_bounds(len(items), ws)[rank]
-    local = np.asarray(score_fn(items[s:e]), dtype=np.float32) if e > s else np.zeros(0, np.float32)
-    return all_gather_scores(local, len(items), device)

@@ -10,5 +10,7 @@ import json; j=json.loads(open('$OUT/bench_128.json').read().strip().splitlines(
 timeout 600 python bench.py --steps 20 --warmup 5 --group 1 --no_cpu_baseline --no_per_query --no_profile > $OUT/bench_group1.json 2> /dev/null; python -c "
 import json; j=json.loads(open('$OUT/bench_group1.json').read().strip().splitlines()[-1]); print('group 1:', j['value'])"
 timeout 900 python tools/bench_setwise_query.py 2>/dev/null | tail -1 > $OUT/setwise_query.json; cat $OUT/setwise_query.json
+timeout 300 python tools/profile_compare.py 2>/dev/null | tail -1 > $OUT/compare_profile.json; cat $OUT/compare_profile.json
+timeout 1200 python tools/bench_llama.py 2> $OUT/llama_bench.err | tail -1 > $OUT/llama_bench.json; cat $OUT/llama_bench.json; tail -2 $OUT/llama_bench.err
 bash tools/gpu_prof.sh > $OUT/prof_stdout.txt 2>&1; tail -22 $OUT/prof_stdout.txt | cut -c1-220
 cp gpurun_out/prof/bench_kernel_stats.csv $OUT/ 2>/dev/null; cp gpurun_out/prof/pmc_summary.json $OUT/ 2>/dev/null
