@@ -17,16 +17,25 @@ QLM_PROMPT = "Passage: {text}\nPlease write a question based on this passage."
 MONOT5_PROMPT = "Query: {query} Document: {document} Relevant:"
 
 
-def _softmax_first(a: np.ndarray, b: np.ndarray) -> np.ndarray:
-    """softmax([a, b])[0] in float32, the way torch.softmax evaluates it (max-subtracted)."""
+def _softmax_first(a: np.ndarray, b: np.ndarray, fp16: bool = False) -> np.ndarray:
+    """softmax([a, b])[0] in float32, the way torch.softmax evaluates it (max-subtracted).  fp16=True reproduces the
+    reference's accelerator path (ref: pointwise.py:22-23: fp16 model on 'cuda'): logits rounded to fp16, softmax
+    evaluated in fp32 and rounded to fp16 as torch does for half tensors - scores then take the reference's quantised
+    values (0.9995, 1.0, ...) and exact ties are resolved by input order exactly as there."""
+    if fp16:
+        a, b = a.astype(np.float16), b.astype(np.float16)
     a = a.astype(np.float32)
     b = b.astype(np.float32)
     m = np.maximum(a, b)
     ea, eb = np.exp(a - m), np.exp(b - m)
-    return ea / (ea + eb)
+    p = ea / (ea + eb)
+    return p.astype(np.float16).astype(np.float32) if fp16 else p
 
 
 class PointwiseLlmRanker(LlmRanker):
+    # Scores are fp32 softmaxes of the engine's fp32 logits (closest to the reference's CPU ground truth).  Set to True to
+    # get the reference's 'cuda' score values instead: fp16 logits and fp16 probabilities, hence its exact ties.
+    fp16_scores = False
 
     def __init__(self, model_name_or_path, tokenizer_name_or_path, device, method="qlm", batch_size=1, cache_dir=None,
                  shard_candidates=False):
@@ -81,7 +90,7 @@ class PointwiseLlmRanker(LlmRanker):
             no_id = self.tokenizer.encode("No", add_special_tokens=False)[0]
             prompts = [YES_NO_PROMPT.format(text=doc.text, query=query) for doc in docs]
             return prompts, "score", [self.tokenizer.pad_token_id], [yes_id, no_id], 1, \
-                lambda raw: _softmax_first(raw[:, 0], raw[:, 1])
+                lambda raw: _softmax_first(raw[:, 0], raw[:, 1], self.fp16_scores)
         return None   # any other method: the reference silently leaves the scores untouched and still sorts (ref :129)
 
     def _counted_batches(self, prompts: List[str], dec_len: int):
@@ -163,4 +172,4 @@ class MonoT5LlmRanker(PointwiseLlmRanker):
     def _spec(self, query: str, docs: List[SearchResult]):
         prompts = [MONOT5_PROMPT.format(query=query, document=doc.text) for doc in docs]
         return prompts, "score", [self.llm.decoder_start_token_id], [self.FALSE_ID, self.TRUE_ID], 1, \
-            lambda raw: _softmax_first(raw[:, 1], raw[:, 0])
+            lambda raw: _softmax_first(raw[:, 1], raw[:, 0], self.fp16_scores)

@@ -193,6 +193,33 @@ def test_llama_setwise_reference_cases_cpu(ckpt_dirs):
     assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"]
 
 
+def test_fp16_score_mode_reproduces_the_reference_cuda_quantisation(runtimes):
+    """PointwiseLlmRanker.fp16_scores: logits and probabilities rounded the way the reference's fp16 'cuda' path rounds
+    them (torch: half logits -> softmax in fp32 -> half) - saturated scores tie exactly and keep their input order."""
+    import torch
+    rt, tok = runtimes["ckpt_gated_untied"]
+
+    class Fixed:
+        model_type, config, decoder_start_token_id = "t5", None, 0
+
+        def score(self, seqs, dec, ids):
+            return np.array([[9.31, -1.2], [9.6, -1.3], [0.2, 0.1], [12.0, -3.0]], np.float32)[:len(seqs)]
+
+    docs = [SearchResult(docid=f"d{i}", score=0.0, text=f"text {i}") for i in range(4)]
+    rk = PointwiseLlmRanker.from_runtime(Fixed(), tok, method="yes_no", batch_size=4)
+    rk.fp16_scores = True
+    res = rk.rerank("q", list(docs))
+    lg = torch.tensor([[9.31, -1.2], [9.6, -1.3], [0.2, 0.1], [12.0, -3.0]]).half()
+    want = torch.softmax(lg, dim=1)[:, 0].float().tolist()            # what the reference computes on an fp16 model
+    got = {r.docid: r.score for r in res}
+    assert [got[f"d{i}"] for i in range(4)] == want
+    assert got["d0"] == got["d1"] == got["d3"] == 1.0                  # saturated: exact ties ...
+    assert [r.docid for r in res] == ["d0", "d1", "d3", "d2"]           # ... resolved by input order (stable sort)
+    rk.fp16_scores = False
+    res = rk.rerank("q", [SearchResult(docid=f"d{i}", score=0.0, text=f"text {i}") for i in range(4)])
+    assert [r.docid for r in res] == ["d3", "d1", "d0", "d2"]           # fp32 scores separate them
+
+
 def test_truncate(cases, runtimes):
     rt, tok = runtimes["ckpt_gated_untied"]
     pw = PointwiseLlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=2)
