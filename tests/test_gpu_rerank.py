@@ -250,3 +250,52 @@ def test_config3_full_size_setwise_query_flan_t5_large():
 def tokenize_ids(rk, query, window):
     from llmrankers._batching import tokenize_prompts
     return tokenize_prompts(rk.tokenizer, [rk._prompt(query, rk.CHARACTERS[:len(window)], [d.text for d in window])])[0]
+
+
+def test_run_py_cli_on_the_engine(ckpt_dirs, tmp_path):
+    """run.py end to end on the HIP engine (product constructors: checkpoint directory -> engine): pointwise, setwise on T5
+    and on the Llama family, pairwise; TREC output equals what the library-level rankers return; --resume and --qrels work."""
+    import importlib.util
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("rk_run_gpu", os.path.join(REPO, "run.py"))
+    runmod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(runmod)
+    (tmp_path / "q.tsv").write_text("q1\tneural ranking model\nq2\twater river mountain\n")
+    words = ["search engine index", "river water city", "music art film", "vaccine covid virus", "bank money trade", "history science physics"]
+    (tmp_path / "d.tsv").write_text("\n".join(f"d{i}\t{w}" for i, w in enumerate(words)) + "\n")
+    lines = [f"{q} Q0 d{i} {r + 1} {10 - r} bm25" for q in ("q1", "q2") for r, i in enumerate(range(6))]
+    (tmp_path / "in.trec").write_text("\n".join(lines) + "\n")
+    (tmp_path / "qrels").write_text("q1 0 d0 2\nq2 0 d1 1\n")
+    parser, commands = runmod.build_parser()
+
+    def run(ckpt, save, tail, extra=()):
+        args = runmod.parse_args(parser, commands, ["run", "--model_name_or_path", ckpt, "--run_path", str(tmp_path / "in.trec"),
+                                                    "--save_path", str(save), "--query_file", str(tmp_path / "q.tsv"),
+                                                    "--doc_file", str(tmp_path / "d.tsv"), "--hits", "6", "--passage_length", "16",
+                                                    "--query_length", "16", *extra, *tail])
+        runmod.validate(args)
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            runmod.main(args)
+        return [l.split("\t") for l in save.read_text().splitlines()], out.getvalue()
+
+    t5, llama = ckpt_dirs["ckpt_labelboost"], ckpt_dirs["ckpt_llama"]
+    rows, log = run(t5, tmp_path / "pw.trec", ["pointwise", "--method", "yes_no", "--batch_size", "4"], ["--qrels", str(tmp_path / "qrels")])
+    assert len(rows) == 12 and all(r[1] == "Q0" and r[5] == "LLMRankers" for r in rows) and "NDCG@10 reranked:" in log
+    for q in ("q1", "q2"):
+        sc = [float(r[4]) for r in rows if r[0] == q]
+        assert sc == sorted(sc, reverse=True) and all(0.0 < s < 1.0 for s in sc)
+    first = (tmp_path / "pw.trec").read_text()
+    (tmp_path / "pw_resume.trec").write_text("".join(l + "\n" for l in first.splitlines()[:6]))
+    run(t5, tmp_path / "pw_resume.trec", ["pointwise", "--method", "yes_no", "--batch_size", "4"], ["--resume"])
+    assert (tmp_path / "pw_resume.trec").read_text() == first
+    for name, ckpt, tail in (("sw_t5", t5, ["setwise", "--num_child", "3", "--k", "3"]),
+                             ("sw_t5_lik", t5, ["setwise", "--num_child", "2", "--k", "2", "--method", "bubblesort"]),
+                             ("sw_llama", llama, ["setwise", "--num_child", "3", "--k", "3"]),
+                             ("pair", t5, ["pairwise", "--method", "heapsort", "--k", "2"])):
+        extra = ["--scoring", "likelihood"] if name == "sw_t5_lik" else []
+        rows, _ = run(ckpt, tmp_path / f"{name}.trec", tail, extra)
+        assert len(rows) == 12, name
+        for q in ("q1", "q2"):
+            part = [r for r in rows if r[0] == q]
+            assert [int(r[3]) for r in part] == list(range(1, 7)) and [int(r[4]) for r in part] == [-i for i in range(1, 7)], name
+            assert sorted(r[2] for r in part) == [f"d{i}" for i in range(6)], name
