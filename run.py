@@ -196,6 +196,15 @@ def main(args):
     query_map, get_doc = load_queries_and_docs(args, ranker)
     logger.info(f"Loading first stage run from {args.run.run_path}.")
     first_stage, cur_qid, cur = [], None, []
+    # docid-keyed cache of the tokenise -> cut -> detokenise round trip (ref: pointwise.py:132-133, run.py:174): the same
+    # passage is retrieved for many queries, its truncated text is a pure function of (text, passage_length)
+    truncated = {}
+
+    def passage(docid):
+        if docid not in truncated:
+            truncated[docid] = ranker.truncate(get_doc(docid), args.run.passage_length)
+        return truncated[docid]
+
     with open(args.run.run_path) as f:
         for line in f:
             qid, _, docid, _, score, _ = line.strip().split()      # 6 whitespace-separated fields (ref: run.py:157)
@@ -205,7 +214,7 @@ def main(args):
                 cur, cur_qid = [], qid
             if len(cur) >= args.run.hits:
                 continue
-            cur.append(SearchResult(docid=docid, score=float(score), text=ranker.truncate(get_doc(docid), args.run.passage_length)))
+            cur.append(SearchResult(docid=docid, score=float(score), text=passage(docid)))
         if cur_qid is not None:
             first_stage.append((cur_qid, query_map[cur_qid], cur[:args.run.hits]))
 

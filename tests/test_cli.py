@@ -133,3 +133,38 @@ def test_resume_appends_and_skips_done_queries(runmod, tmp_path, ckpt_dirs, monk
     run(tmp_path / "s0.trec", ["--dataset_number_of_shards", "2", "--dataset_shard_index", "0"])
     run(tmp_path / "s1.trec", ["--dataset_number_of_shards", "2", "--dataset_shard_index", "1"])
     assert (tmp_path / "s0.trec").read_text() + (tmp_path / "s1.trec").read_text() == full
+
+
+def test_passage_truncation_is_cached_per_docid(runmod, tmp_path, ckpt_dirs, monkeypatch):
+    """The first-stage run lists the same passages for several queries; their tokenise / cut / detokenise round trip
+    (ref: pointwise.py:132-133) runs once per docid."""
+    from conftest import load_state
+    from _stub import OracleRuntime
+    from transformers import T5Tokenizer
+    from llmrankers.pointwise import PointwiseLlmRanker
+    ck = ckpt_dirs["ckpt_gated_untied"]
+    dims, state = load_state(ck)
+    tok = T5Tokenizer.from_pretrained(ck)
+    calls = []
+
+    def make(args):
+        rk = PointwiseLlmRanker.from_runtime(OracleRuntime(dims, state), tok, method="yes_no", batch_size=4)
+        orig = rk.truncate
+        rk.truncate = lambda text, n: (calls.append(text), orig(text, n))[1]
+        return rk
+
+    monkeypatch.setattr(runmod, "build_ranker", make)
+    (tmp_path / "q.tsv").write_text("q1\tneural ranking model\nq2\twater river mountain\nq3\tmusic art film\n")
+    docs = ["search engine index", "river water city", "music art film", "vaccine covid virus"]
+    (tmp_path / "d.tsv").write_text("\n".join(f"d{i}\t{w}" for i, w in enumerate(docs)) + "\n")
+    lines = [f"{q} Q0 d{i} {r + 1} {10 - r} bm25" for q in ("q1", "q2", "q3") for r, i in enumerate([0, 1, 2, 3])]
+    (tmp_path / "in.trec").write_text("\n".join(lines) + "\n")
+    parser, commands = runmod.build_parser()
+    args = runmod.parse_args(parser, commands, ["run", "--model_name_or_path", ck, "--run_path", str(tmp_path / "in.trec"),
+                                                "--save_path", str(tmp_path / "out.trec"), "--query_file", str(tmp_path / "q.tsv"),
+                                                "--doc_file", str(tmp_path / "d.tsv"), "--hits", "4", "pointwise", "--method", "yes_no",
+                                                "--batch_size", "4"])
+    runmod.validate(args)
+    runmod.main(args)
+    assert sorted(c for c in calls if c in docs) == sorted(docs)          # 4 passages truncated once each, not 12 times
+    assert len((tmp_path / "out.trec").read_text().splitlines()) == 12

@@ -11,7 +11,9 @@ Shims needed to import the reference under transformers 5.x (SURVEY.md section 8
   * `openai`, `tiktoken` stub modules (only used by the OpenAI ranker classes),
   * `T5Tokenizer.batch_encode_plus` (removed in 5.x; used at ref: llmrankers/setwise.py:55).
 
-Usage:  python tools/make_goldens.py            (rewrites tests/golden/)
+Usage:  python tools/make_goldens.py            (rewrites tests/golden/ except setwise_large.json, which
+                                                 tools/make_setwise_large_golden.py makes; then run tools/annotate_margins.py)
+        python tools/make_goldens.py --only-monot5 | --only-pairwise | --only-llama   (add one fixture family in place)
 """
 from __future__ import annotations
 
@@ -581,9 +583,17 @@ def main():
         return add_pairwise()
     if "--only-llama" in sys.argv:
         return add_llama()
+    keep = {}                                  # fixtures made by other tools survive a full regeneration
+    for fn in ("setwise_large.json",):         # tools/make_setwise_large_golden.py (30 CPU-minutes)
+        if os.path.exists(os.path.join(GOLD, fn)):
+            with open(os.path.join(GOLD, fn), "rb") as f:
+                keep[fn] = f.read()
     if os.path.isdir(GOLD):
         shutil.rmtree(GOLD)
     os.makedirs(GOLD)
+    for fn, data in keep.items():
+        with open(os.path.join(GOLD, fn), "wb") as f:
+            f.write(data)
     tok_dir = os.path.join(GOLD, "tok")
     tok = make_tokenizer(tok_dir)
     label_ids = [tok.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1] for c in LABELS]
@@ -625,6 +635,18 @@ def main():
     with open(os.path.join(GOLD, "ckpts.json"), "w") as f:
         json.dump(specs, f, indent=1)
     pairwise_goldens(ref_rankers, ref_pairwise, ckpts)
+    # Llama family: own tokenizer, checkpoint recipe, HF logits, reference setwise cases
+    ltok_dir = os.path.join(GOLD, "tok_llama")
+    ltok = make_llama_tokenizer(ltok_dir)
+    llabels = [ltok.encode(" Passage: " + c, add_special_tokens=False)[-1] for c in LABELS]
+    assert len(set(llabels)) == 23, llabels
+    spec = {"dims": "toy-llama", "seed": 21, "gain": 2.0, "boost_ids": llabels, "boost": 6.0, "tokenizer": "tok_llama"}
+    ck = os.path.join(tmp, "ckpt_llama")
+    spec["sha256"] = write_ckpt(ck, spec, ltok_dir)
+    specs["ckpt_llama"] = spec
+    with open(os.path.join(GOLD, "ckpts.json"), "w") as f:
+        json.dump(specs, f, indent=1)
+    llama_goldens(ref_rankers, ref_setwise, ck)
     with open(os.path.join(GOLD, "PROVENANCE.json"), "w") as f:
         import transformers, torch
         json.dump({"generator": "tools/make_goldens.py", "reference": "ielab/llm-rankers @ /root/reference (2025-07-18)",
@@ -632,7 +654,7 @@ def main():
                    "numpy": np.__version__}, f, indent=1)
     shutil.rmtree(tmp)
     total = sum(os.path.getsize(os.path.join(dp, fn)) for dp, _, fns in os.walk(GOLD) for fn in fns)
-    print(f"tests/golden: {total / 1e6:.2f} MB")
+    print(f"tests/golden: {total / 1e6:.2f} MB  (now run tools/annotate_margins.py to add the decision margins)")
 
 
 if __name__ == "__main__":
