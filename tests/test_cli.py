@@ -154,7 +154,7 @@ def test_passage_truncation_is_cached_per_docid(runmod, tmp_path, ckpt_dirs, mon
         return rk
 
     monkeypatch.setattr(runmod, "build_ranker", make)
-    (tmp_path / "q.tsv").write_text("q1\tneural ranking model\nq2\twater river mountain\nq3\tmusic art film\n")
+    (tmp_path / "q.tsv").write_text("q1\tneural ranking model\nq2\twater river mountain\nq3\tart history book\n")
     docs = ["search engine index", "river water city", "music art film", "vaccine covid virus"]
     (tmp_path / "d.tsv").write_text("\n".join(f"d{i}\t{w}" for i, w in enumerate(docs)) + "\n")
     lines = [f"{q} Q0 d{i} {r + 1} {10 - r} bm25" for q in ("q1", "q2", "q3") for r, i in enumerate([0, 1, 2, 3])]
