@@ -506,7 +506,8 @@ __global__ __launch_bounds__(128, 4) void gemm_s64_kernel(GemmArgs p) {
 // that needs only 16*NT KiB, so these workgroups still fit on a CU next to two resident encoder GEMM workgroups.
 // (Tried and dropped: fusing the decoder's RMSNorms into this kernel's activation loads - every workgroup recomputing the
 // row factors of its 32 rows and converting fp32 rows on the fly - removed three launches per layer but made the GEMMs
-// slower by more than the norm kernels cost: pointwise -1.7 %, a setwise compare 6.83 -> 6.98 ms.)
+// slower by more than the norm kernels cost: pointwise -1.7 %, a setwise compare 6.83 -> 6.98 ms.  Likewise 8 instead of
+// 4 K steps in flight per wave: the decoder GEMMs of a compare went 1.81 -> 2.13 ms.)
 #define SKINNY_THREADS 512
 template <int EPI, int NT>
 __global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p) {
