@@ -39,6 +39,10 @@ struct GemmArgs {
   // Producer (fp32 residual epilogue): besides C += acc, write fp16(C x xs) to xraw [M, ldx] and the sums of squares of
   // the new rows per 64-column block to ssq [M, nb]
   half_t* xraw; float* ssq; int ldx, nb; float xs;
+  // Weight-streaming (decoder) form of the same fold: the consumer has no separate statistics kernel in front of it - it adds
+  // the nb_in block sums of ssq_in [M, nb_in] (written by the producer GEMM before it, 32-column blocks) itself:
+  // row factor = rsqrt(sum / K + eps_in) / xs
+  const float* ssq_in; int nb_in; float eps_in;
 };
 
 #define GEMM_BM 128
@@ -120,7 +124,9 @@ __device__ __forceinline__ void gemm_tile_coords(int bid, int tiles_m, int tiles
 // wave tile at (mbase, nbase); valid_mi/valid_ni limit the fragments a caller actually computed.
 // The lane holds row m = mbase + mi*32 + l31 and, per register group q, 4 consecutive columns n.
 template <int EPI, int NI = 2, int MI = 2>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase, int l31, int hh) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase, int l31, int hh,
+                                              float rowfac = 1.f) {
+  const float sc = p.scale * rowfac;    // rowfac: folded-RMSNorm factor of this lane's row (MI == 1 callers), else 1
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = mbase + mi * 32 + l31;
@@ -135,7 +141,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
         half4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          o[j] = f2h_sat(gate_act<EPI>(acc[0][mi][4 * q + j] * p.scale) * (acc[NI - 1][mi][4 * q + j] * p.scale));
+          o[j] = f2h_sat(gate_act<EPI>(acc[0][mi][4 * q + j] * sc) * (acc[NI - 1][mi][4 * q + j] * sc));
         *(half4*)(C + (size_t)m * p.ldc + col) = o;
       }
     } else {
@@ -152,7 +158,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
           }
           float v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * q + j] * p.scale;
+          for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * q + j] * sc;
           if (EPI == EPI_STORE_F16 || EPI == EPI_RELU_F16) {
             half4 o;
 #pragma unroll
@@ -439,31 +445,45 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs p) {
 // One setwise prompt is M ~ 1.5k rows: 256- or 128-row tiles give the O / FFN-out projections 24 - 96 workgroups for 256
 // CUs.  This kernel cuts the output into 64x64 tiles (2 waves, each 32 rows x 64 columns = two MFMA 32x32 fragments) with
 // the same LDS image, swizzle, DMA staging, K order and epilogues as the 128x128 kernel - so a row's result is bit-identical
-// whichever variant runs - at 32 KiB of LDS per workgroup (five per CU).  Latency-bound by design: the point is 16x more
-// workgroups in flight, not MFMA rate.
-template <int EPI>
-__global__ __launch_bounds__(128, 4) void gemm_s64_kernel(GemmArgs p) {
+// whichever variant runs.  Latency-bound by design: the point is 16x more workgroups in flight, not MFMA rate.
+// NST LDS stages of 16 KiB (A + W tile): NST - 1 K tiles are in flight while one is consumed, waited for with counted vmcnt
+// (every wave issues exactly 8 DMA instructions per stage).  With all tiles of such a GEMM resident at once the launch lasts
+// nk x (time of one K step), and a K step of a 2-stage loop is one full L2 round trip (~1.2 us measured): 3 / 4 stages
+// divide that by 2 / 3 at 48 / 64 KiB of LDS (three / two workgroups per CU).
+template <int EPI, int NST>
+__global__ __launch_bounds__(128, NST == 4 ? 2 : (NST == 3 ? 3 : 4)) void gemm_s64_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
   half_t* smem = (half_t*)gemm_smem;
   constexpr int TILE = 64 * 64;                         // halfs per operand tile (8 KiB)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
   const int tiles_m = (p.M + 63) >> 6, tiles_n = (p.N + 63) >> 6;
   int tm, tn;
   gemm_tile_coords(blockIdx.x, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * 64, n0 = tn * 64;
   // DMA staging: a 64-row tile is 512 16-byte slots; wave w owns slots [w*256, w*256+256): 4 instructions of 64 lanes
-  auto stage = [&](half_t* s_tile, const half_t* g, int ld, int row0, int rows_total, int k0) {
+  const half_t* srcA[4];
+  const half_t* srcW[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pslot = (wave * 4 + i) * 64 + lane;
-      const int r = pslot >> 3, c = pslot & 7;
-      int grow = row0 + r;
-      grow = grow < rows_total ? grow : rows_total - 1;
-      const half_t* src = g + (size_t)grow * ld + k0 + ((c ^ ((r >> 1) & 7)) << 3);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(s_tile + (wave * 4 + i) * 512), 16, 0, 0);
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int pslot = (wave * 4 + i) * 64 + lane;
+    const int r = pslot >> 3, c = pslot & 7;
+    const int sw = (c ^ ((r >> 1) & 7)) << 3;
+    const int ga = m0 + r < p.M ? m0 + r : p.M - 1, gw = n0 + r < p.N ? n0 + r : p.N - 1;
+    srcA[i] = p.A + (size_t)ga * p.lda + sw;
+    srcW[i] = p.W + (size_t)gw * p.ldw + sw;
+  }
+  auto stage = [&](int buf, int kt) {
+    half_t* sA = smem + buf * 2 * TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(sA + (wave * 4 + i) * 512), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcW[i] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(sA + TILE + (wave * 4 + i) * 512), 16, 0, 0);
   };
   f32x16 acc[2][1];
 #pragma unroll
@@ -471,17 +491,21 @@ __global__ __launch_bounds__(128, 4) void gemm_s64_kernel(GemmArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
   const int nk = p.K >> 6;
-  stage(smem, p.A, p.lda, m0, p.M, 0);
-  stage(smem + TILE, p.W, p.ldw, n0, p.N, 0);
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) stage(s, s);
+  int cur = 0, nxt = NST - 1;                           // stage consumed / stage refilled this step
   for (int kt = 0; kt < nk; ++kt) {
-    half_t* sA = smem + (kt & 1) * 2 * TILE;
-    half_t* sW = sA + TILE;
-    __syncthreads();   // stage kt landed (the barrier's vmcnt(0) drains this wave's DMA); the other stage is free
-    if (kt + 1 < nk) {
-      half_t* nA = smem + ((kt + 1) & 1) * 2 * TILE;
-      stage(nA, p.A, p.lda, m0, p.M, (kt + 1) * 64);
-      stage(nA + TILE, p.W, p.ldw, n0, p.N, (kt + 1) * 64);
-    }
+    // stage kt has landed when at most min(NST - 2, nk - 1 - kt) younger stages of this wave are still in flight
+    const int younger = nk - 1 - kt < NST - 2 ? nk - 1 - kt : NST - 2;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // ... everyone's has; the stage consumed in step kt - 1 is free
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + NST - 1 < nk) stage(nxt, kt + NST - 1);
+    const half_t* sA = smem + cur * 2 * TILE;
+    const half_t* sW = sA + TILE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int cc = ks * 2 + hh;
@@ -490,6 +514,8 @@ __global__ __launch_bounds__(128, 4) void gemm_s64_kernel(GemmArgs p) {
       for (int ni = 0; ni < 2; ++ni)
         acc[ni][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gemm_frag(sW, ni * 32 + l31, cc), af, acc[ni][0], 0, 0, 0);
     }
+    cur = cur + 1 == NST ? 0 : cur + 1;
+    nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
   __syncthreads();     // every wave is done reading the last stage: LDS becomes the epilogue staging area
   float rsc[1];
@@ -534,6 +560,36 @@ __global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p)
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][0][r] = 0.f;
+  // Wave 0 writes the result: what its epilogue reads besides the accumulators is requested now and travels under the
+  // weight stream - the old fp32 rows of a residual add (registers), the block sums of squares of a folded RMSNorm (DMA
+  // straight into LDS: no registers held across the main loop, the occupancy of this kernel is what hides its latency).
+  __shared__ f32x4 sqs[8 * 64];                 // [instruction][lane]: float4 2i + (lane >> 5) of row (lane & 31)
+  f32x4 old[EPI == EPI_RESID_F32 ? 4 : 1];
+  float rowfac = 1.f;
+  const bool row_ok = mrow0 + l31 < p.M;
+  const bool sq_here = p.ssq_in && !p.rowscale;
+  const bool sq_dma = sq_here && (p.nb_in & 3) == 0 && p.nb_in <= 64;
+  if (wave == 0) {
+    if constexpr (EPI == EPI_RESID_F32) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + 8 * q + 4 * hh;
+        old[q] = (row_ok && n < p.N) ? *(const f32x4*)((const float*)p.C + (size_t)m * p.ldc + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    if (p.rowscale) rowfac = p.rowscale[m];
+    else if (sq_dma) {
+      const int nq = p.nb_in >> 2;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (2 * i < nq) {
+          const int j = 2 * i + hh < nq ? 2 * i + hh : nq - 1;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.ssq_in + (size_t)m * p.nb_in + 4 * j),
+                                           (__attribute__((address_space(3))) void*)(sqs + i * 64), 16, 0, 0);
+        }
+      }
+    }
+  }
   int s = wave;
   for (; s + 24 < nsteps; s += 32) {
     half8 bf[4], wf[4][NT];
@@ -576,7 +632,50 @@ __global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p)
     }
     __syncthreads();
   }
-  if (wave == 0) gemm_epilogue<EPI, NT, 1>(p, acc, mrow0, n0, l31, hh);
+  if (wave != 0) return;
+  if (sq_here) {
+    // blocks added in increasing order, whatever the path (the DMA landed long ago: every barrier above drained vmcnt)
+    float ssum = 0.f;
+    if (sq_dma) {
+      const int nq = p.nb_in >> 2;
+      for (int j = 0; j < nq; ++j) {
+        const f32x4 v = sqs[(j >> 1) * 64 + (j & 1) * 32 + l31];
+        ssum += v[0]; ssum += v[1]; ssum += v[2]; ssum += v[3];
+      }
+    } else {
+      for (int j = 0; j < p.nb_in; ++j) ssum += p.ssq_in[(size_t)m * p.nb_in + j];
+    }
+    rowfac = rsqrtf(ssum / (float)p.K + p.eps_in) / p.xs;
+  }
+  if constexpr (EPI == EPI_RESID_F32) {
+    // C += acc (old rows prefetched above); with p.xraw also the fp16 copy of the new row and the sum of squares of this
+    // workgroup's 32 columns (producer side of the next folded norm): a lane holds 16 of them, its partner (lane ^ 32) the rest
+    const float sc = p.scale * rowfac;
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + 8 * q + 4 * hh;
+      const bool ok = row_ok && n < p.N;
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = old[q][j] + acc[0][0][4 * q + j] * sc;
+      if (ok) {
+        *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = o;
+        if (p.xraw) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ss = __builtin_fmaf(o[j], o[j], ss);
+          const half4 xr = {f2h_sat(o[0] * p.xs), f2h_sat(o[1] * p.xs), f2h_sat(o[2] * p.xs), f2h_sat(o[3] * p.xs)};
+          *(half4*)(p.xraw + (size_t)m * p.ldx + n) = xr;
+        }
+      }
+    }
+    if (p.xraw) {
+      ss += __shfl_xor(ss, 32);
+      if (hh == 0 && row_ok) p.ssq[(size_t)m * p.nb + (n0 >> 5)] = ss;
+    }
+  } else {
+    gemm_epilogue<EPI, NT, 1>(p, acc, mrow0, n0, l31, hh, rowfac);
+  }
 }
 
 // ================================= GEMM v2: 256-row tiles ==================================================

@@ -52,6 +52,7 @@ struct DecLayerW {
   half_t* ckT = nullptr;    // cross-attention W_k regrouped per head and transposed: [H][d_model][64] (direct path)
   half_t* ov = nullptr;     // self-attention W_o W_v [d_model, d_model]: the whole sub-layer at L_d = 1
   float *ln0 = nullptr, *ln1 = nullptr, *ln2 = nullptr;
+  half_t *qkv_f = nullptr, *ov_f = nullptr, *cq_f = nullptr, *ffn_in_f = nullptr;   // norm weight folded in (W[n][k] * ln[k]), as in the encoder
 };
 
 // Llama-family decoder layer (hf: modeling_llama.py:291-330): fused q|k|v and interleaved gate|up carry the RMSNorm weights
@@ -76,6 +77,7 @@ struct Slot {
   half_t* cross_kv = nullptr;                                  // [n_dec][max_tokens][2I] encoder -> decoder hand-off
   int *d_dec_ids = nullptr, *d_last_rows = nullptr, *d_out_ids = nullptr, *d_labels = nullptr, *d_argmax = nullptr;
   float* dhidden = nullptr; half_t *dxn = nullptr, *dqkv = nullptr, *dctx = nullptr, *dq = nullptr, *dffh = nullptr, *dlast = nullptr;
+  half_t* dxraw[2] = {nullptr, nullptr}; float* dssq[2] = {nullptr, nullptr}; float* drowscale = nullptr;   // folded decoder norms (run_decoder)
   half_t *xqk = nullptr, *xctx = nullptr;                      // direct cross-attention: [32][H*d] each
   float *xpart = nullptr, *xstat = nullptr; bool have_cross_kv = false;
   float* d_scores = nullptr; float* h_scores = nullptr;
@@ -101,7 +103,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1;
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
@@ -257,10 +259,23 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
   }
 #endif
   if (variant == 6) {
-    static std::atomic<uint64_t> attr_done{0};
-    ensure_dynamic_lds((const void*)gemm_s64_kernel<EPI>, 32768, attr_done);
     const int tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
-    hipLaunchKernelGGL((gemm_s64_kernel<EPI>), dim3(tiles), dim3(128), 32768, st, a);
+    // stages: as many as keep every tile resident at once (4 -> 2 workgroups per CU, 3 -> 3, 2 -> 4)
+    int nst = e->opt_s64_stages;
+    if (nst < 2 || nst > 4) nst = tiles <= 2 * e->n_cu ? 4 : (tiles <= 3 * e->n_cu ? 3 : 2);
+    if (nst == 4) {
+      static std::atomic<uint64_t> attr_done{0};
+      ensure_dynamic_lds((const void*)gemm_s64_kernel<EPI, 4>, 65536, attr_done);
+      hipLaunchKernelGGL((gemm_s64_kernel<EPI, 4>), dim3(tiles), dim3(128), 65536, st, a);
+    } else if (nst == 3) {
+      static std::atomic<uint64_t> attr_done{0};
+      ensure_dynamic_lds((const void*)gemm_s64_kernel<EPI, 3>, 49152, attr_done);
+      hipLaunchKernelGGL((gemm_s64_kernel<EPI, 3>), dim3(tiles), dim3(128), 49152, st, a);
+    } else {
+      static std::atomic<uint64_t> attr_done{0};
+      ensure_dynamic_lds((const void*)gemm_s64_kernel<EPI, 2>, 32768, attr_done);
+      hipLaunchKernelGGL((gemm_s64_kernel<EPI, 2>), dim3(tiles), dim3(128), 32768, st, a);
+    }
     return;
   }
   if (variant > 6) variant = 5;
@@ -287,7 +302,7 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
 // Folded RMSNorm hooks of one GEMM launch (GemmArgs): consumer side = rowscale, producer side = xraw + ssq.
 #define RK_XRAW_SCALE 0.0625f   // the fp16 copy of the fp32 residual stream is stored x 2^-4: head-room for the outlier
                                 // channels of real T5 checkpoints (fp16 max 65504 -> 1.0e6), exact (power of two)
-struct GemmFold { const float* rowscale = nullptr; half_t* xraw = nullptr; float* ssq = nullptr; };
+struct GemmFold { const float* rowscale = nullptr; half_t* xraw = nullptr; float* ssq = nullptr; const float* ssq_in = nullptr; };
 
 void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int lda, const half_t* W, int ldw, void* C,
           int ldc, int M, int N, int K, int n_split = 0, long split_stride = 0, float scale = 1.f,
@@ -295,6 +310,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
   if (M <= 0) return;
   GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale, bsA, bsW, bsC};
   a.rowscale = fold.rowscale; a.xraw = fold.xraw; a.ssq = fold.ssq; a.ldx = N; a.nb = (N + 63) / 64; a.xs = RK_XRAW_SCALE;
+  a.ssq_in = fold.ssq_in; a.nb_in = (K + 31) / 32; a.eps_in = e->d.eps;
   const double flops = 2.0 * M * (double)N * K * batch;
   const double out_elems = EPI_IS_GATED(epi) ? (double)M * N / 2 : (double)M * N;
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
@@ -308,6 +324,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
     // kernel delaying some tile of the GEMM in flight, not its CU-time; so: many short workgroups)
     const dim3 b(SKINNY_THREADS);
     const unsigned gy = (unsigned)batch, gz = (unsigned)((M + 31) / 32);
+    a.nb = (N + 31) / 32;                                     // this kernel's producer blocks are 32 columns wide
     switch (epi) {
       case EPI_STORE_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F16, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
       case EPI_RESID_F32: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RESID_F32, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
@@ -505,26 +522,48 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
   hipStream_t st = dec_stream(e, sl);
   const int B = sl.n_seq, M = B * Ld, I = e->inner, dm = d.d_model, F = d.d_ff;
   const bool ws = Ld <= 4;   // few decoder positions: weight-streaming GEMMs (any number of sequences); else tiled
-  embed(e, st, sl.d_dec_ids, sl.dhidden, M);
+  // Folded RMSNorm on the weight-streaming path (as in the encoder, minus the statistics kernel): the residual GEMMs leave
+  // the new rows as fp16 (dxraw) with their sums of squares per 32-column block (dssq), the GEMM behind the norm reads
+  // those with the norm weight folded into its matrix and forms the row factor itself (gemm.h: GemmArgs::ssq_in) - three
+  // launches per layer less.  A producer never writes the buffer a workgroup of the same launch may still read: two of each.
+  const bool dfold = ws && e->opt_dec_fold_norm && (e->opt_skinny & 0x3F) == 0x3F;
+  int cur = 0; bool from_embed = true;
+  auto cons = [&]() { GemmFold f; if (from_embed) f.rowscale = sl.drowscale; else f.ssq_in = sl.dssq[cur]; return f; };
+  auto with_prod = [&](GemmFold f) { f.xraw = sl.dxraw[cur ^ 1]; f.ssq = sl.dssq[cur ^ 1]; return f; };
+  auto flip = [&]() { cur ^= 1; from_embed = false; };
+  embed(e, st, sl.d_dec_ids, sl.dhidden, M, dfold ? sl.dxraw[0] : nullptr, dfold ? sl.drowscale : nullptr);
   const size_t smem_self = (64 + 256 + 8 + (size_t)Ld) * sizeof(float);
   const size_t smem_cross = (64 + 256 + 8 + (size_t)sl.maxL) * sizeof(float);
   for (int l = 0; l < d.n_dec_layers; ++l) {
     const DecLayerW& w = e->dec[l];
-    rmsnorm(e, st, sl.dhidden, w.ln0, sl.dxn, nullptr, M);
+    if (!dfold) rmsnorm(e, st, sl.dhidden, w.ln0, sl.dxn, nullptr, M);
     if (Ld == 1) {
       // one decoder position: softmax over a single key is 1, so self-attention is exactly o(v(x)) — the q/k
       // projections, scores and bias are dead (hf: modeling_t5.py:448-509 at L_d = 1)
       // ... and o(v(x)) = (W_o W_v) x: one GEMM with the product matrix formed once at finalize
-      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dxn, dm, w.ov, dm, sl.dhidden, dm, M, dm, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
+      if (dfold) {
+        gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dxraw[cur], dm, w.ov_f, dm, sl.dhidden, dm, M, dm, dm, 0, 0, 1.f, 1, 0, 0, 0, ws, with_prod(cons()));
+        flip();
+      } else {
+        gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dxn, dm, w.ov, dm, sl.dhidden, dm, M, dm, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
+      }
     } else {
-      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.qkv, dm, sl.dqkv, 3 * I, M, 3 * I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
+      if (dfold) gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxraw[cur], dm, w.qkv_f, dm, sl.dqkv, 3 * I, M, 3 * I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws, cons());
+      else gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.qkv, dm, sl.dqkv, 3 * I, M, 3 * I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
       AttnDecArgs a{sl.dqkv, 3 * I, sl.dqkv + I, sl.dqkv + 2 * I, 3 * I, nullptr, sl.dctx, I, e->lut_dec, Ld, 1, Ld};
-      Bracket br(e, st, PC_DEC_ATTN, 4.0 * M * Ld * I, 0);
-      hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_self, st, a);
-      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.o, I, sl.dhidden, dm, M, dm, I, 0, 0, 1.f, 1, 0, 0, 0, ws);
+      {
+        Bracket br(e, st, PC_DEC_ATTN, 4.0 * M * Ld * I, 0);
+        hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_self, st, a);
+      }
+      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.o, I, sl.dhidden, dm, M, dm, I, 0, 0, 1.f, 1, 0, 0, 0, ws, dfold ? with_prod(GemmFold()) : GemmFold());
+      if (dfold) flip();
     }
-    rmsnorm(e, st, sl.dhidden, w.ln1, sl.dxn, nullptr, M);
-    gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.cq, dm, sl.dq, I, M, I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
+    if (dfold) {
+      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxraw[cur], dm, w.cq_f, dm, sl.dq, I, M, I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws, cons());
+    } else {
+      rmsnorm(e, st, sl.dhidden, w.ln1, sl.dxn, nullptr, M);
+      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.cq, dm, sl.dq, I, M, I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
+    }
     if (!sl.have_cross_kv) {
       // query-side cross-attention: qk = W_k^T q per head; scores/softmax/weighted sum over the raw encoder states;
       // ctx = W_v (.) per head  (attention.h: XAttnArgs)
@@ -550,6 +589,16 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
       AttnDecArgs a{sl.dq, I, kv, kv + I, 2 * I, sl.d_seq_off, sl.dctx, I, nullptr, Ld, 0, sl.maxL};
       Bracket br(e, st, PC_DEC_ATTN, 4.0 * Ld * (double)sl.T * I, (double)sl.T * 2 * I * 2.0);
       hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_cross, st, a);
+    }
+    if (dfold) {
+      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.co, I, sl.dhidden, dm, M, dm, I, 0, 0, 1.f, 1, 0, 0, 0, ws, with_prod(GemmFold()));
+      flip();
+      gemm(e, st, PC_DEC_GEMM, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, sl.dxraw[cur], dm, w.ffn_in_f, dm, sl.dffh, F, M,
+           d.gated_gelu ? 2 * F : F, dm, 0, 0, 1.f, 1, 0, 0, 0, ws, cons());
+      const bool last = l + 1 == d.n_dec_layers;   // the final norm (head kernels) reads the fp32 stream itself
+      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dffh, F, w.ffn_out, F, sl.dhidden, dm, M, dm, F, 0, 0, 1.f, 1, 0, 0, 0, ws, last ? GemmFold() : with_prod(GemmFold()));
+      if (!last) flip();
+      continue;
     }
     gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.co, I, sl.dhidden, dm, M, dm, I, 0, 0, 1.f, 1, 0, 0, 0, ws);
     rmsnorm(e, st, sl.dhidden, w.ln2, sl.dxn, nullptr, M);
@@ -1017,6 +1066,18 @@ int rk_engine_finalize(rk_engine* e) {
     RC(up_f(&w.ln0, Fv(p + ".0.layer_norm.weight")));
     RC(up_f(&w.ln1, Fv(p + ".1.layer_norm.weight")));
     RC(up_f(&w.ln2, Fv(p + ".2.layer_norm.weight")));
+    {
+      auto folded = [&](const std::vector<half_t>& wm, const std::vector<float>& ln) {
+        std::vector<half_t> v(wm.size());
+        const size_t rows = wm.size() / dm;
+        for (size_t r = 0; r < rows; ++r)
+          for (int k = 0; k < dm; ++k) v[r * dm + k] = (half_t)((float)wm[r * dm + k] * ln[k]);
+        return v;
+      };
+      RC(up_h(&w.qkv_f, folded(cat3(p + ".0.SelfAttention."), Fv(p + ".0.layer_norm.weight"))));
+      RC(up_h(&w.cq_f, folded(H(p + ".1.EncDecAttention.q.weight"), Fv(p + ".1.layer_norm.weight"))));
+      RC(up_h(&w.ffn_in_f, folded(ffn_in(p + ".2.DenseReluDense"), Fv(p + ".2.layer_norm.weight"))));
+    }
     for (const char* m : {"k", "v"}) { const auto& s = H(p + ".1.EncDecAttention." + m + ".weight"); ckv.insert(ckv.end(), s.begin(), s.end()); }
   }
   RC(up_h(&e->cross_kv_w, ckv));
@@ -1038,6 +1099,9 @@ int rk_engine_finalize(rk_engine* e) {
       HIPCHK(e, hipMemcpy(ov32.data(), d_ov32, ov32.size() * 4, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < ov32.size(); ++i) ov16[i] = (half_t)ov32[i];
       RC(up_h(&e->dec[l].ov, ov16));
+      const auto& ln0 = Fv("decoder.block." + std::to_string(l) + ".layer.0.layer_norm.weight");
+      for (size_t i = 0; i < ov32.size(); ++i) ov16[i] = (half_t)(ov32[i] * ln0[i % dm]);
+      RC(up_h(&e->dec[l].ov_f, ov16));
     }
     e->opt_gemm_variant = saved_variant;
     HIPCHK(e, hipGetLastError());
@@ -1059,6 +1123,8 @@ int rk_engine_finalize(rk_engine* e) {
     RC(dalloc(e, &sl.dhidden, Mc * dm)); RC(dalloc(e, &sl.dxn, Mc * dm)); RC(dalloc(e, &sl.dqkv, Mc * 3 * I));
     RC(dalloc(e, &sl.dctx, Mc * I)); RC(dalloc(e, &sl.dq, Mc * I)); RC(dalloc(e, &sl.dffh, Mc * F));
     RC(dalloc(e, &sl.dlast, Bc * dm));
+    for (int i = 0; i < 2; ++i) { RC(dalloc(e, &sl.dxraw[i], Mc * dm)); RC(dalloc(e, &sl.dssq[i], Mc * ((dm + 31) / 32))); }
+    RC(dalloc(e, &sl.drowscale, Mc));
     RC(dalloc(e, &sl.xqk, (size_t)XA_MAX_ROWS * d.n_heads * dm)); RC(dalloc(e, &sl.xctx, (size_t)XA_MAX_ROWS * d.n_heads * dm));
     RC(dalloc(e, &sl.xpart, (size_t)XA_MAX_CHUNKS * d.n_heads * dm)); RC(dalloc(e, &sl.xstat, (size_t)XA_MAX_CHUNKS * d.n_heads * 2));
     RC(dalloc(e, &sl.d_scores, e->scores_cap));
@@ -1559,6 +1625,8 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x3F : value; return RK_OK; }   // bit per epilogue kind
   if (!strcmp(key, "gemm_persistent")) { e->opt_gemm_persistent = value; return RK_OK; }   // ping-pong GEMM: 1 = one workgroup per CU walks the tiles
   if (!strcmp(key, "attn_tiled_occ")) { e->opt_attn_tiled_occ = value; return RK_OK; }   // tiled encoder attention: register budget for 1 / 2 / 3 waves per SIMD
+  if (!strcmp(key, "gemm_s64_stages")) { e->opt_s64_stages = value; return RK_OK; }   // LDS stages of the 64x64 GEMM: 0 = auto, 2..4
+  if (!strcmp(key, "dec_fold_norm")) { e->opt_dec_fold_norm = value != 0; return RK_OK; }   // decoder RMSNorms folded into the weight-streaming GEMMs (1) or separate kernels (0)
   if (!strcmp(key, "fold_norm")) { e->opt_fold_norm = value != 0; return RK_OK; }           // encoder RMSNorm folded into the GEMMs (1) or separate kernels (0)
 #ifdef RK_MEASURE
   if (!strcmp(key, "attn_ko")) { e->opt_attn_ko = value; return RK_OK; }   // timing-only knock-outs, see AttnEncArgs

@@ -93,6 +93,31 @@ def test_pingpong_gemm_random_shapes_bit_equal_to_lockstep_kernel(toy):
         assert np.abs(ref - want).max() < 2e-3 * np.sqrt(k)
 
 
+def test_small_tile_gemm_stage_counts_bit_equal_to_lockstep_kernel(toy):
+    """The 64x64 kernel keeps 1 - 3 K tiles of DMA in flight with counted vmcnt (2 / 3 / 4 LDS stages): every stage count,
+    K from one tile (shorter than the pipeline) to 44 tiles, each run three times, bit-equal to the lock-step kernel."""
+    eng = toy["ckpt_gated_untied"][2]
+    rs = np.random.RandomState(20260927)
+    shapes = [(int(rs.randint(1, 1500)), int(rs.randint(1, 300)) * 4, int(rs.randint(1, 24)) * 64) for _ in range(12)]
+    shapes += [(1450, 1024, 1024), (1450, 1024, 2816), (64, 64, 64), (65, 68, 128), (130, 64, 192), (2900, 1024, 256)]
+    for m, n, k in shapes:
+        a = rs.standard_normal((m, k)).astype(np.float16)
+        w = rs.standard_normal((n, k)).astype(np.float16)
+        try:
+            eng.set_option("gemm_variant", 2)
+            ref = eng.debug_gemm(a, w, use_glds=True)
+            eng.set_option("gemm_variant", 6)
+            for nst in (0, 2, 3, 4):
+                eng.set_option("gemm_s64_stages", nst)
+                for _ in range(3):
+                    np.testing.assert_array_equal(eng.debug_gemm(a, w, use_glds=True), ref, err_msg=f"shape {(m, n, k)} stages {nst}")
+        finally:
+            eng.set_option("gemm_variant", 0)
+            eng.set_option("gemm_s64_stages", 0)
+        want = a.astype(np.float32) @ w.astype(np.float32).T
+        assert np.abs(ref - want).max() < 2e-3 * np.sqrt(k)
+
+
 @pytest.mark.parametrize("shape", [(1, 64, 64), (32, 128, 1024), (33, 96, 192), (100, 1024, 2816), (256, 1024, 1024), (200, 96, 2816)])
 def test_weight_streaming_gemm_vs_numpy(toy, shape):
     """The decoder's split-K kernel: fixed reduction tree -> every row is independent of how many rows share the launch."""
@@ -342,6 +367,35 @@ def test_folded_rmsnorm_matches_separate_norm_kernels(toy):
     assert np.abs(fold - want).max() < LOGIT_TOL and np.abs(plain - want).max() < LOGIT_TOL
     assert np.abs(_sigm(fold[:, 0] - fold[:, 1]) - _sigm(want[:, 0] - want[:, 1])).max() < SCORE_TOL
     np.testing.assert_array_equal(eng.score(seqs[2:5], [0], ids), fold[2:5])       # batch independence holds for the folded path
+
+
+@pytest.mark.parametrize("ckpt", ["ckpt_gated_untied", "ckpt_relu_tied"])
+def test_decoder_folded_rmsnorm_matches_separate_norm_kernels(toy, ckpt):
+    """Default decoder path for up to 4 decoder positions: the three RMSNorms of a layer are folded into the weight-streaming
+    GEMMs (the residual GEMMs leave fp16 rows + block sums of squares, the next GEMM forms the row factor itself).  Scores
+    at L_d = 1 (product matrix: consumer and producer in one launch), 2 and 3 agree with the separate-kernel path and
+    the fp32 oracle; rows stay independent of the batch they are scored in (bit-exact)."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle
+    dims, state, eng = toy[ckpt]
+    seqs = _synth.synth_token_batch(37, 3, 150, dims.vocab, seed=78)      # 37 rows: two 32-row slabs of the GEMMs
+    ids = [11, 12, 13, 14]
+    orc = T5Oracle(dims, state)
+    for prefix in ([0], [0, 17], [0, 17, 5]):
+        want = orc.score_last(seqs[:9], prefix, ids)
+        try:
+            eng.set_option("dec_fold_norm", 0)
+            plain = eng.score(seqs, prefix, ids)
+        finally:
+            eng.set_option("dec_fold_norm", 1)
+        fold = eng.score(seqs, prefix, ids)
+        assert np.abs(fold - plain).max() < 5e-3, (prefix, np.abs(fold - plain).max())
+        assert np.abs(fold[:9] - want).max() < LOGIT_TOL and np.abs(plain[:9] - want).max() < LOGIT_TOL, prefix
+        np.testing.assert_array_equal(eng.score(seqs[30:35], prefix, ids), fold[30:35])
+        np.testing.assert_array_equal(eng.score(seqs[3:4], prefix, ids), fold[3:4])
+    tok, _ = eng.greedy(seqs[:6], [0], 3)                                   # L_d grows 1 -> 3 across the steps
+    for i in (0, 5):
+        np.testing.assert_array_equal(eng.greedy(seqs[i:i + 1], [0], 3)[0][0], tok[i])
 
 
 def test_comm_single_rank_gather_equals_local_scores(toy):
