@@ -1,0 +1,94 @@
+"""The exact word-level token memo of llmrankers._batching: ids identical to the tokenizer's own for
+every prompt shape the rankers build, untouched tokenizers it does not model, and the self-check that switches it off."""
+import json
+import os
+import random
+import warnings
+
+import pytest
+
+from conftest import GOLD
+from llmrankers import _batching
+from llmrankers._batching import WordSpliceTokenizer, tokenize_prompts
+
+
+@pytest.fixture(scope="module")
+def tok():
+    from transformers import T5Tokenizer
+    return T5Tokenizer.from_pretrained(os.path.join(GOLD, "tok"))
+
+
+def full(tok, prompts):
+    return [list(x) for x in tok(list(prompts))["input_ids"]]
+
+
+def test_memo_is_exact_on_ranker_prompts_and_odd_text(tok):
+    with open(os.path.join(GOLD, "rerank_cases.json")) as f:
+        cases = json.load(f)["cases"]
+    texts = [t for c in cases for _, _, t in c["input"]][:200]
+    rs = random.Random(5)
+    prompts = []
+    for i in range(40):                                                    # the three prompt templates (ref: pointwise.py:41-47, setwise.py:106-111)
+        docs = rs.sample(texts, 4)
+        q = rs.choice(texts)[:40]
+        prompts.append(f"Passage: {docs[0]}\nQuery: {q}\nDoes the passage answer the query? Answer 'Yes' or 'No'")
+        body = "\n\n".join(f'Passage {chr(65 + j)}: "{d}"' for j, d in enumerate(docs))
+        prompts.append(f'Given a query "{q}", which of the following passages is the most relevant one to the query?\n\n{body}'
+                       f"\n\nOutput only the passage label of the most relevant passage:")
+        prompts.append(f"Passage: {docs[1]}\nPlease write a question based on this passage.")
+    prompts += ["", " ", "\n", "a", "  leading and   double  spaces ", "tab\tinside word", "new\nline\n\nblocks\n",
+                "unicode: café naïve 中文 \U0001F600 nb sp zero​width", "punct!? (x) [y] {z} a-b_c 3.14 1,000",
+                "</s> inside <pad> text <extra_id_0> end", "\"quoted\" 'single' ``ticks''", "x" * 300]
+    memo = WordSpliceTokenizer(tok, verify_first=0, verify_every=10 ** 9)  # no self-check: the memo alone must be right
+    assert memo.enabled
+    assert memo(prompts) == full(tok, prompts)
+    assert memo(prompts[::-1]) == full(tok, prompts[::-1])                  # warm: every word from the dictionary
+    assert memo.enabled and len(memo.words) > 100
+
+
+def test_module_entry_point_uses_one_memo_per_tokenizer_and_honours_the_switch(tok, monkeypatch):
+    prompts = ["Passage: alpha beta\nQuery: gamma", "Passage A: \"alpha\"\n\nPassage B: \"beta gamma\""]
+    assert tokenize_prompts(tok, prompts) == full(tok, prompts)
+    assert tokenize_prompts(tok, []) == []
+    memo = _batching._MEMOS[tok]
+    assert memo.enabled and "alpha" in memo.words
+    assert tokenize_prompts(tok, prompts[:1]) == full(tok, prompts[:1]) and _batching._MEMOS[tok] is memo
+    monkeypatch.setenv("RK_TOKEN_CACHE", "0")
+    assert not WordSpliceTokenizer(tok).enabled
+
+
+def test_other_tokenizer_families_go_to_the_tokenizer(tok):
+    from transformers import AutoTokenizer
+    llama = AutoTokenizer.from_pretrained(os.path.join(GOLD, "tok_llama"))
+    memo = WordSpliceTokenizer(llama)
+    assert not memo.enabled                                                 # byte-level BPE: not word-separable as modelled
+    p = ["Passage A: \"x y\"\n\nPassage B: \"z\""]
+    assert memo(p) == full(llama, p)
+
+    class Plain:                                                            # no tokenizers backend at all (test stubs)
+        def __call__(self, texts, **kw):
+            return {"input_ids": [[len(t)] for t in texts]}
+    assert tokenize_prompts(Plain(), ["ab", "c"]) == [[2], [1]]
+
+
+def test_self_check_switches_the_memo_off_on_the_first_difference(tok):
+    class ContextDependent:
+        """Claims the T5 backend but glues a marker to the ids of any text that contains 'magic' somewhere else."""
+        backend_tokenizer = tok.backend_tokenizer
+
+        def __call__(self, texts, **kw):
+            single = isinstance(texts, str)
+            out = tok([texts] if single else list(texts), **kw)["input_ids"]
+            out = [list(ids) + ([7] if ("magic" in t and " " in t.strip()) else []) for ids, t in zip(out, [texts] if single else texts)]
+            return {"input_ids": out[0] if single else out}
+
+    fake = ContextDependent()
+    memo = WordSpliceTokenizer(fake, verify_first=2, verify_every=4)
+    assert memo.enabled
+    assert memo(["plain words only"]) == fake(["plain words only"])["input_ids"]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = memo(["some magic here", "more words"])
+    assert got == fake(["some magic here", "more words"])["input_ids"]      # the caller still gets the tokenizer's ids
+    assert not memo.enabled and w and "switched off" in str(w[0].message)
+    assert memo(["some magic here"]) == fake(["some magic here"])["input_ids"]
