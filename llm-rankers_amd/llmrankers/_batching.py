@@ -8,7 +8,6 @@ derives from the padded shape (total_prompt_tokens, ref: pointwise.py:107,114) i
 """
 import json
 import os
-import re
 import warnings
 import weakref
 from itertools import chain
@@ -32,7 +31,7 @@ class WordSpliceTokenizer:
     compared with the tokenizer's own on the first prompts and then at a fixed stride; the first difference
     switches the memo off for good.  `RK_TOKEN_CACHE=0` disables it.
     """
-    _SEP = re.compile(r"[ \n]+")     # separators both before and after the normaliser; other blanks stay inside a "word"
+    # words are cut at ' ' and '\n' only: separators both before and after the normaliser; other blanks stay inside a "word"
     MAX_WORDS = 2_000_000
 
     def __init__(self, tokenizer, verify_first: int = 4, verify_every: int = 128):
@@ -76,7 +75,7 @@ class WordSpliceTokenizer:
             return False
 
     def _splice(self, prompts: Sequence[str]) -> List[List[int]]:
-        pieces = [[w for w in self._SEP.split(p) if w] for p in prompts]
+        pieces = [[w for w in p.replace("\n", " ").split(" ") if w] for p in prompts]
         words = self.words
         missing = {w for ws in pieces for w in ws if w not in words}
         if missing:

@@ -7,7 +7,6 @@ one label-row read at decoder position 1 (`scoring='likelihood'`, rk_t5_score wi
 Llama-family models (ref: setwise.py:60-69,159-177): chat-template prompt + " Passage:", prefill and ONE greedy token
 (rk_llama_greedy1); `likelihood` scoring raises NotImplementedError for them exactly as in the reference.
 """
-import copy
 import random
 from collections import Counter
 from typing import List
@@ -330,7 +329,7 @@ class SetwiseLlmRanker(LlmRanker):
 
     def rerank(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
         # ref: setwise.py:234-313.  NB: like the reference, the caller's list is re-ordered in place.
-        original_ranking = copy.deepcopy(ranking)
+        original_docids = [doc.docid for doc in ranking]     # (the reference deep-copies the whole list: 3 ms for 100 passages; only the docid order is read)
         self.total_compare = 0
         self.total_completion_tokens = 0
         self.total_prompt_tokens = 0
@@ -346,9 +345,9 @@ class SetwiseLlmRanker(LlmRanker):
             top_doc_ids.add(doc.docid)
             results.append(SearchResult(docid=doc.docid, score=-rank, text=None))
             rank += 1
-        for doc in original_ranking:
-            if doc.docid not in top_doc_ids:
-                results.append(SearchResult(docid=doc.docid, score=-rank, text=None))
+        for docid in original_docids:
+            if docid not in top_doc_ids:
+                results.append(SearchResult(docid=docid, score=-rank, text=None))
                 rank += 1
         return results
 
