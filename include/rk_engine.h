@@ -83,6 +83,15 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
                  const int32_t* dec_prefix, int dec_len, int max_new, int eos_id, int pad_id,
                  int32_t* out_tokens, int32_t* out_steps);
 
+/* rk_t5_greedy with max_new = 2 and a hint: the first new token is expected to be one of cand_ids[n_cand] (the passage
+ * labels of a setwise compare).  Both steps then run in ONE decoder pass - the second speculatively for every candidate -
+ * and out_tokens[n_seq][2] / *out_steps are bit-identical to rk_t5_greedy's; any other first token, or a batch that does
+ * not fit the workspace, falls back to rk_t5_greedy itself.
+ * replaces: self.llm.generate(input_ids, decoder_input_ids=..., max_new_tokens=2)  (setwise.py:113-115) */
+int rk_t5_greedy2(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq,
+                  const int32_t* dec_prefix, int dec_len, const int32_t* cand_ids, int n_cand, int eos_id, int pad_id,
+                  int32_t* out_tokens, int32_t* out_steps);
+
 /* ---- staged / asynchronous form: inputs resident in HBM, used by bench.py and the multi-GPU driver ---- */
 int rk_t5_stage(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq);   /* H2D, synchronous */
 /* enqueue encoder + decoder + head on the engine stream for the staged batch; scores land in an engine-owned

@@ -584,6 +584,9 @@ struct AttnDecArgs {
   half_t* ctx;      int ldctx;   // out rows b*Lq + i
   const float* bias_lut;         // [H][RK_LUT_N] or nullptr
   int Lq, causal, max_keys;
+  // tree form of the causal self-attention (grid = (1, H, rows)): query row r sits at position tree_pos[r] and sees the
+  // rows tree_keys[r * Lq + j], j = 0 .. tree_pos[r] - several continuations share the rows of their common prefix
+  const int* tree_keys; const int* tree_pos;
 };
 
 __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
@@ -593,17 +596,21 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
   float* sRed = sPart + 256;       // [8]
   float* sP = sRed + 8;            // [max_keys]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int b = blockIdx.z, h = blockIdx.y, i = blockIdx.x;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int* tkeys = p.tree_keys ? p.tree_keys + (size_t)b * p.Lq : nullptr;
+  const int i = tkeys ? p.tree_pos[b] : (int)blockIdx.x;
   int koff, Lk;
-  if (p.key_off) { koff = p.key_off[b]; Lk = p.key_off[b + 1] - koff; }
+  if (tkeys) { koff = 0; Lk = i + 1; }
+  else if (p.key_off) { koff = p.key_off[b]; Lk = p.key_off[b + 1] - koff; }
   else { koff = b * p.Lq; Lk = p.Lq; }
   const int nk = p.causal ? (i + 1 < Lk ? i + 1 : Lk) : Lk;   // keys 0..nk-1 are visible
-  const size_t qrow = (size_t)(b * p.Lq + i);
+  const size_t qrow = tkeys ? (size_t)b : (size_t)(b * p.Lq + i);
+  auto krow = [&](int j) { return tkeys ? (size_t)tkeys[j] : (size_t)(koff + j); };
   if (tid < 64) sQ[tid] = (float)p.q[qrow * p.ldq + h * 64 + tid];
   __syncthreads();
   float mx = -1e30f;
   for (int j = tid; j < nk; j += 256) {
-    const half_t* kr = p.k + (size_t)(koff + j) * p.ldkv + h * 64;
+    const half_t* kr = p.k + krow(j) * p.ldkv + h * 64;
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -635,16 +642,16 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
   __syncthreads();
   sum = (sRed[4] + sRed[5]) + (sRed[6] + sRed[7]);
   // P V: wave w takes keys w, w+4, ...; lane = d
-  const half_t* vb = p.v + (size_t)koff * p.ldkv + h * 64 + lane;
+  const half_t* vb = p.v + h * 64 + lane;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int j = wave;
   for (; j + 12 < nk; j += 16) {
-    a0 += sP[j] * (float)vb[(size_t)j * p.ldkv];
-    a1 += sP[j + 4] * (float)vb[(size_t)(j + 4) * p.ldkv];
-    a2 += sP[j + 8] * (float)vb[(size_t)(j + 8) * p.ldkv];
-    a3 += sP[j + 12] * (float)vb[(size_t)(j + 12) * p.ldkv];
+    a0 += sP[j] * (float)vb[krow(j) * p.ldkv];
+    a1 += sP[j + 4] * (float)vb[krow(j + 4) * p.ldkv];
+    a2 += sP[j + 8] * (float)vb[krow(j + 8) * p.ldkv];
+    a3 += sP[j + 12] * (float)vb[krow(j + 12) * p.ldkv];
   }
-  for (; j < nk; j += 4) a0 += sP[j] * (float)vb[(size_t)j * p.ldkv];
+  for (; j < nk; j += 4) a0 += sP[j] * (float)vb[krow(j) * p.ldkv];
   sPart[wave * 64 + lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (wave == 0) {
@@ -672,6 +679,8 @@ struct XAttnArgs {
   half_t* out;           // [M, H, d]   normalised  sum_t p[h][t] e_t  (fp16)
   int Ld, H, d, nch;
   int row0;              // decoder row of this pass's first query (blockIdx.y is relative to it; qk / part / stat / out are per pass)
+  const int* row_seq;    // optional: decoder ROW -> encoder sequence, when the rows are not Ld per sequence (rk_t5_greedy2's
+                         // candidate continuations of one prompt share their prefix rows); nullptr: row / Ld
 };
 
 // grid = (nch, M, ceil(H/HPW)); 256 threads.  One 64-key chunk of one decoder row for a group of up to HPW heads
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
   __shared__ __attribute__((aligned(16))) half2v sP2[32 * 16];
   __shared__ float sRed[2][4][16];
   const int ck = blockIdx.x, m = blockIdx.y, hg = blockIdx.z;
-  const int b = (p.row0 + m) / p.Ld;
+  const int b = p.row_seq ? p.row_seq[p.row0 + m] : (p.row0 + m) / p.Ld;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;
   const int t0 = ck * 64;
@@ -793,7 +802,7 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
 __global__ __launch_bounds__(256) void xattn_combine_kernel(XAttnArgs p) {
   __shared__ float sW[1024], sS[1024];
   const int h = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
-  const int b = (p.row0 + m) / p.Ld;
+  const int b = p.row_seq ? p.row_seq[p.row0 + m] : (p.row0 + m) / p.Ld;
   const int L = p.seq_off[b + 1] - p.seq_off[b];
   const int nv = min(p.nch, (L + 63) >> 6);            // chunks with at least one key
   const float* stat = p.stat + ((size_t)m * p.nch * p.H + h) * 2;

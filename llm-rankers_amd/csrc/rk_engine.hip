@@ -75,7 +75,7 @@ struct Slot {
   int* d_tokens = nullptr; int* d_seq_off = nullptr;
   int n_seq = 0, T = 0, maxL = 0; bool staged = false; int last_n_out = 0;
   half_t* cross_kv = nullptr;                                  // [n_dec][max_tokens][2I] encoder -> decoder hand-off
-  int *d_dec_ids = nullptr, *d_last_rows = nullptr, *d_out_ids = nullptr, *d_labels = nullptr, *d_argmax = nullptr;
+  int *d_dec_ids = nullptr, *d_last_rows = nullptr, *d_out_ids = nullptr, *d_labels = nullptr, *d_argmax = nullptr, *d_row_seq = nullptr, *d_tree_keys = nullptr, *d_tree_pos = nullptr;
   float* dhidden = nullptr; half_t *dxn = nullptr, *dqkv = nullptr, *dctx = nullptr, *dq = nullptr, *dffh = nullptr, *dlast = nullptr;
   half_t* dxraw[2] = {nullptr, nullptr}; float* dssq[2] = {nullptr, nullptr}; float* drowscale = nullptr;   // folded decoder norms (run_decoder)
   half_t *xqk = nullptr, *xctx = nullptr;                      // direct cross-attention: [32][H*d] each
@@ -103,7 +103,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160;
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
@@ -517,10 +517,15 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
 
 // hf: modeling_t5.py:663-750 (decoder stack) for Ld teacher-forced positions per sequence (ids already on the
 // device in sl.d_dec_ids, row = b*Ld + t).  Leaves the residual stream in sl.dhidden.
-int run_decoder(rk_engine* e, Slot& sl, int Ld) {
+// tree (rk_t5_greedy2): the decoder rows are not Ld per sequence - several continuations of a prompt share the rows of their
+// common prefix.  rows = row count, Ld = longest position count; device arrays: keys[r * Ld + j] = row at position j of
+// row r's sequence, pos[r] = position of row r, seq[r] = its encoder sequence.  Query-side cross-attention only.
+struct DecTree { int rows; const int* keys; const int* pos; const int* seq; };
+int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
   const rk_model_desc& d = e->d;
   hipStream_t st = dec_stream(e, sl);
-  const int B = sl.n_seq, M = B * Ld, I = e->inner, dm = d.d_model, F = d.d_ff;
+  const int B = sl.n_seq, M = tree ? tree->rows : B * Ld, I = e->inner, dm = d.d_model, F = d.d_ff;
+  if (tree && (sl.have_cross_kv || Ld < 2)) return fail(e, RK_ERR_STATE, "the tree form needs the query-side cross-attention and L_d >= 2");
   const bool ws = Ld <= 4;   // few decoder positions: weight-streaming GEMMs (any number of sequences); else tiled
   // Folded RMSNorm on the weight-streaming path (as in the encoder, minus the statistics kernel): the residual GEMMs leave
   // the new rows as fp16 (dxraw) with their sums of squares per 32-column block (dssq), the GEMM behind the norm reads
@@ -553,7 +558,12 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
       AttnDecArgs a{sl.dqkv, 3 * I, sl.dqkv + I, sl.dqkv + 2 * I, 3 * I, nullptr, sl.dctx, I, e->lut_dec, Ld, 1, Ld};
       {
         Bracket br(e, st, PC_DEC_ATTN, 4.0 * M * Ld * I, 0);
-        hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_self, st, a);
+        if (tree) {
+          a.tree_keys = tree->keys; a.tree_pos = tree->pos;
+          hipLaunchKernelGGL(attn_dec_kernel, dim3(1, d.n_heads, M), dim3(256), smem_self, st, a);
+        } else {
+          hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_self, st, a);
+        }
       }
       gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.o, I, sl.dhidden, dm, M, dm, I, 0, 0, 1.f, 1, 0, 0, 0, ws, dfold ? with_prod(GemmFold()) : GemmFold());
       if (dfold) flip();
@@ -573,7 +583,7 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld) {
       for (int r0 = 0; r0 < M; r0 += blk) {
         const int nr = std::min(blk, M - r0);
         gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dq + (size_t)r0 * I, I, w.ckT, 64, sl.xqk, H * dm, nr, dm, 64, 0, 0, 1.f, H, 64, (long)dm * 64, dm);
-        XAttnArgs xa{sl.xqk, sl.enc_out, sl.d_seq_off, sl.xpart, sl.xstat, sl.xctx, Ld, H, dm, nch, r0};
+        XAttnArgs xa{sl.xqk, sl.enc_out, sl.d_seq_off, sl.xpart, sl.xstat, sl.xctx, Ld, H, dm, nch, r0, tree ? tree->seq : nullptr};
         {
           Bracket br(e, st, PC_DEC_ATTN, 4.0 * nr * (double)sl.maxL * H * dm, (double)sl.T * dm * 2.0 * 2);
           if ((long)nch * nr * ((H + 15) / 16) >= 2 * e->n_cu)
@@ -1120,6 +1130,7 @@ int rk_engine_finalize(rk_engine* e) {
     RC(dalloc(e, &sl.cross_kv, (size_t)d.n_dec_layers * Tc * 2 * I));
     RC(dalloc(e, &sl.d_dec_ids, Mc)); RC(dalloc(e, &sl.d_last_rows, Bc)); RC(dalloc(e, &sl.d_out_ids, 8192));
     RC(dalloc(e, &sl.d_labels, (size_t)d.max_dec_len)); RC(dalloc(e, &sl.d_argmax, Bc));
+    RC(dalloc(e, &sl.d_row_seq, Mc)); RC(dalloc(e, &sl.d_tree_keys, Mc * (size_t)d.max_dec_len)); RC(dalloc(e, &sl.d_tree_pos, Mc));
     RC(dalloc(e, &sl.dhidden, Mc * dm)); RC(dalloc(e, &sl.dxn, Mc * dm)); RC(dalloc(e, &sl.dqkv, Mc * 3 * I));
     RC(dalloc(e, &sl.dctx, Mc * I)); RC(dalloc(e, &sl.dq, Mc * I)); RC(dalloc(e, &sl.dffh, Mc * F));
     RC(dalloc(e, &sl.dlast, Bc * dm));
@@ -1230,6 +1241,34 @@ int rk_t5_qlm(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, i
   return RK_OK;
 }
 
+// One greedy step over the staged batch (encoder done): decoder over rows[b] (Ld ids per sequence), final norm of the last
+// position, full-vocabulary head, arg-max -> amax[b].  Synchronous (the caller decides the next ids on the host).
+static int greedy_step(rk_engine* e, Slot& sl, const std::vector<std::vector<int>>& rows, int Ld, std::vector<int>& amax) {
+  const int n_seq = (int)rows.size();
+  hipStream_t sd = dec_stream(e, sl);
+  std::vector<int> flat((size_t)n_seq * Ld), rowmap(n_seq);
+  for (int b = 0; b < n_seq; ++b) { memcpy(&flat[(size_t)b * Ld], rows[b].data(), Ld * sizeof(int)); rowmap[b] = b * Ld + Ld - 1; }
+  HIPCHK(e, hipStreamSynchronize(sd));
+  HIPCHK(e, hipMemcpy(sl.d_dec_ids, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(sl.d_last_rows, rowmap.data(), n_seq * sizeof(int), hipMemcpyHostToDevice));
+  sl.cache_dec.clear(); sl.cache_rows.clear();
+  int rc = run_graphed(e, sd, {1, 0, n_seq, Ld, sl.have_cross_kv ? sl.maxL : (sl.maxL + 63) / 64, (int)sl.have_cross_kv, (int)(e->logits_cap / (size_t)e->d.vocab)}, [&]() -> int {
+    int r = run_decoder(e, sl, Ld);
+    if (r) return r;
+    rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, n_seq, head_scale(e));
+    gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dlast, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, n_seq, e->d.vocab, e->d.d_model,
+         0, 0, 1.f, 1, 0, 0, 0, true);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_seq), dim3(256), 0, sd, e->logits, e->d.vocab, e->d.vocab, sl.d_argmax);
+    return RK_OK;
+  });
+  if (rc) return rc;
+  amax.resize(n_seq);
+  HIPCHK(e, hipMemcpyAsync(amax.data(), sl.d_argmax, n_seq * sizeof(int), hipMemcpyDeviceToHost, sd));
+  HIPCHK(e, hipStreamSynchronize(sd));
+  HIPCHK(e, hipGetLastError());
+  return RK_OK;
+}
+
 int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq, const int32_t* dec_prefix,
                  int dec_len, int max_new, int eos_id, int pad_id, int32_t* out_tokens, int32_t* out_steps) {
   int rc;
@@ -1245,31 +1284,12 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
   // step (cross K/V are reused), which equals HF's KV-cached greedy loop (hf: generation/utils.py:2868-2935).
   std::vector<std::vector<int>> rows(n_seq, std::vector<int>(dec_prefix, dec_prefix + dec_len));
   std::vector<char> done(n_seq, 0);
-  std::vector<int> flat, rowmap(n_seq), amax(n_seq);
+  std::vector<int> amax(n_seq);
   for (int b = 0; b < n_seq; ++b)
     for (int t = 0; t < max_new; ++t) out_tokens[b * max_new + t] = pad_id;
   int steps = 0;
   for (int t = 0; t < max_new; ++t) {
-    const int Ld = dec_len + t;
-    flat.resize((size_t)n_seq * Ld);
-    for (int b = 0; b < n_seq; ++b) { memcpy(&flat[(size_t)b * Ld], rows[b].data(), Ld * sizeof(int)); rowmap[b] = b * Ld + Ld - 1; }
-    HIPCHK(e, hipStreamSynchronize(sd));
-    HIPCHK(e, hipMemcpy(sl.d_dec_ids, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(e, hipMemcpy(sl.d_last_rows, rowmap.data(), n_seq * sizeof(int), hipMemcpyHostToDevice));
-    sl.cache_dec.clear(); sl.cache_rows.clear();
-    rc = run_graphed(e, sd, {1, 0, n_seq, Ld, sl.have_cross_kv ? sl.maxL : (sl.maxL + 63) / 64, (int)sl.have_cross_kv, (int)(e->logits_cap / (size_t)e->d.vocab)}, [&]() -> int {
-      int r = run_decoder(e, sl, Ld);
-      if (r) return r;
-      rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, n_seq, head_scale(e));
-      gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dlast, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, n_seq, e->d.vocab, e->d.d_model,
-           0, 0, 1.f, 1, 0, 0, 0, true);
-      hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_seq), dim3(256), 0, sd, e->logits, e->d.vocab, e->d.vocab, sl.d_argmax);
-      return RK_OK;
-    });
-    if (rc) return rc;
-    HIPCHK(e, hipMemcpyAsync(amax.data(), sl.d_argmax, n_seq * sizeof(int), hipMemcpyDeviceToHost, sd));
-    HIPCHK(e, hipStreamSynchronize(sd));
-    HIPCHK(e, hipGetLastError());
+    if ((rc = greedy_step(e, sl, rows, dec_len + t, amax))) return rc;
     ++steps;
     bool all_done = true;
     for (int b = 0; b < n_seq; ++b) {
@@ -1285,6 +1305,98 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
   if ((rc = sync_all(e))) return rc;
   sl.dec_pending = false;
   if (out_steps) *out_steps = steps;
+  return RK_OK;
+}
+
+// Two greedy tokens in ONE decoder pass (the setwise `generation` compare: ref llmrankers/setwise.py:113-121 runs
+// generate(max_new_tokens=2) after "<pad> Passage").  The first new token is almost always one of a few label tokens, and a
+// decoder pass over a handful of rows costs what its ~270 launches cost, so the second step is computed for EVERY candidate
+// at once: the prefix rows of a prompt once, plus one row per candidate at position dec_len that attends to the prefix rows
+// and itself (attn_dec_kernel's tree form) and to the prompt (XAttnArgs::row_seq).  The last prefix row gives token 1 over
+// the full vocabulary; the row of the candidate that IS token 1 gives token 2.  Rows are independent of the batch they run in (tests), so both tokens are bit-identical to
+// rk_t5_greedy(max_new = 2); a first token outside the candidates, or a batch too large for the workspace, takes that path.
+int rk_t5_greedy2(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq, const int32_t* dec_prefix,
+                  int dec_len, const int32_t* cand_ids, int n_cand, int eos_id, int pad_id, int32_t* out_tokens, int32_t* out_steps) {
+  if (!e) return RK_ERR_INVALID;
+  const int Ld = dec_len + 1;
+  const long per_seq = (long)dec_len + n_cand;                         // rows of one prompt: the prefix once, one row per candidate
+  const long M = (long)n_seq * per_seq, R = (long)n_seq * (1 + n_cand);
+  const bool fits = cand_ids && n_cand > 0 && dec_prefix && dec_len > 0 && Ld <= e->d.max_dec_len && R <= e->d.max_seqs &&
+                    M <= (long)e->d.max_seqs * e->d.max_dec_len && M <= XA_MAX_ROWS && M <= e->opt_greedy_spec &&
+                    use_xattn_direct(e, e->slots[0], Ld);
+  if (!fits) return rk_t5_greedy(e, tokens, seq_offsets, n_seq, dec_prefix, dec_len, 2, eos_id, pad_id, out_tokens, out_steps);
+  int rc;
+  if ((rc = check_ids(e, cand_ids, n_cand, "candidate"))) return rc;
+  if ((rc = rk_t5_stage(e, tokens, seq_offsets, n_seq))) return rc;
+  Slot& sl = e->slots[0];
+  if ((rc = check_ids(e, dec_prefix, dec_len, "decoder"))) return rc;
+  if ((rc = ensure_logits(e, (size_t)R))) return rc;
+  if ((rc = encoder_then_handoff(e, sl, Ld))) return rc;
+  hipStream_t sd = dec_stream(e, sl);
+  // row layout of prompt b: [prefix position 0 .. dec_len-1][candidate 0 .. n_cand-1 at position dec_len]
+  std::vector<int> ids((size_t)M), rows((size_t)R), rseq((size_t)M), rpos((size_t)M), keys((size_t)M * Ld, 0), amax((size_t)R);
+  for (int b = 0; b < n_seq; ++b) {
+    const int r0 = (int)(b * per_seq);
+    for (int i = 0; i < dec_len; ++i) {
+      const int r = r0 + i;
+      ids[r] = dec_prefix[i]; rseq[r] = b; rpos[r] = i;
+      for (int j = 0; j <= i; ++j) keys[(size_t)r * Ld + j] = r0 + j;
+    }
+    rows[b] = r0 + dec_len - 1;                                       // token 1: the last prefix row
+    for (int c = 0; c < n_cand; ++c) {
+      const int r = r0 + dec_len + c;
+      ids[r] = cand_ids[c]; rseq[r] = b; rpos[r] = dec_len;
+      for (int j = 0; j < dec_len; ++j) keys[(size_t)r * Ld + j] = r0 + j;
+      keys[(size_t)r * Ld + dec_len] = r;
+      rows[n_seq + b * n_cand + c] = r;                                // token 2 if token 1 was candidate c
+    }
+  }
+  HIPCHK(e, hipStreamSynchronize(sd));
+  HIPCHK(e, hipMemcpy(sl.d_dec_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(sl.d_last_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(sl.d_row_seq, rseq.data(), rseq.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(sl.d_tree_pos, rpos.data(), rpos.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(e, hipMemcpy(sl.d_tree_keys, keys.data(), keys.size() * sizeof(int), hipMemcpyHostToDevice));
+  sl.cache_dec.clear(); sl.cache_rows.clear();
+  const DecTree tree{(int)M, sl.d_tree_keys, sl.d_tree_pos, sl.d_row_seq};
+  rc = run_graphed(e, sd, {2, 0, n_seq, Ld, (sl.maxL + 63) / 64, n_cand, (int)(e->logits_cap / (size_t)e->d.vocab)}, [&]() -> int {
+    int r = run_decoder(e, sl, Ld, &tree);
+    if (r) return r;
+    rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, (int)R, head_scale(e));
+    gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dlast, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, (int)R, e->d.vocab, e->d.d_model,
+         0, 0, 1.f, 1, 0, 0, 0, true);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, sd, e->logits, e->d.vocab, e->d.vocab, sl.d_argmax);
+    return RK_OK;
+  });
+  if (rc) return rc;
+  HIPCHK(e, hipMemcpyAsync(amax.data(), sl.d_argmax, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, sd));
+  HIPCHK(e, hipStreamSynchronize(sd));
+  HIPCHK(e, hipGetLastError());
+  bool all_done = true, miss = false;
+  for (int b = 0; b < n_seq; ++b) {
+    const int t1 = amax[b];
+    out_tokens[b * 2] = t1;
+    out_tokens[b * 2 + 1] = pad_id;                                    // finished rows emit pad (hf: generation/utils.py:2927-2929)
+    if (t1 == eos_id) continue;
+    all_done = false;
+    int c = 0;
+    while (c < n_cand && cand_ids[c] != t1) ++c;
+    if (c == n_cand) miss = true;
+    else out_tokens[b * 2 + 1] = amax[n_seq + b * n_cand + c];
+  }
+  if (miss) {
+    // a first token outside the candidates: the ordinary second step (same encoder output, one more decoder pass)
+    std::vector<std::vector<int>> seq_rows(n_seq, std::vector<int>(dec_prefix, dec_prefix + dec_len));
+    for (int b = 0; b < n_seq; ++b) seq_rows[b].push_back(out_tokens[b * 2]);
+    std::vector<int> a2;
+    if ((rc = greedy_step(e, sl, seq_rows, Ld, a2))) return rc;
+    for (int b = 0; b < n_seq; ++b)
+      if (out_tokens[b * 2] != eos_id) out_tokens[b * 2 + 1] = a2[b];
+  }
+  if ((rc = mark_decoder_done(e, sl))) return rc;
+  if ((rc = sync_all(e))) return rc;
+  sl.dec_pending = false;
+  if (out_steps) *out_steps = all_done ? 1 : 2;
   return RK_OK;
 }
 
@@ -1626,6 +1738,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_persistent")) { e->opt_gemm_persistent = value; return RK_OK; }   // ping-pong GEMM: 1 = one workgroup per CU walks the tiles
   if (!strcmp(key, "attn_tiled_occ")) { e->opt_attn_tiled_occ = value; return RK_OK; }   // tiled encoder attention: register budget for 1 / 2 / 3 waves per SIMD
   if (!strcmp(key, "gemm_s64_stages")) { e->opt_s64_stages = value; return RK_OK; }   // LDS stages of the 64x64 GEMM: 0 = auto, 2..4
+  if (!strcmp(key, "greedy_spec")) { e->opt_greedy_spec = value; return RK_OK; }            // rk_t5_greedy2: most decoder rows (prompts x (prefix + candidates)) of a speculative pass; 0 = never speculate
   if (!strcmp(key, "dec_fold_norm")) { e->opt_dec_fold_norm = value != 0; return RK_OK; }   // decoder RMSNorms folded into the weight-streaming GEMMs (1) or separate kernels (0)
   if (!strcmp(key, "fold_norm")) { e->opt_fold_norm = value != 0; return RK_OK; }           // encoder RMSNorm folded into the GEMMs (1) or separate kernels (0)
 #ifdef RK_MEASURE

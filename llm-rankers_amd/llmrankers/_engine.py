@@ -48,6 +48,7 @@ ABI = {
     "rk_t5_score": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _f32p]),
     "rk_t5_qlm": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, _i32p, C.c_int, _f32p]),
     "rk_t5_greedy": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
+    "rk_t5_greedy2": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
     "rk_t5_stage": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int]),
     "rk_t5_score_staged": (C.c_int, [C.c_void_p, _i32p, C.c_int, _i32p, C.c_int]),
     "rk_engine_sync": (C.c_int, [C.c_void_p]),
@@ -201,11 +202,19 @@ class RkEngine:
         return out
 
     def greedy(self, seqs: Sequence[Sequence[int]], dec_prefix: Sequence[int], max_new: int, eos_id: int = 1,
-               pad_id: int = 0) -> Tuple[np.ndarray, int]:
+               pad_id: int = 0, candidates: Optional[Sequence[int]] = None) -> Tuple[np.ndarray, int]:
+        """`candidates` (max_new == 2 only): token ids the first new token is expected to be among - same result, one
+        decoder pass instead of two (rk_t5_greedy2)."""
         tok, off = pack_ragged(seqs)
         dp = _i32(dec_prefix)
         out = np.empty((len(seqs), max_new), dtype=np.int32)
         steps = C.c_int32(0)
+        if candidates is not None and len(candidates) and max_new == 2:
+            cd = _i32(candidates)
+            self._chk(self.lib.rk_t5_greedy2(self.h, tok.ctypes.data_as(_i32p), off.ctypes.data_as(_i32p), len(seqs),
+                                             dp.ctypes.data_as(_i32p), len(dp), cd.ctypes.data_as(_i32p), len(cd), eos_id, pad_id,
+                                             out.ctypes.data_as(_i32p), C.byref(steps)))
+            return out, int(steps.value)
         self._chk(self.lib.rk_t5_greedy(self.h, tok.ctypes.data_as(_i32p), off.ctypes.data_as(_i32p), len(seqs),
                                         dp.ctypes.data_as(_i32p), len(dp), max_new, eos_id, pad_id,
                                         out.ctypes.data_as(_i32p), C.byref(steps)))

@@ -204,11 +204,14 @@ class T5Runtime:
     def qlm(self, seqs, labels) -> np.ndarray:
         return np.concatenate([self.engine.qlm(c, labels) for c in self._chunks(seqs)], axis=0)
 
-    def greedy(self, seqs, dec_prefix, max_new, eos_id=1, pad_id=0) -> np.ndarray:
-        """[B, max_new] new tokens; columns after the step at which every row had finished hold -1."""
+    supports_greedy_candidates = True
+
+    def greedy(self, seqs, dec_prefix, max_new, eos_id=1, pad_id=0, candidates=None) -> np.ndarray:
+        """[B, max_new] new tokens; columns after the step at which every row had finished hold -1.  `candidates`: see
+        RkEngine.greedy (a hint that never changes the result)."""
         parts = []
         for c in self._chunks(seqs):
-            toks, steps = self.engine.greedy(c, dec_prefix, max_new, eos_id, pad_id)
+            toks, steps = self.engine.greedy(c, dec_prefix, max_new, eos_id, pad_id, candidates)
             toks = toks.copy()
             toks[:, steps:] = -1
             parts.append(toks)

@@ -97,7 +97,12 @@ class SetwiseLlmRanker(LlmRanker):
         """Greedy, max_new_tokens=2, continuing "<pad> Passage".  Returns full output id rows the way
         HF generate does: prefix + new tokens, all rows cut at the step where every row had finished."""
         eos, pad = self.tokenizer.eos_token_id, self.tokenizer.pad_token_id
-        new = self.llm.greedy(token_lists, self.decoder_input_ids, 2, eos, pad)
+        if getattr(self.llm, "supports_greedy_candidates", False):
+            # hint: the first new token is normally a passage label -> both steps in one decoder pass (rk_t5_greedy2)
+            new = self.llm.greedy(token_lists, self.decoder_input_ids, 2, eos, pad,
+                                  candidates=self.target_token_ids[:self.num_child + 1])
+        else:
+            new = self.llm.greedy(token_lists, self.decoder_input_ids, 2, eos, pad)
         out = []
         for row in np.asarray(new):
             out.append(list(self.decoder_input_ids) + [int(t) for t in row if t >= 0])

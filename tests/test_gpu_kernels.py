@@ -398,6 +398,38 @@ def test_decoder_folded_rmsnorm_matches_separate_norm_kernels(toy, ckpt):
         np.testing.assert_array_equal(eng.greedy(seqs[i:i + 1], [0], 3)[0][0], tok[i])
 
 
+@pytest.mark.parametrize("ckpt", ["ckpt_gated_untied", "ckpt_relu_tied"])
+def test_two_token_greedy_with_candidates_equals_two_steps(toy, ckpt):
+    """rk_t5_greedy2: the second step computed speculatively for every candidate first token, in the same decoder pass as
+    the first - tokens and step count identical to rk_t5_greedy(max_new=2), whether the first token is a candidate
+    (speculation hit), is not (fallback), or is EOS; one prompt and a batch; candidates beyond the workspace fall back."""
+    from llmrankers import _synth
+    dims, state, eng = toy[ckpt]
+    seqs = _synth.synth_token_batch(5, 3, 120, dims.vocab, seed=91)
+    for prefix in ([0], [0, 17]):
+        want, wsteps = eng.greedy(seqs, prefix, 2)
+        firsts = sorted(set(int(t) for t in want[:, 0]))
+        cases = [firsts, firsts + [3, 4], [5, 6, 7] if not set(firsts) & {5, 6, 7} else [8, 9], list(range(20, 20 + 200))]
+        for cand in cases:
+            got, gsteps = eng.greedy(seqs, prefix, 2, candidates=cand)
+            np.testing.assert_array_equal(got, want, err_msg=f"prefix {prefix} candidates {cand[:6]}")
+            assert gsteps == wsteps
+        for i in range(len(seqs)):
+            one, _ = eng.greedy(seqs[i:i + 1], prefix, 2, candidates=firsts)
+            np.testing.assert_array_equal(one[0], want[i])
+        # EOS as the first token: pad follows and a single-row call stops after one step
+        eos = int(want[0, 0])
+        w1, s1 = eng.greedy(seqs[:1], prefix, 2, eos_id=eos)
+        g1, t1 = eng.greedy(seqs[:1], prefix, 2, eos_id=eos, candidates=firsts)
+        np.testing.assert_array_equal(g1, w1)
+        assert (s1, t1) == (1, 1) and int(w1[0, 1]) == 0
+    try:
+        eng.set_option("greedy_spec", 0)                                     # switch: never speculate
+        np.testing.assert_array_equal(eng.greedy(seqs, [0], 2, candidates=[3, 4])[0], eng.greedy(seqs, [0], 2)[0])
+    finally:
+        eng.set_option("greedy_spec", 160)
+
+
 def test_comm_single_rank_gather_equals_local_scores(toy):
     """rk_comm_*: RCCL communicator of ONE rank on this GPU; the all_gather of the slot's device score buffer returns
     exactly what rk_t5_read_scores returns (the N > 1 path differs only in the number of ranks)."""

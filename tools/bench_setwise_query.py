@@ -28,8 +28,11 @@ class EngineRuntime:
     def score(self, seqs, dec_prefix, out_ids):
         return self.engine.score(seqs, dec_prefix, out_ids)
 
-    def greedy(self, seqs, dec_prefix, max_new, eos_id=1, pad_id=0):
-        toks, steps = self.engine.greedy(seqs, dec_prefix, max_new, eos_id, pad_id)
+    supports_greedy_candidates = True
+
+    def greedy(self, seqs, dec_prefix, max_new, eos_id=1, pad_id=0, candidates=None):
+        toks, steps = self.engine.greedy(seqs, dec_prefix, max_new, eos_id, pad_id,
+                                         candidates if os.environ.get("RK_GREEDY_SPEC", "1") == "1" else None)
         toks = toks.copy()
         toks[:, steps:] = -1
         return toks
@@ -39,9 +42,23 @@ def main():
     from transformers import T5Tokenizer
     tok = T5Tokenizer.from_pretrained(os.path.join(REPO, "tests", "golden", "tok"))
     dims = _synth.FLAN_T5_LARGE
-    eng = RkEngine(dims, 0, max_tokens=32768, max_seqs=16, max_dec_len=8)
-    eng.load_state(_synth.synth_tensors(dims, seed=929, threads=min(32, os.cpu_count() or 8)))
+    eng = RkEngine(dims, 0, max_tokens=32768, max_seqs=256, max_dec_len=8)
+    # random weights would generate arbitrary tokens ("Unexpected output" on every compare): like the goldens
+    # (tests/golden/setwise_large.json) the lm_head rows of the passage labels a prompt can hold (A .. K at num_child = 10)
+    # and EOS are scaled x6, so that a generation is "<label> </s>" as with a trained checkpoint - the case the product
+    # path is built for
+    state = _synth.synth_state_dict(dims, seed=929, threads=min(32, os.cpu_count() or 8))
+    label_ids = [tok.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1] for c in SetwiseLlmRanker.CHARACTERS[:11]]
+    head = state["lm_head.weight"].copy()
+    ids = np.asarray(sorted(set(label_ids + [tok.eos_token_id])), dtype=np.int64)
+    head[ids] = (head[ids] * np.float32(6.0)).astype(np.float16).astype(np.float32)
+    state["lm_head.weight"] = head
+    eng.load_state(state.items())
+    del state, head
     eng.set_option("dec_graph", int(os.environ.get("RK_DEC_GRAPH", "1")))
+    for kv in os.environ.get("RK_OPTS", "").split(","):
+        if kv:
+            eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     rt = EngineRuntime(eng, dims)
     import bench
     rs = random.Random(3)
@@ -69,6 +86,15 @@ def main():
                 "ms_per_query": round(best * 1e3, 1), "compares": rk.total_compare,
                 "algorithmic_tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / 2500.0, 4),
                 "avg_prompt_tokens": round(rk.total_prompt_tokens / max(rk.total_compare, 1), 1), "top10": res0}
+    if os.environ.get("RK_HOSTPROF"):                       # where the host time of one query goes (stderr)
+        import cProfile, pstats
+        rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring="generation", method="heapsort")
+        ranking = [SearchResult(docid=d, score=s, text=rk.truncate(t, 128)) for d, s, t in docs]
+        pr = cProfile.Profile(); pr.enable()
+        with contextlib.redirect_stdout(io.StringIO()):
+            rk.rerank("which passage mentions the most relevant words", ranking)
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(25)
     for scoring in ("likelihood", "generation"):
         assert out[f"{scoring}_batched"]["top10"] == out[f"{scoring}_one_by_one"]["top10"], "batched build phase changed the ranking"
     print(json.dumps(out))
