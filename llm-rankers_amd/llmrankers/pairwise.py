@@ -50,6 +50,8 @@ class PairwiseLlmRanker(LlmRanker):
         self.llm, self.tokenizer = runtime, tokenizer
         self.config = getattr(runtime, "config", None)
         self.decoder_input_ids = self.tokenizer.encode("<pad> Passage", add_special_tokens=False)
+        # the two labels a generation normally starts with: hint for the one-pass two-token greedy (rk_t5_greedy2)
+        self._label_ids = [self.tokenizer.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1] for c in "AB"]
         self.total_compare = 0
         self.total_completion_tokens = 0
         self.total_prompt_tokens = 0
@@ -61,7 +63,10 @@ class PairwiseLlmRanker(LlmRanker):
         number of new tokens each row needed (EOS included), from which the reference's batch-level output length
         follows: HF stops a batch when all its rows have finished."""
         eos, pad = self.tokenizer.eos_token_id, self.tokenizer.pad_token_id
-        new = np.asarray(self.llm.greedy(token_lists, self.decoder_input_ids, 2, eos, pad))
+        if getattr(self.llm, "supports_greedy_candidates", False):
+            new = np.asarray(self.llm.greedy(token_lists, self.decoder_input_ids, 2, eos, pad, candidates=self._label_ids))
+        else:
+            new = np.asarray(self.llm.greedy(token_lists, self.decoder_input_ids, 2, eos, pad))
         texts, lens = [], []
         for row in new:
             toks = [int(t) for t in row if t >= 0]
