@@ -76,18 +76,27 @@ __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16
 
 // MINW: minimum waves per SIMD the register allocation must allow (1: up to 512 registers, one workgroup per CU;
 // 2: 256 registers, two workgroups per CU overlap each other's load / softmax / MFMA phases)
-template <int MINW>
-__global__ __launch_bounds__(256, MINW) void attn_enc_kernel(AttnEncArgs p) {
-  __shared__ __attribute__((aligned(16))) half_t sK[2][64 * ATT_KSTR];
-  __shared__ __attribute__((aligned(16))) half_t sVt[2][64 * ATT_VSTR];
+// KS = 2 (launched when the batch holds a sequence longer than ATT_SPLIT_MIN_L): 8 waves; waves 4-7 take the same 128 queries
+// over the SECOND half of the key tiles of such a sequence, with their own LDS stages, and the two running softmax states
+// are merged through LDS at the end - a single long prompt (one setwise compare) is 12 x 16 workgroups walking 23 key tiles
+// each, and only the length of that walk matters.  Whether a sequence is split depends on ITS length alone, so its result
+// does not depend on the batch it is scored in; sequences up to ATT_SPLIT_MIN_L are computed exactly as by KS = 1.
+#define ATT_SPLIT_MIN_L 512
+#define ATT_GROUP_BYTES (2 * 64 * ATT_KSTR * 2 + 2 * 64 * ATT_VSTR * 2)
+template <int MINW, int KS = 1>
+__global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char sGroup[KS][ATT_GROUP_BYTES];
   __shared__ float sLut[RK_LUT_N + 3];
   const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;
   if (qt * 128 >= L) return;   // uniform for the whole block
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;
+  const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;      // within the group
+  half_t (*sK)[64 * ATT_KSTR] = (half_t (*)[64 * ATT_KSTR])sGroup[grp];
+  half_t (*sVt)[64 * ATT_VSTR] = (half_t (*)[64 * ATT_VSTR])(sGroup[grp] + 2 * 64 * ATT_KSTR * 2);
   const int hh = lane >> 5, l31 = lane & 31;
-  for (int i = tid; i < RK_LUT_N; i += 256) sLut[i] = p.bias_lut[h * RK_LUT_N + i] * ATT_LOG2E;
+  for (int i = threadIdx.x; i < RK_LUT_N; i += 256 * KS) sLut[i] = p.bias_lut[h * RK_LUT_N + i] * ATT_LOG2E;
   const int q0 = qt * 128 + wave * 32;
   const bool wave_active = q0 < L;
   const int qpos = q0 + l31;
@@ -103,6 +112,9 @@ __global__ __launch_bounds__(256, MINW) void attn_enc_kernel(AttnEncArgs p) {
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
   const int nkt = (L + 63) >> 6;
+  const bool split = KS == 2 && L > ATT_SPLIT_MIN_L;
+  const int n_iter = split ? (nkt + 1) >> 1 : nkt;                 // group 0's tile count (>= group 1's)
+  const int kt_begin = grp ? n_iter : 0, kt_end = grp ? (split ? nkt : n_iter) : n_iter;   // group 1 of an unsplit sequence: empty
   // staging roles: K: thread takes rows (tid>>3) and 32+(tid>>3), chunk tid&7; V: key pair tid>>3, chunk tid&7
   const int srow = tid >> 3, scc = tid & 7;
   half8 rk0, rk1, rv0, rv1;
@@ -124,13 +136,16 @@ __global__ __launch_bounds__(256, MINW) void attn_enc_kernel(AttnEncArgs p) {
       *(half2v*)(sVt[buf] + (scc * 8 + j) * ATT_VSTR + 2 * srow) = pr;
     }
   };
-  load_tile(0);
-  store_tile(0);
+  if (kt_begin < kt_end) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);          // in flight while this tile is computed
-    if (wave_active) {
+  for (int it = 0; it < n_iter; ++it) {
+    const int kt = kt_begin + it;
+    const int cur = it & 1;
+    if (kt + 1 < kt_end) load_tile(kt + 1);       // in flight while this tile is computed
+    if (wave_active && kt < kt_end) {
       const half_t* kbuf = sK[cur];
       const half_t* vbuf = sVt[cur];
       f32x16 s0, s1;
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(256, MINW) void attn_enc_kernel(AttnEncArgs p) {
         if (far_l || far_r) {
           const float cb = far_l ? sLut[0] : sLut[RK_LUT_N - 1];
           auto bias = [&](int, int) { return cb; };
-          if (kt == 0) {
+          if (kt == kt_begin) {
             if (last) attn_tile_softmax<true, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
             else attn_tile_softmax<false, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
           } else {
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(256, MINW) void attn_enc_kernel(AttnEncArgs p) {
             rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
             return sLut[rel + RK_LUT_R];
           };
-          if (kt == 0) {
+          if (kt == kt_begin) {
             if (last) attn_tile_softmax<true, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
             else attn_tile_softmax<false, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
           } else {
@@ -198,8 +213,31 @@ __global__ __launch_bounds__(256, MINW) void attn_enc_kernel(AttnEncArgs p) {
         }
       }
     }
-    if (kt + 1 < nkt) store_tile(cur ^ 1);        // buffer cur^1 was last read before the previous barrier
+    if (kt + 1 < kt_end) store_tile(cur ^ 1);     // buffer cur^1 was last read before the previous barrier
     __syncthreads();
+  }
+  if (KS == 2) {
+    // merge the two halves of a split sequence: group 1 hands (m, l, O) of its keys to the wave of group 0 that holds
+    // the same queries - through its own, now idle, LDS stages ([value][lane]: conflict-free)
+    float* sx = (float*)sGroup[1];
+    if (split && grp == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sx[r * 256 + tid] = o0[r]; sx[(16 + r) * 256 + tid] = o1[r]; }
+      sx[32 * 256 + tid] = m_run; sx[33 * 256 + tid] = l_run;
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    if (split && wave_active) {
+      const float m1 = sx[32 * 256 + tid], l1 = sx[33 * 256 + tid];
+      const float m = fmaxf(m_run, m1);
+      const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+      l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o0[r] = o0[r] * a0 + sx[r * 256 + tid] * a1;
+        o1[r] = o1[r] * a0 + sx[(16 + r) * 256 + tid] * a1;
+      }
+    }
   }
   // all waves are past the last barrier: reuse sK[0] to turn per-lane 8-byte pieces into whole context rows
   if (wave_active) {

@@ -103,7 +103,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1;
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
@@ -480,6 +480,8 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
       }
       else if (e->opt_attn_tiled_occ >= 3)
         hipLaunchKernelGGL(attn_enc_kernel<3>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
+      else if (e->opt_attn_tiled_occ == 2 && e->opt_attn_split && sl.maxL > ATT_SPLIT_MIN_L)   // long prompts: two key halves per workgroup
+        hipLaunchKernelGGL((attn_enc_kernel<2, 2>), dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(512), 0, st, a);
       else if (e->opt_attn_tiled_occ == 2)
         hipLaunchKernelGGL(attn_enc_kernel<2>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
       else
@@ -1738,6 +1740,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_persistent")) { e->opt_gemm_persistent = value; return RK_OK; }   // ping-pong GEMM: 1 = one workgroup per CU walks the tiles
   if (!strcmp(key, "attn_tiled_occ")) { e->opt_attn_tiled_occ = value; return RK_OK; }   // tiled encoder attention: register budget for 1 / 2 / 3 waves per SIMD
   if (!strcmp(key, "gemm_s64_stages")) { e->opt_s64_stages = value; return RK_OK; }   // LDS stages of the 64x64 GEMM: 0 = auto, 2..4
+  if (!strcmp(key, "attn_split")) { e->opt_attn_split = value != 0; return RK_OK; }           // sequences longer than 512 tokens: key tiles split over two wave groups (1) or one walk (0)
   if (!strcmp(key, "greedy_spec")) { e->opt_greedy_spec = value; return RK_OK; }            // rk_t5_greedy2: most decoder rows (prompts x (prefix + candidates)) of a speculative pass; 0 = never speculate
   if (!strcmp(key, "dec_fold_norm")) { e->opt_dec_fold_norm = value != 0; return RK_OK; }   // decoder RMSNorms folded into the weight-streaming GEMMs (1) or separate kernels (0)
   if (!strcmp(key, "fold_norm")) { e->opt_fold_norm = value != 0; return RK_OK; }           // encoder RMSNorm folded into the GEMMs (1) or separate kernels (0)

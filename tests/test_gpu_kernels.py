@@ -430,6 +430,33 @@ def test_two_token_greedy_with_candidates_equals_two_steps(toy, ckpt):
         eng.set_option("greedy_spec", 160)
 
 
+def test_key_split_attention_for_long_sequences(toy):
+    """Sequences longer than 512 tokens walk their key tiles in two halves (two wave groups, merged at the end): close to
+    the single walk and the oracle, and a function of the sequence's own length only - the same bits alone, in a batch
+    with shorter sequences and next to another long one; sequences up to 512 tokens keep the bits of the single walk."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle
+    dims, state, eng = toy["ckpt_gated_untied"]
+    rs = np.random.RandomState(11)
+    lens = [1450, 40, 513, 512, 200, 777, 64]
+    seqs = [list(rs.randint(3, dims.vocab, size=n)) for n in lens]
+    ids = [11, 12, 13, 14]
+    split = eng.score(seqs, [0], ids)
+    try:
+        eng.set_option("attn_split", 0)
+        single = eng.score(seqs, [0], ids)
+    finally:
+        eng.set_option("attn_split", 1)
+    assert np.abs(split - single).max() < 2e-3, np.abs(split - single).max()
+    short = [i for i, n in enumerate(lens) if n <= 512]
+    np.testing.assert_array_equal(split[short], single[short])
+    want = T5Oracle(dims, state).score_last([seqs[2], seqs[5]], [0], ids)
+    assert np.abs(split[[2, 5]] - want).max() < LOGIT_TOL
+    for i in (0, 2, 3, 5):                                                   # alone == in the batch
+        np.testing.assert_array_equal(eng.score(seqs[i:i + 1], [0], ids)[0], split[i])
+    np.testing.assert_array_equal(eng.score([seqs[5], seqs[1], seqs[0]], [0], ids), split[[5, 1, 0]])
+
+
 def test_comm_single_rank_gather_equals_local_scores(toy):
     """rk_comm_*: RCCL communicator of ONE rank on this GPU; the all_gather of the slot's device score buffer returns
     exactly what rk_t5_read_scores returns (the N > 1 path differs only in the number of ranks)."""
