@@ -19,7 +19,8 @@
 #include "common.h"
 #include <type_traits>
 
-enum GemmEpi { EPI_STORE_F16 = 0, EPI_RESID_F32 = 1, EPI_GEGLU_F16 = 2, EPI_RELU_F16 = 3, EPI_STORE_F32 = 4, EPI_SWIGLU_F16 = 5 };
+enum GemmEpi { EPI_STORE_F16 = 0, EPI_RESID_F32 = 1, EPI_GEGLU_F16 = 2, EPI_RELU_F16 = 3, EPI_STORE_F32 = 4, EPI_SWIGLU_F16 = 5,
+               EPI_ARGMAX_F32 = 6 };   // weight-streaming kernel only: per 32-column block the row maximum and its first index
 // gated epilogues: gate / up rows interleaved in groups of 32 by the weight packer, out = act(gate) * up
 #define EPI_IS_GATED(E) ((E) == EPI_GEGLU_F16 || (E) == EPI_SWIGLU_F16)
 
@@ -43,6 +44,8 @@ struct GemmArgs {
   // the nb_in block sums of ssq_in [M, nb_in] (written by the producer GEMM before it, 32-column blocks) itself:
   // row factor = rsqrt(sum / K + eps_in) / xs
   const float* ssq_in; int nb_in; float eps_in;
+  // EPI_ARGMAX_F32 (greedy head): C = float [M, ldc] block maxima, amax_idx = int [M, ldc] their first column (ldc = blocks)
+  int* amax_idx;
 };
 
 #define GEMM_BM 128
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p)
   const int m = mrow0 + l31 < p.M ? mrow0 + l31 : p.M - 1;
   p.A += (size_t)blockIdx.y * p.bsA;          // batched form: one small GEMM per blockIdx.y (e.g. per attention head)
   p.W += (size_t)blockIdx.y * p.bsW;
-  p.C = (char*)p.C + (size_t)blockIdx.y * p.bsC * ((EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) ? 4 : 2);
+  p.C = (char*)p.C + (size_t)blockIdx.y * p.bsC * ((EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_ARGMAX_F32) ? 4 : 2);
   const half_t* arow = p.A + (size_t)m * p.lda + 8 * hh;
   const half_t* wrow[NT];
 #pragma unroll
@@ -672,6 +675,27 @@ __global__ __launch_bounds__(SKINNY_THREADS) void gemm_skinny_kernel(GemmArgs p)
     if (p.xraw) {
       ss += __shfl_xor(ss, 32);
       if (hh == 0 && row_ok) p.ssq[(size_t)m * p.nb + (n0 >> 5)] = ss;
+    }
+  } else if constexpr (EPI == EPI_ARGMAX_F32) {
+    // the logits of this block never reach memory: largest value and its FIRST column (torch.argmax tie rule) among the
+    // workgroup's 32 columns; argmax_blocks_kernel finishes the row
+    const float sc = p.scale * rowfac;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 8 * q + 4 * hh + j;
+        const float v = acc[0][0][4 * q + j] * sc;
+        if (n < p.N && (v > best || (v == best && n < bi))) { best = v; bi = n; }
+      }
+    const float ov = __shfl_xor(best, 32);
+    const int oi = __shfl_xor(bi, 32);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    if (hh == 0 && row_ok) {
+      ((float*)p.C)[(size_t)m * p.ldc + blockIdx.x] = best;
+      p.amax_idx[(size_t)m * p.ldc + blockIdx.x] = bi;
     }
   } else {
     gemm_epilogue<EPI, NT, 1>(p, acc, mrow0, n0, l31, hh, rowfac);

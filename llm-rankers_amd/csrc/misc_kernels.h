@@ -113,18 +113,20 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const half_t* __restrict
   if (lane == 0) out[idx] = s;
 }
 
-// Greedy decoding step: first index of the row maximum (torch.argmax tie rule; hf: generation/utils.py greedy).
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, int ld, int n_cols,
-                                                          int* __restrict__ out) {
+// Greedy decoding step, second half of the fused head: the weight-streaming head GEMM (EPI_ARGMAX_F32) left, per 32-column
+// block, the row maximum and its first column; one workgroup per row picks the first index of the overall maximum
+// (torch.argmax tie rule; hf: generation/utils.py greedy).
+__global__ __launch_bounds__(256) void argmax_blocks_kernel(const float* __restrict__ bval, const int* __restrict__ bidx,
+                                                            int n_blocks, int* __restrict__ out) {
   __shared__ float sv[4];
   __shared__ int si[4];
   const int row = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const float* src = logits + (size_t)row * ld;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int c = tid; c < n_cols; c += 256) {
-    const float v = src[c];
-    if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+  for (int c = tid; c < n_blocks; c += 256) {
+    const float v = bval[(size_t)row * n_blocks + c];
+    const int i = bidx[(size_t)row * n_blocks + c];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

@@ -99,7 +99,8 @@ struct rk_engine {
   std::vector<EncLayerW> enc;
   std::vector<DecLayerW> dec;
   float *enc_final_ln = nullptr, *dec_final_ln = nullptr, *lut_enc = nullptr, *lut_dec = nullptr;
-  float* logits = nullptr; size_t logits_cap = 0;              // full-vocabulary paths (qlm, greedy); slot 0 only
+  float* logits = nullptr; size_t logits_cap = 0;              // full-vocabulary logits (qlm); slot 0 only
+  float* amax_val = nullptr; int* amax_idx = nullptr; size_t amax_rows = 0;   // greedy head: per-row block maxima / first columns
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
@@ -318,7 +319,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
   Bracket br(e, st, cls, flops, bytes);
   // Kernel family is chosen by the CALLER's regime, never by M: a row's result must not depend on how many other rows
   // share the launch (the split-K weight-streaming kernel and the tiled kernels sum K in different orders).
-  if ((weight_streaming || batch > 1) && n_split == 0 && (((e->opt_skinny >> epi) & 1) || batch > 1)) {
+  if ((weight_streaming || batch > 1) && n_split == 0 && (((e->opt_skinny >> epi) & 1) || batch > 1 || epi == EPI_ARGMAX_F32)) {
     // (a form where one workgroup takes up to 8 row slabs - 8x fewer, fatter workgroups - was bit-identical but made
     // the step 6 % slower: what the decoder costs the concurrent encoder GEMMs is the serial LENGTH of its chain, every
     // kernel delaying some tile of the GEMM in flight, not its CU-time; so: many short workgroups)
@@ -331,6 +332,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
       case EPI_GEGLU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_GEGLU_F16, 2>), dim3((N + 63) / 64, gy, gz), b, 0, st, a); break;
       case EPI_SWIGLU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_SWIGLU_F16, 2>), dim3((N + 63) / 64, gy, gz), b, 0, st, a); break;
       case EPI_RELU_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RELU_F16, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
+      case EPI_ARGMAX_F32: a.amax_idx = e->amax_idx; hipLaunchKernelGGL((gemm_skinny_kernel<EPI_ARGMAX_F32, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
       default: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F32, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
     }
     return;
@@ -908,6 +910,8 @@ void rk_engine_destroy(rk_engine* e) {
   e->graphs.clear();
   for (void* p : e->allocs) hipFree(p);
   if (e->logits) hipFree(e->logits);
+  if (e->amax_val) hipFree(e->amax_val);
+  if (e->amax_idx) hipFree(e->amax_idx);
   for (auto& sl : e->slots) {
     if (sl.h_scores) hipHostFree(sl.h_scores);
     if (sl.h_small) hipHostFree(sl.h_small);
@@ -1243,6 +1247,28 @@ int rk_t5_qlm(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, i
   return RK_OK;
 }
 
+// Greedy head: full-vocabulary logits of `rows` final-normed rows (x: [rows, d_model] fp16) reduced to their first arg-max
+// WITHOUT writing the logits: the weight-streaming GEMM keeps per 32-column block the maximum and its first column
+// (gemm.h: EPI_ARGMAX_F32), argmax_blocks_kernel picks per row.  hf: modeling_t5.py:1044-1047 + torch.argmax.
+static int ensure_amax(rk_engine* e, size_t rows, int vocab) {
+  if (rows <= e->amax_rows) return RK_OK;
+  int rc = sync_all(e);
+  if (rc) return rc;
+  if (e->amax_val) HIPCHK(e, hipFree(e->amax_val));
+  if (e->amax_idx) HIPCHK(e, hipFree(e->amax_idx));
+  e->amax_val = nullptr; e->amax_idx = nullptr; e->amax_rows = 0;
+  const size_t nblk = (size_t)(vocab + 31) / 32;
+  HIPCHK(e, hipMalloc((void**)&e->amax_val, rows * nblk * sizeof(float)));
+  HIPCHK(e, hipMalloc((void**)&e->amax_idx, rows * nblk * sizeof(int)));
+  e->amax_rows = rows;
+  return RK_OK;
+}
+static void head_argmax(rk_engine* e, hipStream_t st, const half_t* x, int rows, int d_model, int vocab, int* d_out) {
+  const int nblk = (vocab + 31) / 32;
+  gemm(e, st, PC_HEAD, EPI_ARGMAX_F32, x, d_model, e->lm_head, d_model, e->amax_val, nblk, rows, vocab, d_model, 0, 0, 1.f, 1, 0, 0, 0, true);
+  hipLaunchKernelGGL(argmax_blocks_kernel, dim3(rows), dim3(256), 0, st, e->amax_val, e->amax_idx, nblk, d_out);
+}
+
 // One greedy step over the staged batch (encoder done): decoder over rows[b] (Ld ids per sequence), final norm of the last
 // position, full-vocabulary head, arg-max -> amax[b].  Synchronous (the caller decides the next ids on the host).
 static int greedy_step(rk_engine* e, Slot& sl, const std::vector<std::vector<int>>& rows, int Ld, std::vector<int>& amax) {
@@ -1254,13 +1280,11 @@ static int greedy_step(rk_engine* e, Slot& sl, const std::vector<std::vector<int
   HIPCHK(e, hipMemcpy(sl.d_dec_ids, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(e, hipMemcpy(sl.d_last_rows, rowmap.data(), n_seq * sizeof(int), hipMemcpyHostToDevice));
   sl.cache_dec.clear(); sl.cache_rows.clear();
-  int rc = run_graphed(e, sd, {1, 0, n_seq, Ld, sl.have_cross_kv ? sl.maxL : (sl.maxL + 63) / 64, (int)sl.have_cross_kv, (int)(e->logits_cap / (size_t)e->d.vocab)}, [&]() -> int {
+  int rc = run_graphed(e, sd, {1, 0, n_seq, Ld, sl.have_cross_kv ? sl.maxL : (sl.maxL + 63) / 64, (int)sl.have_cross_kv, (int)e->amax_rows}, [&]() -> int {
     int r = run_decoder(e, sl, Ld);
     if (r) return r;
     rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, n_seq, head_scale(e));
-    gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dlast, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, n_seq, e->d.vocab, e->d.d_model,
-         0, 0, 1.f, 1, 0, 0, 0, true);
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_seq), dim3(256), 0, sd, e->logits, e->d.vocab, e->d.vocab, sl.d_argmax);
+    head_argmax(e, sd, sl.dlast, n_seq, e->d.d_model, e->d.vocab, sl.d_argmax);
     return RK_OK;
   });
   if (rc) return rc;
@@ -1279,7 +1303,7 @@ int rk_t5_greedy(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets
   if (!dec_prefix || dec_len <= 0 || max_new <= 0 || dec_len + max_new - 1 > e->d.max_dec_len)
     return fail(e, RK_ERR_CAPACITY, "dec_len %d + max_new %d exceeds max_dec_len %d", dec_len, max_new, e->d.max_dec_len);
   if ((rc = check_ids(e, dec_prefix, dec_len, "decoder"))) return rc;
-  if ((rc = ensure_logits(e, n_seq))) return rc;
+  if ((rc = ensure_amax(e, (size_t)n_seq, e->d.vocab))) return rc;
   if ((rc = encoder_then_handoff(e, sl, dec_len + max_new - 1))) return rc;
   hipStream_t sd = dec_stream(e, sl);
   // Per-row decoder ids grow by one token per step; the tiny decoder is recomputed over the whole prefix each
@@ -1332,7 +1356,7 @@ int rk_t5_greedy2(rk_engine* e, const int32_t* tokens, const int32_t* seq_offset
   if ((rc = rk_t5_stage(e, tokens, seq_offsets, n_seq))) return rc;
   Slot& sl = e->slots[0];
   if ((rc = check_ids(e, dec_prefix, dec_len, "decoder"))) return rc;
-  if ((rc = ensure_logits(e, (size_t)R))) return rc;
+  if ((rc = ensure_amax(e, (size_t)R, e->d.vocab))) return rc;
   if ((rc = encoder_then_handoff(e, sl, Ld))) return rc;
   hipStream_t sd = dec_stream(e, sl);
   // row layout of prompt b: [prefix position 0 .. dec_len-1][candidate 0 .. n_cand-1 at position dec_len]
@@ -1361,13 +1385,11 @@ int rk_t5_greedy2(rk_engine* e, const int32_t* tokens, const int32_t* seq_offset
   HIPCHK(e, hipMemcpy(sl.d_tree_keys, keys.data(), keys.size() * sizeof(int), hipMemcpyHostToDevice));
   sl.cache_dec.clear(); sl.cache_rows.clear();
   const DecTree tree{(int)M, sl.d_tree_keys, sl.d_tree_pos, sl.d_row_seq};
-  rc = run_graphed(e, sd, {2, 0, n_seq, Ld, (sl.maxL + 63) / 64, n_cand, (int)(e->logits_cap / (size_t)e->d.vocab)}, [&]() -> int {
+  rc = run_graphed(e, sd, {2, 0, n_seq, Ld, (sl.maxL + 63) / 64, n_cand, (int)e->amax_rows}, [&]() -> int {
     int r = run_decoder(e, sl, Ld, &tree);
     if (r) return r;
     rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dlast, sl.d_last_rows, (int)R, head_scale(e));
-    gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dlast, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, (int)R, e->d.vocab, e->d.d_model,
-         0, 0, 1.f, 1, 0, 0, 0, true);
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, sd, e->logits, e->d.vocab, e->d.vocab, sl.d_argmax);
+    head_argmax(e, sd, sl.dlast, (int)R, e->d.d_model, e->d.vocab, sl.d_argmax);
     return RK_OK;
   });
   if (rc) return rc;
@@ -1579,13 +1601,11 @@ int rk_llama_greedy1(rk_engine* e, const int32_t* tokens, const int32_t* seq_off
   if (!e || !out_tokens) return RK_ERR_INVALID;
   int rc = llama_prefill(e, tokens, seq_offsets, n_seq);
   if (rc) return rc;
-  if ((rc = ensure_logits(e, n_seq))) return rc;
+  if ((rc = ensure_amax(e, (size_t)n_seq, e->ld.vocab))) return rc;
   Slot& sl = e->slots[0];
   hipStream_t st = sl.se;
   // full-vocabulary head on the n_seq last rows: weight-streaming GEMM, then the first arg-max (torch.argmax tie rule)
-  gemm(e, st, PC_HEAD, EPI_STORE_F32, sl.dlast, e->ld.hidden, e->lm_head, e->ld.hidden, e->logits, e->ld.vocab, n_seq, e->ld.vocab, e->ld.hidden,
-       0, 0, 1.f, 1, 0, 0, 0, true);
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_seq), dim3(256), 0, st, e->logits, e->ld.vocab, e->ld.vocab, sl.d_argmax);
+  head_argmax(e, st, sl.dlast, n_seq, e->ld.hidden, e->ld.vocab, sl.d_argmax);
   std::vector<int> amax(n_seq);
   HIPCHK(e, hipMemcpyAsync(amax.data(), sl.d_argmax, n_seq * sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(e, hipStreamSynchronize(st));

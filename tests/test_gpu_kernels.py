@@ -457,6 +457,41 @@ def test_key_split_attention_for_long_sequences(toy):
     np.testing.assert_array_equal(eng.score([seqs[5], seqs[1], seqs[0]], [0], ids), split[[5, 1, 0]])
 
 
+def test_fused_greedy_head_first_index_on_exact_ties(ckpt_dirs):
+    """The greedy head never writes the logits: the head GEMM keeps per 32-column block the maximum and its first column,
+    a second kernel picks per row.  Exact ties - identical lm_head rows in one block (both lane halves) and in later
+    blocks - resolve to the FIRST index (torch.argmax).  Two tie groups, +8x and -8x one direction: whatever the sign of
+    a row's projection, one group holds the row maximum, and the token must be that group's smallest index."""
+    from llmrankers import _synth
+    dims, state = load_state(ckpt_dirs["ckpt_gated_untied"])
+    head = state["lm_head.weight"].copy()
+    plus, minus = [37, 45, 59, 70, 131, 200], [38, 46, 60, 71, 132, 201]
+    for r in plus:
+        head[r] = head[40] * np.float32(8.0)
+    for r in minus:
+        head[r] = head[40] * np.float32(-8.0)
+    state = dict(state)
+    state["lm_head.weight"] = head
+    eng = _engine(dims, state)
+    try:
+        seqs = _synth.synth_token_batch(8, 3, 90, dims.vocab, seed=3)
+        tok, _ = eng.greedy(seqs, [0], 1)
+        full = np.concatenate([eng.score(seqs, [0], list(range(c, min(c + 64, dims.vocab)))) for c in range(0, dims.vocab, 64)], axis=1)
+        hits = 0
+        for b in range(len(seqs)):
+            assert len(set(full[b, plus].tolist())) == 1 and len(set(full[b, minus].tolist())) == 1   # the ties are exact
+            want = int(np.argmax(full[b]))                                   # numpy: first index of the maximum
+            others = np.delete(full[b], plus if want in plus else (minus if want in minus else [want]))
+            if full[b, want] - others.max() > 0.05:                          # (the scored logits sum K in another order)
+                assert int(tok[b, 0]) == want, (b, int(tok[b, 0]), want)
+                hits += want in (37, 38)
+        assert hits >= 3, hits                                              # a tie group won, and its FIRST index was returned
+        # two new tokens and the candidate form go through the same head
+        np.testing.assert_array_equal(eng.greedy(seqs, [0], 2, candidates=[37, 38])[0], eng.greedy(seqs, [0], 2)[0])
+    finally:
+        eng.close()
+
+
 def test_comm_single_rank_gather_equals_local_scores(toy):
     """rk_comm_*: RCCL communicator of ONE rank on this GPU; the all_gather of the slot's device score buffer returns
     exactly what rk_t5_read_scores returns (the N > 1 path differs only in the number of ranks)."""
