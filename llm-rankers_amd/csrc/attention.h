@@ -721,6 +721,9 @@ struct XAttnArgs {
                          // candidate continuations of one prompt share their prefix rows); nullptr: row / Ld
 };
 
+// (Tried and dropped: ONE workgroup per row of a short sequence walking its <= 4 chunks with a running softmax - no fp32
+// partial sums through HBM, no combine launch: 76 us per layer at 320 rows against 58 + 14 us for this pair; the row's
+// chunks in sequence are slower than the same chunks side by side, and the pointwise step did not move.)
 // grid = (nch, M, ceil(H/HPW)); 256 threads.  One 64-key chunk of one decoder row for a group of up to HPW heads
 // (16: one workgroup per chunk and row - the 256-passage groups; 4: four times as many, lighter workgroups for the
 // few-row setwise calls, where 48 workgroups of 16 heads left most of the chip idle).  Per-head arithmetic is the same.
