@@ -287,3 +287,35 @@ def test_unknown_sort_method_and_cpu_device(runtimes, ckpt_dirs):
     # no silent CPU fallback in the product path: device='cpu' must fail loudly
     with pytest.raises((RuntimeError, FileNotFoundError)):
         PointwiseLlmRanker(ckpt_dirs["ckpt_gated_untied"], None, "cpu", method="yes_no", batch_size=2)
+
+
+def test_generation_passes_label_candidates_to_runtimes_that_take_them(runtimes):
+    """SetwiseLlmRanker / PairwiseLlmRanker hand the label token ids to a runtime that advertises
+    `supports_greedy_candidates` (the engine then runs both greedy steps in one decoder pass); a runtime that does not
+    is called exactly as before.  The hint never changes what is returned."""
+    from llmrankers.pairwise import PairwiseLlmRanker
+    rt, tok = runtimes["ckpt_labelboost"]
+    seen = []
+
+    class Hinted:
+        supports_greedy_candidates = True
+        config = rt.config
+
+        def greedy(self, seqs, dec_prefix, max_new, eos_id=1, pad_id=0, candidates=None):
+            seen.append(list(candidates) if candidates is not None else None)
+            return rt.greedy(seqs, dec_prefix, max_new, eos_id, pad_id)
+
+        def score(self, *a, **k):
+            return rt.score(*a, **k)
+
+    docs = [SearchResult(docid=f"d{i}", score=0.0, text=f"text {i} about things") for i in range(4)]
+    plain = SetwiseLlmRanker.from_runtime(rt, tok, num_child=3, k=2, scoring="generation")
+    hinted = SetwiseLlmRanker.from_runtime(Hinted(), tok, num_child=3, k=2, scoring="generation")
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert hinted.compare("a query", docs) == plain.compare("a query", docs)
+    assert seen == [hinted.target_token_ids[:4]]
+    pw = PairwiseLlmRanker.from_runtime(Hinted(), tok, method="bubblesort", k=2)
+    pw0 = PairwiseLlmRanker.from_runtime(rt, tok, method="bubblesort", k=2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert pw.compare("a query", ["one text", "another text"]) == pw0.compare("a query", ["one text", "another text"])
+    assert seen[-1] == pw._label_ids and len(seen[-1]) == 2
