@@ -50,3 +50,15 @@ __device__ __forceinline__ float row16_sum_f(float v) {
   return v;
 }
 
+// Folded RMSNorm row factor from the per-block sums of squares a residual GEMM epilogue left: blocks added in increasing
+// order, rsqrt(sum / d + eps) / xs.  ONE definition for rowscale_kernel and for the GEMMs that form the factor themselves
+// (gemm.h: gemm_row_factors) - which of the two runs depends on the tile variant, i.e. on the batch, so they must agree bit for bit.
+__device__ __forceinline__ float rk_row_factor(const float* __restrict__ src, int nb, int d, float eps, float xs) {
+  float s = 0.f;
+  if ((nb & 3) == 0) {
+    for (int j = 0; j < nb; j += 4) { const f32x4 v = *(const f32x4*)(src + j); s += v[0]; s += v[1]; s += v[2]; s += v[3]; }
+  } else {
+    for (int j = 0; j < nb; ++j) s += src[j];
+  }
+  return rsqrtf(s / (float)d + eps) / xs;
+}

@@ -354,10 +354,9 @@ __device__ __forceinline__ void gemm_row_factors(const GemmArgs& p, int mbase, i
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     rsc[mi] = p.scale;
-    if (p.rowscale) {
-      const int m = mbase + mi * 32 + l31;
-      rsc[mi] *= p.rowscale[m < p.M ? m : p.M - 1];
-    }
+    const int m = mbase + mi * 32 + l31;
+    if (p.rowscale) rsc[mi] *= p.rowscale[m < p.M ? m : p.M - 1];
+    else if (p.ssq_in) rsc[mi] *= rk_row_factor(p.ssq_in + (size_t)(m < p.M ? m : p.M - 1) * p.nb_in, p.nb_in, p.K, p.eps_in, p.xs);   // no statistics kernel ran (small M)
   }
 }
 

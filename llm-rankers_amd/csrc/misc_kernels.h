@@ -44,14 +44,7 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__
                                                        int n_rows, int nb, int d, float eps, float xs) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= n_rows) return;
-  const float* src = ssq + (size_t)row * nb;
-  float s = 0.f;
-  if ((nb & 3) == 0) {
-    for (int j = 0; j < nb; j += 4) { const f32x4 v = *(const f32x4*)(src + j); s += v[0]; s += v[1]; s += v[2]; s += v[3]; }
-  } else {
-    for (int j = 0; j < nb; ++j) s += src[j];
-  }
-  rowscale[row] = rsqrtf(s / (float)d + eps) / xs;
+  rowscale[row] = rk_row_factor(ssq + (size_t)row * nb, nb, d, eps, xs);
 }
 
 // hf: modeling_t5.py:59-72 (T5LayerNorm): y = w * x * rsqrt(mean(x^2) + eps); fp32 statistics, fp16 result

@@ -104,7 +104,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1;
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
@@ -242,6 +242,13 @@ int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_p
   return bv;
 }
 
+// does a folded-norm consumer GEMM of this shape run the persistent ping-pong kernel (row factors from rowscale_kernel)?
+bool consumer_uses_pp2(const rk_engine* e, int epi, int M, int N, int K) {
+  int v = choose_variant(e, epi, M, N, K, false);
+  if (v > 6) v = 5;
+  return v == 5 && K >= 128;
+}
+
 template <int EPI>
 void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
   int variant = choose_variant(e, EPI, a.M, a.N, a.K, a.xraw != nullptr);
@@ -311,7 +318,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
   if (M <= 0) return;
   GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale, bsA, bsW, bsC};
   a.rowscale = fold.rowscale; a.xraw = fold.xraw; a.ssq = fold.ssq; a.ldx = N; a.nb = (N + 63) / 64; a.xs = RK_XRAW_SCALE;
-  a.ssq_in = fold.ssq_in; a.nb_in = (K + 31) / 32; a.eps_in = e->d.eps;
+  a.ssq_in = fold.ssq_in; a.nb_in = (K + 63) / 64; a.eps_in = e->d.eps;       // (tiled producers: 64-column blocks)
   const double flops = 2.0 * M * (double)N * K * batch;
   const double out_elems = EPI_IS_GATED(epi) ? (double)M * N / 2 : (double)M * N;
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
@@ -325,7 +332,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
     // kernel delaying some tile of the GEMM in flight, not its CU-time; so: many short workgroups)
     const dim3 b(SKINNY_THREADS);
     const unsigned gy = (unsigned)batch, gz = (unsigned)((M + 31) / 32);
-    a.nb = (N + 31) / 32;                                     // this kernel's producer blocks are 32 columns wide
+    a.nb = (N + 31) / 32; a.nb_in = (K + 31) / 32;             // this kernel's producer blocks are 32 columns wide
     switch (epi) {
       case EPI_STORE_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F16, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
       case EPI_RESID_F32: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RESID_F32, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
@@ -446,13 +453,19 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
   // producer of the stream: embedding / residual epilogue), their weights carry the norm weight, and their epilogue
   // applies the row factor - the two norm kernels per layer (re-reading the fp32 stream) are gone.
   const bool fold = e->opt_fold_norm != 0;
-  GemmFold cons, prod;
-  if (fold) { cons.rowscale = sl.rowscale; prod.xraw = sl.xraw; prod.ssq = sl.ssq; }
+  GemmFold cons, cons_ssq, prod;
+  if (fold) { cons.rowscale = sl.rowscale; cons_ssq.ssq_in = sl.ssq; prod.xraw = sl.xraw; prod.ssq = sl.ssq; }
+  // The persistent ping-pong GEMM takes its row factors ready-made (loaded under its last MFMAs): a rowscale_kernel runs in
+  // front of it.  The fill-in tile variants of small launches (one setwise prompt) add the block sums themselves in their
+  // epilogue (gemm_row_factors, same rk_row_factor -> same bits): two 5-us launches per layer less where launches are what costs.
+  const bool qkv_pp2 = !e->opt_consumer_stats || consumer_uses_pp2(e, EPI_STORE_F16, T, 3 * I, dm);
+  const bool ffn_pp2 = !e->opt_consumer_stats || consumer_uses_pp2(e, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, T, d.gated_gelu ? 2 * F : F, dm);
   embed(e, st, sl.d_tokens, sl.hidden, T, fold ? sl.xraw : nullptr, fold ? sl.rowscale : nullptr);
   for (int l = 0; l < d.n_enc_layers; ++l) {
     const EncLayerW& w = e->enc[l];
     if (fold) {
-      gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xraw, dm, w.qkv_f, dm, sl.qkv, 3 * I, T, 3 * I, dm, 0, 0, 1.f, 1, 0, 0, 0, false, cons);
+      gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xraw, dm, w.qkv_f, dm, sl.qkv, 3 * I, T, 3 * I, dm, 0, 0, 1.f, 1, 0, 0, 0, false,
+           (l == 0 || qkv_pp2) ? cons : cons_ssq);            // layer 0: the embedding kernel wrote the row factors
     } else {
       rmsnorm(e, st, sl.hidden, w.ln0, sl.xn, nullptr, T);
       gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xn, dm, w.qkv, dm, sl.qkv, 3 * I, T, 3 * I, dm);
@@ -491,14 +504,14 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
     }
     if (fold) {
       gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, I, w.o, I, sl.hidden, dm, T, dm, I, 0, 0, 1.f, 1, 0, 0, 0, false, prod);
-      rowscale(e, st, sl.ssq, sl.rowscale, T);
+      if (ffn_pp2) rowscale(e, st, sl.ssq, sl.rowscale, T);
       if (d.gated_gelu)
-        gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_GEGLU_F16, sl.xraw, dm, w.ffn_in_f, dm, sl.ffh, F, T, 2 * F, dm, 0, 0, 1.f, 1, 0, 0, 0, false, cons);
+        gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_GEGLU_F16, sl.xraw, dm, w.ffn_in_f, dm, sl.ffh, F, T, 2 * F, dm, 0, 0, 1.f, 1, 0, 0, 0, false, ffn_pp2 ? cons : cons_ssq);
       else
-        gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_RELU_F16, sl.xraw, dm, w.ffn_in_f, dm, sl.ffh, F, T, F, dm, 0, 0, 1.f, 1, 0, 0, 0, false, cons);
+        gemm(e, st, PC_ENC_GEMM_FFN_IN, EPI_RELU_F16, sl.xraw, dm, w.ffn_in_f, dm, sl.ffh, F, T, F, dm, 0, 0, 1.f, 1, 0, 0, 0, false, ffn_pp2 ? cons : cons_ssq);
       const bool last = l + 1 == d.n_enc_layers;   // the final norm reads the fp32 stream itself
       gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, sl.ffh, F, w.ffn_out, F, sl.hidden, dm, T, dm, F, 0, 0, 1.f, 1, 0, 0, 0, false, last ? GemmFold() : prod);
-      if (!last) rowscale(e, st, sl.ssq, sl.rowscale, T);
+      if (!last && qkv_pp2) rowscale(e, st, sl.ssq, sl.rowscale, T);
       continue;
     }
     gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, I, w.o, I, sl.hidden, dm, T, dm, I);
@@ -1760,6 +1773,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_persistent")) { e->opt_gemm_persistent = value; return RK_OK; }   // ping-pong GEMM: 1 = one workgroup per CU walks the tiles
   if (!strcmp(key, "attn_tiled_occ")) { e->opt_attn_tiled_occ = value; return RK_OK; }   // tiled encoder attention: register budget for 1 / 2 / 3 waves per SIMD
   if (!strcmp(key, "gemm_s64_stages")) { e->opt_s64_stages = value; return RK_OK; }   // LDS stages of the 64x64 GEMM: 0 = auto, 2..4
+  if (!strcmp(key, "consumer_stats")) { e->opt_consumer_stats = value != 0; return RK_OK; }   // encoder row factors formed by the non-persistent consumer GEMMs themselves (1) or always by rowscale_kernel (0)
   if (!strcmp(key, "attn_split")) { e->opt_attn_split = value != 0; return RK_OK; }           // sequences longer than 512 tokens: key tiles split over two wave groups (1) or one walk (0)
   if (!strcmp(key, "greedy_spec")) { e->opt_greedy_spec = value; return RK_OK; }            // rk_t5_greedy2: most decoder rows (prompts x (prefix + candidates)) of a speculative pass; 0 = never speculate
   if (!strcmp(key, "dec_fold_norm")) { e->opt_dec_fold_norm = value != 0; return RK_OK; }   // decoder RMSNorms folded into the weight-streaming GEMMs (1) or separate kernels (0)

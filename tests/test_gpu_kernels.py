@@ -360,9 +360,16 @@ def test_folded_rmsnorm_matches_separate_norm_kernels(toy):
         for v in (1, 2, 3, 4, 5, 6):
             eng.set_option("gemm_variant", v)
             np.testing.assert_array_equal(eng.score(seqs, [0], ids), fold, err_msg=f"tile variant {v}")
+        # row factors formed by the consumer GEMM's epilogue (fill-in variants) or by rowscale_kernel (ping-pong kernel): same bits
+        for v in (0, 1, 6):
+            eng.set_option("gemm_variant", v)
+            eng.set_option("consumer_stats", 0)
+            np.testing.assert_array_equal(eng.score(seqs, [0], ids), fold, err_msg=f"rowscale_kernel in front of variant {v}")
+            eng.set_option("consumer_stats", 1)
     finally:
         eng.set_option("gemm_variant", 0)
         eng.set_option("fold_norm", 1)
+        eng.set_option("consumer_stats", 1)
     assert np.abs(fold - plain).max() < 5e-3, np.abs(fold - plain).max()
     assert np.abs(fold - want).max() < LOGIT_TOL and np.abs(plain - want).max() < LOGIT_TOL
     assert np.abs(_sigm(fold[:, 0] - fold[:, 1]) - _sigm(want[:, 0] - want[:, 1])).max() < SCORE_TOL
