@@ -83,6 +83,7 @@ struct Slot {
   float* d_scores = nullptr; float* h_scores = nullptr;
   int* h_small = nullptr;                                      // pinned staging for small int uploads
   std::vector<int> cache_dec, cache_out, cache_rows;
+  std::vector<int> cache_g2; unsigned long dec_epoch = 0, g2_epoch = ~0ul;   // rk_t5_greedy2's five index arrays, valid while no other path wrote the decoder id / row buffers (dec_epoch)
   hipEvent_t ev_enc = nullptr, ev_dec = nullptr; bool dec_pending = false;
 };
 
@@ -417,6 +418,7 @@ int set_device(rk_engine* e) {
 int upload_small(rk_engine* e, Slot& sl, hipStream_t st, std::vector<int>* cache, int* dptr, int pin_slot, const int* src, int n) {
   if ((int)cache->size() == n && (n == 0 || memcmp(cache->data(), src, n * sizeof(int)) == 0)) return RK_OK;
   HIPCHK(e, hipStreamSynchronize(st));   // the pinned slot may still be in flight
+  ++sl.dec_epoch;
   if (n > 8192) {                        // larger than a pinned slot: plain synchronous copy
     HIPCHK(e, hipMemcpy(dptr, src, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
     cache->assign(src, src + n);
@@ -717,7 +719,7 @@ int upload_dec_ids_shared(rk_engine* e, Slot& sl, const int32_t* prefix, int Ld)
   if (ids.size() > 8192) {   // larger than a pinned slot: plain synchronous copy
     HIPCHK(e, hipStreamSynchronize(st));
     HIPCHK(e, hipMemcpy(sl.d_dec_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
-    sl.cache_dec.clear();
+    sl.cache_dec.clear(); ++sl.dec_epoch;
     return RK_OK;
   }
   return upload_small(e, sl, st, &sl.cache_dec, sl.d_dec_ids, 0, ids.data(), (int)ids.size());
@@ -1292,7 +1294,7 @@ static int greedy_step(rk_engine* e, Slot& sl, const std::vector<std::vector<int
   HIPCHK(e, hipStreamSynchronize(sd));
   HIPCHK(e, hipMemcpy(sl.d_dec_ids, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPCHK(e, hipMemcpy(sl.d_last_rows, rowmap.data(), n_seq * sizeof(int), hipMemcpyHostToDevice));
-  sl.cache_dec.clear(); sl.cache_rows.clear();
+  sl.cache_dec.clear(); sl.cache_rows.clear(); ++sl.dec_epoch;
   int rc = run_graphed(e, sd, {1, 0, n_seq, Ld, sl.have_cross_kv ? sl.maxL : (sl.maxL + 63) / 64, (int)sl.have_cross_kv, (int)e->amax_rows}, [&]() -> int {
     int r = run_decoder(e, sl, Ld);
     if (r) return r;
@@ -1390,13 +1392,23 @@ int rk_t5_greedy2(rk_engine* e, const int32_t* tokens, const int32_t* seq_offset
       rows[n_seq + b * n_cand + c] = r;                                // token 2 if token 1 was candidate c
     }
   }
-  HIPCHK(e, hipStreamSynchronize(sd));
-  HIPCHK(e, hipMemcpy(sl.d_dec_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(e, hipMemcpy(sl.d_last_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(e, hipMemcpy(sl.d_row_seq, rseq.data(), rseq.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(e, hipMemcpy(sl.d_tree_pos, rpos.data(), rpos.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPCHK(e, hipMemcpy(sl.d_tree_keys, keys.data(), keys.size() * sizeof(int), hipMemcpyHostToDevice));
-  sl.cache_dec.clear(); sl.cache_rows.clear();
+  // the five index arrays are the same for every compare of a query (same prefix, candidates and prompt count): uploaded
+  // only when they differ from what this path left on the device and nobody else wrote the shared id / row buffers since
+  std::vector<int> sig;
+  sig.reserve(ids.size() + rows.size() + rseq.size() + rpos.size() + keys.size() + 2);
+  sig.push_back(n_seq); sig.push_back(Ld);
+  for (const std::vector<int>* v : {&ids, &rows, &rseq, &rpos, &keys}) sig.insert(sig.end(), v->begin(), v->end());
+  if (sl.g2_epoch != sl.dec_epoch || sig != sl.cache_g2) {
+    HIPCHK(e, hipStreamSynchronize(sd));
+    HIPCHK(e, hipMemcpy(sl.d_dec_ids, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(sl.d_last_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(sl.d_row_seq, rseq.data(), rseq.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(sl.d_tree_pos, rpos.data(), rpos.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(sl.d_tree_keys, keys.data(), keys.size() * sizeof(int), hipMemcpyHostToDevice));
+    sl.cache_dec.clear(); sl.cache_rows.clear();
+    sl.cache_g2.swap(sig);
+    sl.g2_epoch = ++sl.dec_epoch;
+  }
   const DecTree tree{(int)M, sl.d_tree_keys, sl.d_tree_pos, sl.d_row_seq};
   rc = run_graphed(e, sd, {2, 0, n_seq, Ld, (sl.maxL + 63) / 64, n_cand, (int)e->amax_rows}, [&]() -> int {
     int r = run_decoder(e, sl, Ld, &tree);
