@@ -8,7 +8,6 @@ the two orderings of a pair in one engine call, and for `allpair` for as many pa
 once (the reference's batch_size only shapes its host loop and the padded-shape counters, reproduced arithmetically).
 Llama-family models raise NotImplementedError as in the other rankers.
 """
-import copy
 from itertools import combinations
 from typing import List
 
@@ -145,7 +144,7 @@ class PairwiseLlmRanker(LlmRanker):
 
     def rerank(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
         # ref: pairwise.py:164-295
-        original_ranking = copy.deepcopy(ranking)
+        original_docids = [doc.docid for doc in ranking]      # (the reference deep-copies the list; only the docid order is read)
         self.total_compare = 0
         self.total_completion_tokens = 0
         self.total_prompt_tokens = 0
@@ -178,9 +177,9 @@ class PairwiseLlmRanker(LlmRanker):
             top.add(doc.docid)
             results.append(SearchResult(docid=doc.docid, score=-rank, text=None))
             rank += 1
-        for doc in original_ranking:
-            if doc.docid not in top:
-                results.append(SearchResult(docid=doc.docid, score=-rank, text=None))
+        for docid in original_docids:
+            if docid not in top:
+                results.append(SearchResult(docid=docid, score=-rank, text=None))
                 rank += 1
         return results
 
