@@ -56,3 +56,33 @@ def test_create_without_gpu_fails_loudly():
         assert e.code in (-2, -3)
     else:
         raise AssertionError("engine creation succeeded without a GPU")
+
+
+def test_header_is_plain_c_and_a_c_caller_links(tmp_path):
+    """The boundary is a C ABI: include/rk_engine.h compiles as C99 (no C++ or torch types), and a C translation unit that
+    takes the address of every declared entry point links against the in-tree library - what a cgo / JNI / ctypes binding
+    on the reference's side needs.  Nothing is executed (no GPU here)."""
+    import shutil
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("gcc not available")
+    inc = os.path.join(REPO, "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "rk_engine.h")], check=True)
+    names = _header_functions()
+    src = tmp_path / "bind.c"
+    src.write_text('#include "rk_engine.h"\n#include <stdio.h>\nint main(void) {\n  const void* f[] = {\n'
+                   + "".join(f"    (const void*)&{n},\n" for n in names)
+                   + '  };\n  printf("%d entry points\\n", (int)(sizeof f / sizeof f[0]));\n  return f[0] == 0;\n}\n')
+    obj = tmp_path / "bind.o"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-Wno-pedantic", "-I", inc, "-c", str(src), "-o", str(obj)], check=True)
+    out = subprocess.run(["nm", "-u", str(obj)], check=True, capture_output=True, text=True).stdout
+    undefined = {line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("rk_")}
+    assert undefined == set(names)
+    lib = os.path.join(REPO, "llm-rankers_amd", "lib", "librk_engine.so")
+    exported = subprocess.run(["nm", "-D", "--defined-only", lib], check=True, capture_output=True, text=True).stdout
+    exported = {line.split()[-1] for line in exported.splitlines() if line.split()}
+    assert undefined <= exported
