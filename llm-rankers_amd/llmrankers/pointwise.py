@@ -160,6 +160,44 @@ class PointwiseLlmRanker(LlmRanker):
                 doc.score = float(sc)
         return sorted(ranking, key=lambda x: x.score, reverse=True)
 
+    def rerank_many(self, items):
+        """Several queries per engine launch sequence: `items` = [(query, ranking), ...] -> (rankings, counters) where
+        rankings[i] is exactly what `rerank(*items[i])` returns (same objects scored in place, same order) and counters[i]
+        = (total_compare, total_prompt_tokens, total_completion_tokens) that call would have left.  The reference ranks one
+        query at a time (ref: run.py:183-201); a passage's score does not depend on what shares its engine call (ragged
+        execution, bit-exact), so the batches of all the queries go to the engine together - its GEMMs then run on several
+        hundred passages instead of a hundred and the decoder chain runs once (grouped launches).
+        qlm (per-query labels), unknown methods and sharded runs take the one-by-one path."""
+        items = list(items)
+        specs = []
+        grouped = not self.shard_candidates
+        for query, ranking in items:
+            spec = self._spec(query, ranking) if grouped else None
+            specs.append(spec)
+            if spec is None or spec[1] != "score" or (specs[0] is not None and (spec[2], spec[3]) != (specs[0][2], specs[0][3])):
+                grouped = False
+        if not grouped or not items:
+            out, counters = [], []
+            for query, ranking in items:
+                out.append(self.rerank(query, ranking))
+                counters.append((self.total_compare, self.total_prompt_tokens, self.total_completion_tokens))
+            return out, counters
+        chunks, counters, sizes = [], [], []
+        for (query, ranking), spec in zip(items, specs):
+            self._reset()
+            prompts, _, _, _, dec_len, _ = spec
+            chunks.extend(self._counted_batches(prompts, dec_len))
+            counters.append((self.total_compare, self.total_prompt_tokens, self.total_completion_tokens))
+            sizes.append(len(prompts))
+        raw = self._raw(chunks, "score", specs[0][2], specs[0][3])
+        out, pos = [], 0
+        for (query, ranking), spec, n in zip(items, specs, sizes):
+            for doc, sc in zip(ranking, spec[5](raw[pos:pos + n])):
+                doc.score = float(sc)
+            pos += n
+            out.append(sorted(ranking, key=lambda x: x.score, reverse=True))
+        return out, counters
+
     def truncate(self, text, length):
         return self.tokenizer.convert_tokens_to_string(self.tokenizer.tokenize(text)[:length])
 

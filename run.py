@@ -227,6 +227,32 @@ def main(args):
     first_stage_order = {qid: [d.docid for d in ranking] for qid, _, ranking in first_stage}
 
     results, n_cmp, n_prompt, n_compl = [], 0, 0, 0
+    # --queries_per_call N (pointwise only): N queries go to the engine in one launch sequence (PointwiseLlmRanker.rerank_many:
+    # same rankings and counters as one query at a time, the engine's grouped-launch throughput instead of its per-query one)
+    per_call = max(1, int(getattr(args.run, "queries_per_call", 1) or 1))
+    if per_call > 1 and not hasattr(ranker, "rerank_many"):
+        per_call = 1
+    pending = []
+
+    def flush():
+        nonlocal n_cmp, n_prompt, n_compl
+        if not pending:
+            return
+        if len(pending) == 1:
+            qid, query, ranking = pending[0]
+            ranked = [ranker.rerank(query, ranking)]
+            counters = [(ranker.total_compare, ranker.total_prompt_tokens, ranker.total_completion_tokens)]
+        else:
+            ranked, counters = ranker.rerank_many([(query, ranking) for _, query, ranking in pending])
+        for (qid, query, _), res, (c, p, t) in zip(pending, ranked, counters):
+            results.append((qid, query, res))
+            n_cmp += c
+            n_prompt += p
+            n_compl += t
+        if resume:                                                   # durable after every call (ref: Rank-R1/run_setwise.py:79-87)
+            write_run_file(args.run.save_path, results[-len(pending):], "LLMRankers", mode="a")
+        pending.clear()
+
     tic = time.time()
     for qid, query, ranking in first_stage:
         if qid in done:
@@ -235,12 +261,10 @@ def main(args):
             random.shuffle(ranking)
         elif args.run.shuffle_ranking == "inverse":
             ranking = ranking[::-1]
-        results.append((qid, query, ranker.rerank(query, ranking)))
-        n_cmp += ranker.total_compare
-        n_prompt += ranker.total_prompt_tokens
-        n_compl += ranker.total_completion_tokens
-        if resume:                                                   # durable after every query (ref: Rank-R1/run_setwise.py:79-87)
-            write_run_file(args.run.save_path, results[-1:], "LLMRankers", mode="a")
+        pending.append((qid, query, ranking))
+        if len(pending) >= per_call:
+            flush()
+    flush()
     toc = time.time()
     n = max(len(results), 1)
     print(f"Avg comparisons: {n_cmp / n}")
@@ -284,6 +308,8 @@ def build_parser():
     rp.add_argument("--dataset_number_of_shards", type=int, default=1)
     rp.add_argument("--dataset_shard_index", type=int, default=0)
     rp.add_argument("--qrels", type=str, default=None, help="TREC qrels file: print NDCG@10 of the input and the reranked run")
+    rp.add_argument("--queries_per_call", type=int, default=1,
+                    help="pointwise: queries scored per engine launch sequence (same rankings and counters; 3-4 reach the engine's grouped throughput)")
     pw = commands.add_parser("pointwise")
     pw.add_argument("--method", type=str, default="yes_no", choices=["qlm", "yes_no"])
     pw.add_argument("--batch_size", type=int, default=2)

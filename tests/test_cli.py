@@ -168,3 +168,70 @@ def test_passage_truncation_is_cached_per_docid(runmod, tmp_path, ckpt_dirs, mon
     runmod.main(args)
     assert sorted(c for c in calls if c in docs) == sorted(docs)          # 4 passages truncated once each, not 12 times
     assert len((tmp_path / "out.trec").read_text().splitlines()) == 12
+
+
+def test_queries_per_call_gives_the_same_run_and_statistics(runmod, tmp_path, ckpt_dirs, monkeypatch, capsys):
+    """--queries_per_call N (pointwise): N queries per engine launch sequence through PointwiseLlmRanker.rerank_many - the
+    TREC file and the printed averages (comparisons, prompt / completion tokens) are those of one query at a time, also
+    with --resume and with a last, shorter group; rerank_many itself returns per query what rerank returns (scores, order,
+    counters), for yes_no and MonoT5, and takes the one-by-one path for qlm."""
+    from conftest import load_state
+    from _stub import OracleRuntime
+    from transformers import T5Tokenizer
+    from llmrankers.pointwise import PointwiseLlmRanker, MonoT5LlmRanker
+    from llmrankers.rankers import SearchResult
+    ck = ckpt_dirs["ckpt_gated_untied"]
+    dims, state = load_state(ck)
+    tok = T5Tokenizer.from_pretrained(ck)
+    engine_calls = []
+
+    class Counting(OracleRuntime):
+        def score_batches(self, batches, dec_prefix, out_ids):           # like T5Runtime: consecutive batches merged into one engine call
+            flat = [s for b in batches for s in b]
+            engine_calls.append(len(flat))
+            return [self.score(flat, dec_prefix, out_ids)]
+
+    monkeypatch.setattr(runmod, "build_ranker", lambda args: PointwiseLlmRanker.from_runtime(
+        Counting(dims, state), tok, method=args.pointwise.method, batch_size=args.pointwise.batch_size))
+    words = ["search engine index", "river water city", "music art film", "vaccine covid virus", "bank money trade"]
+    (tmp_path / "q.tsv").write_text("".join(f"q{i}\t{w}\n" for i, w in enumerate(words)))
+    (tmp_path / "d.tsv").write_text("".join(f"d{i}\t{w} {words[(i + 2) % 5]}\n" for i, w in enumerate(words)))
+    lines = [f"q{q} Q0 d{(q + r) % 5} {r + 1} {10 - r} bm25" for q in range(5) for r in range(4)]
+    (tmp_path / "in.trec").write_text("\n".join(lines) + "\n")
+    parser, commands = runmod.build_parser()
+
+    def run(save, extra=()):
+        args = runmod.parse_args(parser, commands, ["run", "--model_name_or_path", ck, "--run_path", str(tmp_path / "in.trec"),
+                                                    "--save_path", str(save), "--query_file", str(tmp_path / "q.tsv"),
+                                                    "--doc_file", str(tmp_path / "d.tsv"), "--hits", "4", *extra,
+                                                    "pointwise", "--method", "yes_no", "--batch_size", "3"])
+        runmod.validate(args)
+        capsys.readouterr()
+        runmod.main(args)
+        return [l for l in capsys.readouterr().out.splitlines() if l.startswith("Avg") and "time" not in l]
+
+    stats1 = run(tmp_path / "one.trec")
+    n1 = len(engine_calls)
+    del engine_calls[:]
+    stats3 = run(tmp_path / "three.trec", ["--queries_per_call", "3"])             # groups of 3 + 2
+    assert (tmp_path / "three.trec").read_text() == (tmp_path / "one.trec").read_text()
+    assert stats3 == stats1 and len(stats1) == 3
+    assert n1 == 5 and engine_calls == [12, 8]                                      # 3 + 2 queries of 4 passages per engine call
+    run(tmp_path / "res.trec", ["--queries_per_call", "2", "--resume"])
+    assert (tmp_path / "res.trec").read_text() == (tmp_path / "one.trec").read_text()
+
+    def ranking(q):
+        return [SearchResult(docid=f"d{(q + r) % 5}", score=float(10 - r), text=f"{words[(q + r) % 5]} and {words[q]}") for r in range(4)]
+
+    for cls, kw in ((PointwiseLlmRanker, {"method": "yes_no"}), (PointwiseLlmRanker, {"method": "qlm"})):
+        rk = cls.from_runtime(OracleRuntime(dims, state), tok, batch_size=3, **kw)
+        single, counters = [], []
+        for q in range(3):
+            res = rk.rerank(words[q], ranking(q))
+            single.append([(d.docid, d.score) for d in res])
+            counters.append((rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens))
+        many, cnt = rk.rerank_many([(words[q], ranking(q)) for q in range(3)])
+        assert [[(d.docid, d.score) for d in res] for res in many] == single and cnt == counters
+        assert (rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens) == counters[-1]
+    assert PointwiseLlmRanker.from_runtime(OracleRuntime(dims, state), tok, method="yes_no", batch_size=3).rerank_many([]) == ([], [])
+    assert MonoT5LlmRanker.rerank_many is PointwiseLlmRanker.rerank_many
