@@ -192,34 +192,38 @@ class SetwiseLlmRanker(LlmRanker):
         """Independent compares in ONE engine call.  Same outputs and counters as `compare()` on each window in turn
         (num_permutation == 1 only: no random draws are involved); the engine's results do not depend on which
         prompts share a call (ragged execution, bit-exact batch independence)."""
-        assert self.num_permutation == 1
+        outs, prompt_tokens, completion_tokens = self._compare_windows([query] * len(doc_lists), doc_lists)
         self.total_compare += len(doc_lists)
-        texts = [self._prompt(query, self.CHARACTERS[:len(docs)], [d.text for d in docs]) for docs in doc_lists]
+        self.total_prompt_tokens += sum(prompt_tokens)
+        self.total_completion_tokens += sum(completion_tokens)
+        return outs
+
+    def _compare_windows(self, queries: List[str], doc_lists: List[List]):
+        """The engine call behind `_compare_many`, for windows that may belong to different queries (`rerank_many`):
+        -> (labels, prompt tokens per window, completion tokens per window); touches no counter."""
+        assert self.num_permutation == 1
+        texts = [self._prompt(q, self.CHARACTERS[:len(docs)], [d.text for d in docs]) for q, docs in zip(queries, doc_lists)]
         if self.model_type == "llama":
             if self.scoring != 'generation':
                 raise NotImplementedError
             ids = [self._llama_prompt_ids(t) for t in texts]
             toks = self.llm.greedy1(ids)
-            outs = []
-            for seq, tok in zip(ids, toks):
-                self.total_prompt_tokens += len(seq)
-                self.total_completion_tokens += len(seq) + 1
-                outs.append(self.tokenizer.decode([int(tok)], skip_special_tokens=True).strip().upper())
+            outs = [self.tokenizer.decode([int(tok)], skip_special_tokens=True).strip().upper() for tok in toks]
             for output in outs:
                 if not (len(output) == 1 and output in self.CHARACTERS):
                     print(f"Unexpected output: {output}")
-            return outs
+            return outs, [len(seq) for seq in ids], [len(seq) + 1 for seq in ids]
         ids = tokenize_prompts(self.tokenizer, texts)
-        self.total_prompt_tokens += sum(len(i) for i in ids)
-        outs = []
+        prompt_tokens = [len(i) for i in ids]
+        outs, completion_tokens = [], [0] * len(ids)
         if self.scoring == 'generation':
             eos = self.tokenizer.eos_token_id
-            for row in self._generate(ids):
+            for r, row in enumerate(self._generate(ids)):
                 new = row[len(self.decoder_input_ids):]
                 if eos in new:                                  # alone, this row would have stopped at its own EOS
                     new = new[:new.index(eos) + 1]
                 row = list(self.decoder_input_ids) + new
-                self.total_completion_tokens += len(row)
+                completion_tokens[r] = len(row)
                 outs.append(self.tokenizer.decode(row, skip_special_tokens=True).strip()[-1])
         elif self.scoring == 'likelihood':
             if any(len(docs) == 0 for docs in doc_lists):
@@ -232,7 +236,7 @@ class SetwiseLlmRanker(LlmRanker):
         for output in outs:
             if not (len(output) == 1 and output in self.CHARACTERS):
                 print(f"Unexpected output: {output}")
-        return outs
+        return outs, prompt_tokens, completion_tokens
 
     def _batched_ok(self) -> bool:
         # level-wise batching needs compare() to be ours (no subclass / instance override) and draw-free
@@ -355,6 +359,110 @@ class SetwiseLlmRanker(LlmRanker):
                 results.append(SearchResult(docid=docid, score=-rank, text=None))
                 rank += 1
         return results
+
+    # ---- several queries at once ---------------------------------------------------------------------------
+    def _heapsort_steps(self, arr, k):
+        """heapSort(arr, query, k) as a generator: yields lists of windows whose compares are independent of each other
+        (one tree level of the build phase, then one sift-down step at a time) and is sent their labels.  Same array
+        updates, compares and order as `_build_heap_batched` + `heapify` (the shipped single-query path)."""
+        c, n = self.num_child, len(arr)
+        levels = {}
+        for i in range(n // c, -1, -1):
+            if c * i + 1 < n:
+                depth, first = 0, 0
+                while i >= first + c ** depth:
+                    first += c ** depth
+                    depth += 1
+                levels.setdefault(depth, []).append(i)
+        for depth in sorted(levels, reverse=True):
+            active = levels[depth]
+            while active:
+                windows = [[i] + list(range(c * i + 1, min(c * (i + 1) + 1, n))) for i in active]
+                outs = yield [[arr[j] for j in inds] for inds in windows]
+                nxt = []
+                for i, inds, out in zip(active, windows, outs):
+                    best = self._pick(out)
+                    largest = inds[best] if best < len(inds) else i
+                    if largest != i:
+                        arr[i], arr[largest] = arr[largest], arr[i]
+                        if c * largest + 1 < n:
+                            nxt.append(largest)
+                active = nxt
+        ranked = 0
+        for m in range(n - 1, 0, -1):
+            arr[m], arr[0] = arr[0], arr[m]
+            ranked += 1
+            if ranked == k:
+                break
+            i = 0
+            while c * i + 1 < m:
+                inds = [i] + list(range(c * i + 1, min(c * (i + 1) + 1, m)))
+                (out,) = yield [[arr[j] for j in inds]]
+                best = self._pick(out)
+                largest = inds[best] if best < len(inds) else i
+                if largest == i:
+                    break
+                arr[i], arr[largest] = arr[largest], arr[i]
+                i = largest
+
+    def rerank_many(self, items):
+        """Several queries at once: `items` = [(query, ranking), ...] -> (results, counters); results[i] and counters[i] =
+        (total_compare, total_prompt_tokens, total_completion_tokens) are exactly what `rerank(*items[i])` gives, and the
+        callers' lists end up re-ordered the same way.  The compares of ONE query are a dependency chain (each sift-down step
+        needs the previous label), but the chains of different queries are independent: their pending compares go to the
+        engine together, one call per step of all the chains - several ~900-token prompts per launch sequence instead of one
+        (a compare's result does not depend on what shares its engine call: ragged execution, bit-exact).
+        heapsort with the draw-free default settings; anything else takes the one-by-one path."""
+        items = list(items)
+        if self.method != "heapsort" or not self._batched_ok() or len(items) < 2:
+            out, counters = [], []
+            for query, ranking in items:
+                out.append(self.rerank(query, ranking))
+                counters.append((self.total_compare, self.total_prompt_tokens, self.total_completion_tokens))
+            return out, counters
+        originals = [[doc.docid for doc in ranking] for _, ranking in items]
+        counts = [[0, 0, 0] for _ in items]
+        gens = [self._heapsort_steps(ranking, self.k) for _, ranking in items]
+        pending = {}
+        for q, gen in enumerate(gens):
+            try:
+                pending[q] = next(gen)
+            except StopIteration:
+                pass
+        while pending:
+            order = sorted(pending)
+            queries = [items[q][0] for q in order for _ in pending[q]]
+            windows = [w for q in order for w in pending[q]]
+            outs, ptok, ctok = self._compare_windows(queries, windows)
+            pos, nxt = 0, {}
+            for q in order:
+                n = len(pending[q])
+                counts[q][0] += n
+                counts[q][1] += sum(ptok[pos:pos + n])
+                counts[q][2] += sum(ctok[pos:pos + n])
+                try:
+                    nxt[q] = gens[q].send(outs[pos:pos + n])
+                except StopIteration:
+                    pass
+                pos += n
+            pending = nxt
+        results = []
+        for (query, ranking), original in zip(items, originals):
+            ordered = list(reversed(ranking))
+            res, top, rank = [], set(), 1
+            for doc in ordered[:self.k]:
+                top.add(doc.docid)
+                res.append(SearchResult(docid=doc.docid, score=-rank, text=None))
+                rank += 1
+            for docid in original:
+                if docid not in top:
+                    res.append(SearchResult(docid=docid, score=-rank, text=None))
+                    rank += 1
+            results.append(res)
+        counters = [tuple(c) for c in counts]
+        if counters:
+            self.total_compare, self.total_prompt_tokens, self.total_completion_tokens = counters[-1]
+        return results, counters
 
     def truncate(self, text, length):
         return self.tokenizer.convert_tokens_to_string(self.tokenizer.tokenize(text)[:length])

@@ -227,8 +227,9 @@ def main(args):
     first_stage_order = {qid: [d.docid for d in ranking] for qid, _, ranking in first_stage}
 
     results, n_cmp, n_prompt, n_compl = [], 0, 0, 0
-    # --queries_per_call N (pointwise only): N queries go to the engine in one launch sequence (PointwiseLlmRanker.rerank_many:
-    # same rankings and counters as one query at a time, the engine's grouped-launch throughput instead of its per-query one)
+    # --queries_per_call N: N queries go to the engine together (PointwiseLlmRanker.rerank_many: all their batches in one launch
+    # sequence; SetwiseLlmRanker.rerank_many: their heapsorts advance in lockstep, one engine call per step of all the chains) -
+    # same rankings and counters as one query at a time, the engine's batched throughput instead of its per-query one
     per_call = max(1, int(getattr(args.run, "queries_per_call", 1) or 1))
     if per_call > 1 and not hasattr(ranker, "rerank_many"):
         per_call = 1
@@ -309,7 +310,7 @@ def build_parser():
     rp.add_argument("--dataset_shard_index", type=int, default=0)
     rp.add_argument("--qrels", type=str, default=None, help="TREC qrels file: print NDCG@10 of the input and the reranked run")
     rp.add_argument("--queries_per_call", type=int, default=1,
-                    help="pointwise: queries scored per engine launch sequence (same rankings and counters; 3-4 reach the engine's grouped throughput)")
+                    help="pointwise / setwise heapsort: queries handed to the engine together (same rankings and counters as one at a time)")
     pw = commands.add_parser("pointwise")
     pw.add_argument("--method", type=str, default="yes_no", choices=["qlm", "yes_no"])
     pw.add_argument("--batch_size", type=int, default=2)

@@ -319,3 +319,59 @@ def test_generation_passes_label_candidates_to_runtimes_that_take_them(runtimes)
     with contextlib.redirect_stdout(io.StringIO()):
         assert pw.compare("a query", ["one text", "another text"]) == pw0.compare("a query", ["one text", "another text"])
     assert seen[-1] == pw._label_ids and len(seen[-1]) == 2
+
+
+@pytest.mark.parametrize("scoring", ["generation", "likelihood"])
+def test_setwise_rerank_many_equals_one_query_at_a_time(runtimes, scoring):
+    """SetwiseLlmRanker.rerank_many advances the heapsorts of several queries in lockstep, their pending compares in one
+    engine call per step: per query the result, the caller's re-ordered list and the counters are those of rerank();
+    engine calls carry compares of several queries; other settings fall back to one query at a time."""
+    rt, tok = runtimes["ckpt_labelboost"]
+    calls = []
+
+    class Spy:
+        config = rt.config
+
+        def score(self, seqs, *a, **k):
+            calls.append(len(seqs))
+            return rt.score(seqs, *a, **k)
+
+        def greedy(self, seqs, *a, **k):
+            calls.append(len(seqs))
+            return rt.greedy(seqs, *a, **k)
+
+    rs = random.Random(17)
+    words = "alpha beta gamma delta river water neural model search index music film bank money".split()
+
+    def make(n, seed):
+        r = random.Random(seed)
+        return [SearchResult(docid=f"q{seed}d{i}", score=float(n - i), text=" ".join(r.choice(words) for _ in range(6))) for i in range(n)]
+
+    sizes = [14, 1, 9, 23, 0, 5]
+    queries = [" ".join(rs.choice(words) for _ in range(3)) for _ in sizes]
+    for num_child, k in ((3, 4), (2, 10)):
+        one = SetwiseLlmRanker.from_runtime(rt, tok, num_child=num_child, k=k, scoring=scoring)
+        want, want_lists, want_counters = [], [], []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for q, (query, n) in enumerate(zip(queries, sizes)):
+                ranking = make(n, q)
+                res = one.rerank(query, ranking)
+                want.append([(d.docid, d.score, d.text) for d in res])
+                want_lists.append([d.docid for d in ranking])
+                want_counters.append((one.total_compare, one.total_prompt_tokens, one.total_completion_tokens))
+        del calls[:]
+        many = SetwiseLlmRanker.from_runtime(Spy(), tok, num_child=num_child, k=k, scoring=scoring)
+        rankings = [make(n, q) for q, n in enumerate(sizes)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            got, counters = many.rerank_many(list(zip(queries, rankings)))
+        assert [[(d.docid, d.score, d.text) for d in res] for res in got] == want
+        assert [[d.docid for d in r] for r in rankings] == want_lists
+        assert counters == want_counters
+        assert (many.total_compare, many.total_prompt_tokens, many.total_completion_tokens) == want_counters[-1]
+        assert sum(calls) == sum(c[0] for c in want_counters) and len(calls) < sum(calls) / 2   # same compares, far fewer engine calls
+    # settings with random draws / other sorts: the one-by-one path
+    bub = SetwiseLlmRanker.from_runtime(rt, tok, num_child=2, k=2, scoring=scoring, method="bubblesort")
+    ref = SetwiseLlmRanker.from_runtime(rt, tok, num_child=2, k=2, scoring=scoring, method="bubblesort")
+    with contextlib.redirect_stdout(io.StringIO()):
+        got, _ = bub.rerank_many([(queries[0], make(6, 0)), (queries[2], make(5, 2))])
+        assert [[d.docid for d in r] for r in got] == [[d.docid for d in ref.rerank(queries[0], make(6, 0))], [d.docid for d in ref.rerank(queries[2], make(5, 2))]]

@@ -86,6 +86,24 @@ def main():
                 "ms_per_query": round(best * 1e3, 1), "compares": rk.total_compare,
                 "algorithmic_tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / 2500.0, 4),
                 "avg_prompt_tokens": round(rk.total_prompt_tokens / max(rk.total_compare, 1), 1), "top10": res0}
+    # several queries at once (SetwiseLlmRanker.rerank_many / run.py --queries_per_call): the dependency chains of NQ queries
+    # advance in lockstep, their pending compares share an engine call; identical rankings, amortised time per query
+    NQ = int(os.environ.get("RK_MANY", "4"))
+    qtexts = ["which passage mentions the most relevant words"] + [" ".join(rs.choice(vocab) for _ in range(7)) for _ in range(NQ - 1)]
+    for scoring in ("likelihood", "generation"):
+        rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring=scoring, method="heapsort")
+        best, res0 = None, None
+        for rep in range(3):
+            items = [(q, [SearchResult(docid=d, score=s, text=rk.truncate(t, 128)) for d, s, t in docs]) for q in qtexts]
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                res, counters = rk.rerank_many(items)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            res0 = [r.docid for r in res[0]][:10]
+        assert res0 == out[f"{scoring}_batched"]["top10"], "rerank_many changed the ranking of the first query"
+        out[f"{scoring}_many{NQ}"] = {"ms_per_query": round(best * 1e3 / NQ, 1), "queries_per_call": NQ,
+                                      "compares": sum(c[0] for c in counters)}
     if os.environ.get("RK_HOSTPROF"):                       # where the host time of one query goes (stderr)
         import cProfile, pstats
         rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring="generation", method="heapsort")
