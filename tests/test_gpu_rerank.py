@@ -247,6 +247,46 @@ def test_config3_full_size_setwise_query_flan_t5_large():
     eng.close()
 
 
+def test_rerank_many_equals_one_query_at_a_time_on_the_engine(cases, stack):
+    """rerank_many on the HIP engine: the recorded reference cases of one checkpoint handed over together - pointwise: all
+    batches in one launch sequence; setwise heapsort: the queries' sift-down chains in lockstep, one engine call per step -
+    give per query exactly (bit for bit: scores, order, caller lists, counters) what rerank() gives alone."""
+    from llmrankers.rankers import SearchResult
+
+    def key(c):
+        return (c["kind"], c["ckpt"], c.get("method"), c.get("scoring"), c.get("num_child"), c.get("k"), c.get("batch_size"), c.get("num_permutation"))
+
+    groups = {}
+    for c in cases:
+        if c.get("raises") or (c["kind"] == "setwise" and (c["method"] != "heapsort" or c["num_permutation"] != 1)):
+            continue
+        groups.setdefault(key(c), []).append(c)
+    checked = 0
+    for grp in groups.values():
+        base = grp[0]
+        rt, tok = stack[base["ckpt"]]
+        # several queries over the recorded inputs (a group may hold a single recorded case: vary the query text)
+        items = [(c["query"] + suffix, [tuple(x) for x in c["input"]]) for c in grp for suffix in ("", " again", " once more")]
+        one, many = _build(base, rt, tok), _build(base, rt, tok)
+        want, lists, counters = [], [], []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for q, inp in items:
+                ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in inp]
+                random.seed(929)
+                res = one.rerank(q, ranking)
+                want.append([(r.docid, r.score) for r in res])
+                lists.append([r.docid for r in ranking])
+                counters.append((one.total_compare, one.total_prompt_tokens, one.total_completion_tokens))
+            rankings = [[SearchResult(docid=d, score=s, text=t) for d, s, t in inp] for _, inp in items]
+            got, cnt = many.rerank_many([(q, r) for (q, _), r in zip(items, rankings)])
+        assert [[(r.docid, r.score) for r in res] for res in got] == want, key(base)
+        assert cnt == counters, key(base)
+        if base["kind"] == "setwise":
+            assert [[r.docid for r in ranking] for ranking in rankings] == lists
+        checked += 1
+    assert checked >= 6
+
+
 def tokenize_ids(rk, query, window):
     from llmrankers._batching import tokenize_prompts
     return tokenize_prompts(rk.tokenizer, [rk._prompt(query, rk.CHARACTERS[:len(window)], [d.text for d in window])])[0]
