@@ -405,6 +405,33 @@ class SetwiseLlmRanker(LlmRanker):
                 arr[i], arr[largest] = arr[largest], arr[i]
                 i = largest
 
+    def _bubblesort_steps(self, ranking):
+        """`_bubblesort` as a generator (one window per step; same windows, swaps and `last_start` shortcut)."""
+        c = self.num_child
+        full = len(ranking) - (c + 1)
+        last_start = full
+        for i in range(self.k):
+            start, end = last_start, last_start + (c + 1)
+            changed = False
+            while True:
+                if start < i:
+                    start = i
+                window = ranking[start:end]
+                (out,) = yield [window]
+                best = self._pick(out)
+                if best != 0:
+                    ranking[start], ranking[start + best] = ranking[start + best], ranking[start]
+                    if not changed:
+                        changed = True
+                        if last_start != full and best == len(window) - 1:
+                            last_start += len(window) - 1
+                if start == i:
+                    break
+                if not changed:
+                    last_start -= c
+                start -= c
+                end -= c
+
     def rerank_many(self, items):
         """Several queries at once: `items` = [(query, ranking), ...] -> (results, counters); results[i] and counters[i] =
         (total_compare, total_prompt_tokens, total_completion_tokens) are exactly what `rerank(*items[i])` gives, and the
@@ -412,9 +439,9 @@ class SetwiseLlmRanker(LlmRanker):
         needs the previous label), but the chains of different queries are independent: their pending compares go to the
         engine together, one call per step of all the chains - several ~900-token prompts per launch sequence instead of one
         (a compare's result does not depend on what shares its engine call: ragged execution, bit-exact).
-        heapsort with the draw-free default settings; anything else takes the one-by-one path."""
+        heapsort and bubblesort with the draw-free default settings; anything else takes the one-by-one path."""
         items = list(items)
-        if self.method != "heapsort" or not self._batched_ok() or len(items) < 2:
+        if self.method not in ("heapsort", "bubblesort") or not self._batched_ok() or len(items) < 2:
             out, counters = [], []
             for query, ranking in items:
                 out.append(self.rerank(query, ranking))
@@ -422,7 +449,8 @@ class SetwiseLlmRanker(LlmRanker):
             return out, counters
         originals = [[doc.docid for doc in ranking] for _, ranking in items]
         counts = [[0, 0, 0] for _ in items]
-        gens = [self._heapsort_steps(ranking, self.k) for _, ranking in items]
+        heap = self.method == "heapsort"
+        gens = [self._heapsort_steps(ranking, self.k) if heap else self._bubblesort_steps(ranking) for _, ranking in items]
         pending = {}
         for q, gen in enumerate(gens):
             try:
@@ -448,7 +476,7 @@ class SetwiseLlmRanker(LlmRanker):
             pending = nxt
         results = []
         for (query, ranking), original in zip(items, originals):
-            ordered = list(reversed(ranking))
+            ordered = list(reversed(ranking)) if heap else ranking
             res, top, rank = [], set(), 1
             for doc in ordered[:self.k]:
                 top.add(doc.docid)

@@ -310,7 +310,7 @@ def build_parser():
     rp.add_argument("--dataset_shard_index", type=int, default=0)
     rp.add_argument("--qrels", type=str, default=None, help="TREC qrels file: print NDCG@10 of the input and the reranked run")
     rp.add_argument("--queries_per_call", type=int, default=1,
-                    help="pointwise / setwise heapsort: queries handed to the engine together (same rankings and counters as one at a time)")
+                    help="pointwise / setwise: queries handed to the engine together (same rankings and counters as one at a time)")
     pw = commands.add_parser("pointwise")
     pw.add_argument("--method", type=str, default="yes_no", choices=["qlm", "yes_no"])
     pw.add_argument("--batch_size", type=int, default=2)

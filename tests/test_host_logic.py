@@ -369,9 +369,29 @@ def test_setwise_rerank_many_equals_one_query_at_a_time(runtimes, scoring):
         assert counters == want_counters
         assert (many.total_compare, many.total_prompt_tokens, many.total_completion_tokens) == want_counters[-1]
         assert sum(calls) == sum(c[0] for c in want_counters) and len(calls) < sum(calls) / 2   # same compares, far fewer engine calls
-    # settings with random draws / other sorts: the one-by-one path
-    bub = SetwiseLlmRanker.from_runtime(rt, tok, num_child=2, k=2, scoring=scoring, method="bubblesort")
-    ref = SetwiseLlmRanker.from_runtime(rt, tok, num_child=2, k=2, scoring=scoring, method="bubblesort")
+    # bubblesort: the same lockstep driver (one window per query and step)
+    for num_child, k in ((2, 2), (3, 3)):
+        ref = SetwiseLlmRanker.from_runtime(rt, tok, num_child=num_child, k=k, scoring=scoring, method="bubblesort")
+        bub = SetwiseLlmRanker.from_runtime(Spy(), tok, num_child=num_child, k=k, scoring=scoring, method="bubblesort")
+        bsizes = [9, 6, 12, 5]
+        want, want_lists, want_counters = [], [], []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for q, n in enumerate(bsizes):
+                ranking = make(n, q)
+                want.append([(d.docid, d.score) for d in ref.rerank(queries[q], ranking)])
+                want_lists.append([d.docid for d in ranking])
+                want_counters.append((ref.total_compare, ref.total_prompt_tokens, ref.total_completion_tokens))
+            del calls[:]
+            rankings = [make(n, q) for q, n in enumerate(bsizes)]
+            got, counters = bub.rerank_many(list(zip(queries, rankings)))
+        assert [[(d.docid, d.score) for d in r] for r in got] == want and counters == want_counters
+        assert [[d.docid for d in r] for r in rankings] == want_lists
+        assert max(calls) > 1                                                       # windows of several queries shared a call
+    # permutation voting draws random numbers: the one-by-one path
+    perm = SetwiseLlmRanker.from_runtime(rt, tok, num_child=2, k=2, scoring=scoring, num_permutation=2)
+    ref = SetwiseLlmRanker.from_runtime(rt, tok, num_child=2, k=2, scoring=scoring, num_permutation=2)
     with contextlib.redirect_stdout(io.StringIO()):
-        got, _ = bub.rerank_many([(queries[0], make(6, 0)), (queries[2], make(5, 2))])
+        random.seed(5)
+        got, _ = perm.rerank_many([(queries[0], make(6, 0)), (queries[2], make(5, 2))])
+        random.seed(5)
         assert [[d.docid for d in r] for r in got] == [[d.docid for d in ref.rerank(queries[0], make(6, 0))], [d.docid for d in ref.rerank(queries[2], make(5, 2))]]
