@@ -142,6 +142,15 @@ int rk_comm_world(const rk_engine* e, int* out_rank, int* out_world);
  * Returns without synchronising.  rk_comm_read_gathered_slot waits and copies out[world][n_floats]. */
 int rk_comm_all_gather_slot(rk_engine* e, int slot, int n_floats);
 int rk_comm_read_gathered_slot(rk_engine* e, int slot, float* out, int n_floats_total);
+/* Appended form for a rank whose share of the candidates takes several engine calls (more than max_seqs sequences or
+ * max_tokens tokens): after each blocking call (rk_t5_score / rk_t5_qlm: scores in slot 0) or rk_t5_score_slot, copy that
+ * call's n_floats scores to offset dst_offset of the engine's send buffer (device to device, on the producing stream);
+ * then ONE ncclAllGather of the first n_floats of the send buffer (every rank passes the same n_floats = the largest
+ * share; capacity = rk_comm_init's max_floats_per_rank); rk_comm_read_appended waits and copies out[world][n_floats].
+ * Every rank issues exactly one collective per query, whatever its number of engine calls. */
+int rk_comm_append_scores_slot(rk_engine* e, int slot, int n_floats, int dst_offset);
+int rk_comm_all_gather_appended(rk_engine* e, int n_floats);
+int rk_comm_read_appended(rk_engine* e, float* out, int n_floats_total);
 int rk_comm_destroy(rk_engine* e);
 
 /* ---- measurement (HIP events on the engine's own stream) ---- */

@@ -7,6 +7,7 @@
 // finfo.min padding mask (exp underflows to exactly 0).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 struct AttnEncArgs {
   const half_t* qkv;     // [T, ld]: q at column 0, k at column I, v at column 2I (output of the fused QKV GEMM)
@@ -38,12 +39,15 @@ struct AttnEncArgs {
 // FIRST: tile 0 - no previous maximum, no rescale of the (zero) output accumulators.  bias(r, sub) returns the table
 // entry for register r of s0 (sub = 0) or s1 (sub = 1).
 #define ATT_LOG2E 1.4426950408889634f
-template <bool MASK, bool FIRST, class BiasFn>
+// CHUNKED: the table reads are fenced into groups of four registers (8 values in flight instead of 32) for kernels that
+// run close to their register budget; the arithmetic and the order of every sum are the same.
+template <bool MASK, bool FIRST, class BiasFn, bool CHUNKED = false>
 __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m_run, float& l_run,
                                                   int key_base, int L, BiasFn bias) {
   float tmax = -1e30f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
+    if (CHUNKED && (r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
     s0[r] = fmaf(s0[r], ATT_LOG2E, bias(r, 0));
     s1[r] = fmaf(s1[r], ATT_LOG2E, bias(r, 1));
     if (MASK) {
@@ -53,6 +57,7 @@ __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16
     }
     tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
   }
+  if (CHUNKED) __builtin_amdgcn_sched_barrier(0);
   tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
   const float m_new = FIRST ? tmax : fmaxf(m_run, tmax);
   float psum = 0.f;
@@ -608,6 +613,324 @@ __global__ __launch_bounds__(NG * 384, NG == 1 ? 2 : 3) void attn_enc_pair_kerne
     }
     __syncthreads();   // (1) the rows of step pr are in LDS
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// DMA form of the short-sequence kernel (round 3): the production path for L <= 192.
+// The pair kernel above moved K and V global -> VGPR -> LDS (V through a scalar 16-bit transpose: 16 two-byte LDS stores per
+// lane and head), ran ONE lock-step workgroup per CU with three workgroup barriers per head, and sized its grid so that
+// 320 sequences became 320 workgroups on 256 CUs.  rocprofv3 (profiles/r02d_*): 262 us per launch at 320 x 184 tokens,
+// 8 % MFMA busy, 41 % of the wave cycles waiting, 4.4 M LDS bank-conflict cycles - 29 % of the kernel's HBM floor.  Here
+//   * K and V rows go global -> LDS by DMA (global_load_lds_dwordx4), row-major, no staging registers and no LDS stores;
+//     the bank-conflict swizzles are applied to the per-lane SOURCE address (the DMA image is lane-linear): K chunks by
+//     (row>>1)&7 for the ds_read_b128 A fragments (the GEMM's image), V chunk bit 2 by key bit 1 for the transposing reads;
+//   * V^T fragments come straight out of the row-major image with ds_read_b64_tr_b16 (each 16-lane group reads a
+//     [4 keys][16 d] block and every lane receives one d column of it);
+//   * three row buffers rotate (K_h, V_h, K_h+1): the next head's K lands while this head is computed, V_h is fetched at
+//     the head boundary and awaited after the first key tile's QK^T + softmax with a COUNTED vmcnt - two barriers per
+//     head, neither behind an exposed memory round trip - and 75 KiB of LDS / <= 168 VGPRs put TWO such workgroups on a
+//     CU, whose phases interleave;
+//   * the context rows leave the registers directly: v_permlane32_swap pairs the 8-byte pieces of the two half-waves into
+//     16-byte stores (no LDS staging, no barrier);
+//   * the grid is (heads / heads_per_wg, sequences) with a few heads per workgroup, so 5120 (sequence, head) units
+//     spread evenly over 512 workgroup slots.
+// Per-(sequence, head) arithmetic is attn_tile_softmax's and the MFMA operand order of the kernels above: bit-identical.
+// grid = (ceil(H / heads_per_wg), B), 384 threads, dynamic LDS = ATTD_LDS_BYTES.
+#define ATTD_ROWS 192
+#define ATTD_BUF_HALFS (ATTD_ROWS * 64)
+#define ATTD_LUT_N (2 * ATTD_ROWS)
+#define ATTD_LDS_BYTES (3 * ATTD_BUF_HALFS * 2 + 2 * ATTD_LUT_N * 4)
+typedef __fp16 attd_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef unsigned attd_u32x4 __attribute__((ext_vector_type(4)));
+#define ATTD_SWZ(r) (((((r) >> 1) & 1) << 2) | ((((r) >> 3) & 1) << 1) | (((r) >> 2) & 1))
+
+// the four transposing reads of k16 step G of a key tile (keys 16 G .. 16 G + 16): va = byte addresses of this lane's share
+// for {o0 first key quad, o0 second, o1 first, o1 second} at the tile's first key; see pv_tile
+template <int G>
+__device__ __forceinline__ void attd_issue_vt(half4 (&d)[4], const unsigned (&va)[4]) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d[0]) : "v"(va[0]), "n"(G * 2048));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d[1]) : "v"(va[1]), "n"(G * 2048 + 1024));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d[2]) : "v"(va[2]), "n"(G * 2048));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d[3]) : "v"(va[3]), "n"(G * 2048 + 1024));
+}
+
+#ifndef ATTD_MINW
+#define ATTD_MINW 3
+#endif
+__global__ __launch_bounds__(384, ATTD_MINW) void attn_enc_dma_kernel(AttnEncArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char attd_smem[];
+  half_t* const sbuf = (half_t*)attd_smem;                                  // three [192][64] row images
+  float* const sLut = (float*)(attd_smem + 3 * ATTD_BUF_HALFS * 2);         // two bias tables (this head's / the next one's)
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  const int tok0 = p.seq_off[b];
+  const int L = p.seq_off[b + 1] - tok0;
+  const int H = p.I >> 6;
+  const int h_first = blockIdx.x * p.heads_per_wg;
+  const int nh = min(H, h_first + p.heads_per_wg) - h_first;
+  if (nh <= 0 || L <= 0) return;                                            // uniform for the whole block
+  const int nkt = (L + 63) >> 6, nrows = nkt * 64;
+  const bool dma_wave = 32 * wave < nrows;                                  // this wave's 32 rows exist (wave-uniform)
+  const int q0 = wave * 32;
+  const bool wave_active = q0 < L;
+
+  // Everything a lane derives from its lane number (fragment addresses, DMA source offsets ...) is ~25 registers.  Kept
+  // across the head loop they would not fit beside the softmax at three waves per SIMD, so every head re-derives them from
+  // an opaque copy of the lane number (a dozen integer instructions against ~1200 of softmax).
+  struct LaneCtx {
+    int hh, l31, tid, qpos;
+    unsigned qoff;       // BYTE offset of this lane's part of its query row from the head's column base
+    int lut_idx;         // entry of the head's bias table this thread converts for the next head
+    int lut_q;           // sLut[lut_q + key - 4hh] = bias(key - qpos) * log2(e)
+    int kfo0, vfo0;      // fragment offsets (halfs), see below
+  };
+  auto lane_ctx = [&](int lane) {
+    LaneCtx c;
+    c.hh = lane >> 5; c.l31 = lane & 31; c.tid = wave * 64 + lane; c.qpos = q0 + c.l31;
+    c.qoff = ((unsigned)(tok0 + (c.qpos < L ? c.qpos : L - 1)) * (unsigned)p.ld + 8 * c.hh) * 2u;
+    int li = c.tid - (ATTD_ROWS - 1);                                       // table entry tid <-> key - query = tid - 191
+    c.lut_idx = (li < -RK_LUT_R ? -RK_LUT_R : (li > RK_LUT_R ? RK_LUT_R : li)) + RK_LUT_R;
+    c.lut_q = (ATTD_ROWS - 1) - c.qpos + 4 * c.hh;
+    // K fragment of k16 step s: row l31 (+32, + 64 kt) of the GEMM-style image, chunk (2s + hh) ^ swizzle = chunk0 ^ 2s
+    c.kfo0 = c.l31 * 64 + ((c.hh ^ ATTD_SWZ(c.l31)) << 3);
+    // V: this lane's share of the transposing read - group g = lane>>4 covers d columns 16 (g&1) .. +16 of keys 4 hh .. +4;
+    // lane i16 of the group supplies the address of key i16>>2, columns 4 (i16&3) .. +4.  key = 16 x + 8 sec + 4 hh +
+    // (i16 >> 2): swizzle bit 2 = i16 bit 3, bit 0 = hh, bit 1 = sec (second read of a fragment: ^16 halfs); o1 (d + 32)
+    // is chunk bit 2 flipped (^32 halfs)
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    c.vfo0 = (4 * c.hh + (i16 >> 2)) * 64 + (((2 * g1 + ((i16 & 3) >> 1)) ^ ((((i16 >> 3) & 1) << 2) | c.hh)) << 3) + 4 * (i16 & 1);
+    return c;
+  };
+  // DMA piece i of this wave fills LDS slots (4 wave + i) * 64 + lane: row r = slot >> 3, 16-B chunk c = slot & 7 (lane-
+  // linear image); the global chunk it fetches is c ^ swizzle(r).
+  // One swizzle serves both images: chunk ^= f(r), f = (r bit 1) << 2 | (r bit 3) << 1 | (r bit 2).  Over any 16
+  // consecutive rows f takes each value twice (rows 2j, 2j+1, which sit in different halves of a 256-B bank row): the
+  // ds_read_b128 K fragments are conflict-free like the GEMM's; and bit 2 follows key bit 1, so the four key rows of a
+  // transposing V read occupy the four 64-B quarters of the bank row.
+  auto issue_rows = [&](int lane, int which, int buf, int h) {   // which: 1 = K columns, 2 = V columns of the fused qkv rows
+    const char* hb = (const char*)(p.qkv + which * p.I + h * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int slot = (4 * wave + i) * 64 + lane, r = slot >> 3, c = slot & 7;
+      const unsigned off = ((unsigned)(tok0 + (r < L ? r : L - 1)) * (unsigned)p.ld + ((c ^ ATTD_SWZ(r)) << 3)) * 2u;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hb + off),
+                                       (__attribute__((address_space(3))) void*)(sbuf + buf * ATTD_BUF_HALFS + (4 * wave + i) * 512),
+                                       16, 0, 0);
+    }
+  };
+
+  half8 qf[4];
+  float lutreg, qwarm;
+  // The Q rows and the table entry of the NEXT head travel through inline asm (invisible to the waitcnt pass, which would
+  // otherwise drain the DMA queue at their first use): unconditional, issued and awaited in the same loop iteration, and
+  // the wait's "+v" operands order every use behind it (the rules of the pair kernel above; tests/test_isa_guards.py).
+  // Sixteen more live registers do not fit beside the softmax at three waves per SIMD, so the Q fragments are loaded
+  // straight into qf once the head's last QK^T is done; what is issued a head ahead is one dword per row (qwarm) that
+  // pulls the row's 128-byte line into L2, so that the real loads are short.
+  auto issue_warm = [&](const LaneCtx& c, int h) {
+    const char* hb = (const char*)(p.qkv + h * 64);
+    asm volatile("global_load_dword %0, %1, %2" : "=&v"(qwarm) : "v"(c.qoff), "s"(hb) : "memory");
+    const float* lb = p.bias_lut + h * RK_LUT_N;
+    asm volatile("global_load_dword %0, %1, %2" : "=&v"(lutreg) : "v"(c.lut_idx * 4), "s"(lb) : "memory");
+  };
+  auto issue_q = [&](const LaneCtx& c, int h) {
+    const char* hb = (const char*)(p.qkv + h * 64);
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(qf[0]) : "v"(c.qoff), "s"(hb) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=&v"(qf[1]) : "v"(c.qoff), "s"(hb) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=&v"(qf[2]) : "v"(c.qoff), "s"(hb) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:96" : "=&v"(qf[3]) : "v"(c.qoff), "s"(hb) : "memory");
+  };
+  auto wait_q = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(lutreg), "+v"(qwarm) :: "memory");
+  };
+
+  f32x16 o0, o1;
+  float m_run, l_run;
+  auto qk_tile = [&](const LaneCtx& c, const half_t* kbuf, int kt, f32x16& s0, f32x16& s1) {
+    const half_t* kb_ = kbuf + kt * 64 * 64 + c.kfo0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const half8 k0 = *(const half8*)(kb_ + ((c.kfo0 ^ (s << 4)) - c.kfo0));
+      const half8 k1 = *(const half8*)(kb_ + 32 * 64 + ((c.kfo0 ^ (s << 4)) - c.kfo0));
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+    }
+  };
+  auto sm_tile = [&](const LaneCtx& c, const float* lut, int kt, f32x16& s0, f32x16& s1) {
+    const int key_base = kt * 64 + 4 * c.hh;
+    const float* lq = lut + c.lut_q + kt * 64;
+    auto bias = [&](int r, int sub) { return lq[(r & 3) + 8 * (r >> 2) + 32 * sub]; };
+    const bool last = kt == nkt - 1;
+    using BF = decltype(bias);
+    if (kt == 0) {
+      if (last) attn_tile_softmax<true, true, BF, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+      else attn_tile_softmax<false, true, BF, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+    } else {
+      if (last) attn_tile_softmax<true, false, BF, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+      else attn_tile_softmax<false, false, BF, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
+    }
+  };
+  // P V of one key tile.  The V^T fragments are read with inline-asm ds_read_b64_tr_b16 (the builtin form makes the waitcnt
+  // pass drain the whole DMA queue - vmcnt(0) - in front of the first read: it cannot tell the K rows still in flight for
+  // the next head from the V rows being read).  Four reads (one k16 step: first / second key quad for o0 and o1) are
+  // issued one step ahead of the MFMAs that consume them; LDS operations return in order, so lgkmcnt(4) retires the
+  // older four.  The sched_barriers around the tile keep compiler-issued LDS reads out of the counted span.
+  auto pv_tile = [&](auto firstc, const LaneCtx& c, const half_t* vbuf, int kt, const f32x16& s0, const f32x16& s1) {
+    constexpr bool FIRST_TILE = decltype(firstc)::value;   // key tile 0: the accumulators start from zero (C = 0 in the first MFMAs)
+    const unsigned vb0 = (unsigned)(size_t)(const __attribute__((address_space(3))) half_t*)(vbuf + kt * 64 * 64) ;
+    unsigned va[4];                                        // byte addresses: o0 first / second key quad, o1 first / second
+#pragma unroll
+    for (int i = 0; i < 4; ++i) va[i] = vb0 + 2u * (unsigned)(c.vfo0 ^ (16 * i));
+    half4 v[2][4];
+    auto step = [&](auto gc, half4 (&d)[4]) {
+      constexpr int g = decltype(gc)::value, sub = g >> 1, sp = g & 1;
+      half8 pf;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pf[i] = (half_t)(sub == 0 ? s0[8 * sp + i] : s1[8 * sp + i]);
+      if constexpr (g < 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+      __builtin_amdgcn_sched_barrier(0);
+      const half8 vf0 = {d[0][0], d[0][1], d[0][2], d[0][3], d[1][0], d[1][1], d[1][2], d[1][3]};
+      const half8 vf1 = {d[2][0], d[2][1], d[2][2], d[2][3], d[3][0], d[3][1], d[3][2], d[3][3]};
+      if constexpr (FIRST_TILE && g == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf0, pf, z, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf1, pf, z, 0, 0, 0);
+      } else {
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf0, pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf1, pf, o1, 0, 0, 0);
+      }
+    };
+    using std::integral_constant;
+    attd_issue_vt<0>(v[0], va);
+    attd_issue_vt<1>(v[1], va);
+    step(integral_constant<int, 0>{}, v[0]);
+    attd_issue_vt<2>(v[0], va);
+    step(integral_constant<int, 1>{}, v[1]);
+    attd_issue_vt<3>(v[1], va);
+    step(integral_constant<int, 2>{}, v[0]);
+    step(integral_constant<int, 3>{}, v[1]);
+  };
+  auto opaque_lane = [&]() {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    return lane;
+  };
+
+  // ---- prologue: K rows, Q rows and table of the first head -------------------------------------------------------
+  {
+    const int lane = opaque_lane();
+    const LaneCtx c = lane_ctx(lane);
+    if (dma_wave) issue_rows(lane, 1, 0, h_first);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_warm(c, h_first);
+    issue_q(c, h_first);
+    wait_q();
+    sLut[c.tid] = lutreg * ATT_LOG2E;
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the table entry is written
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  int kb = 0, vb = 1, nb = 2;                             // buffers of K_h, V_h, K_h+1
+  auto head = [&](auto lastc, int n) {
+    constexpr bool LAST = decltype(lastc)::value;
+    const int h = h_first + n;
+    const int lane = opaque_lane();
+    const LaneCtx c = lane_ctx(lane);
+    const half_t* kbuf = sbuf + kb * ATTD_BUF_HALFS;
+    const half_t* vbuf = sbuf + vb * ATTD_BUF_HALFS;
+    const float* lut = sLut + (n & 1) * ATTD_LUT_N;
+    // everyone is past the barrier that ended head h-1: its K and V buffers are free
+    if (dma_wave) issue_rows(lane, 2, vb, h);
+    if constexpr (!LAST) {
+      if (dma_wave) issue_rows(lane, 1, nb, h + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_warm(c, h + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 s0, s1;
+    if (wave_active) {
+      qk_tile(c, kbuf, 0, s0, s1);
+      __builtin_amdgcn_sched_barrier(0);
+      sm_tile(c, lut, 0, s0, s1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // V_h: this wave's four DMA instructions are the oldest loads in flight (behind them: 4 K rows + the line touch + the
+    // table entry of the next head; the context stores of the previous head are older but at most 4, and can only make
+    // the wait stricter)
+    if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_active) {
+      pv_tile(std::integral_constant<bool, true>{}, c, vbuf, 0, s0, s1);
+      __builtin_amdgcn_sched_barrier(0);
+      for (int kt = 1; kt < nkt; ++kt) {
+        qk_tile(c, kbuf, kt, s0, s1);
+        __builtin_amdgcn_sched_barrier(0);
+        sm_tile(c, lut, kt, s0, s1);
+        __builtin_amdgcn_sched_barrier(0);
+        pv_tile(std::integral_constant<bool, false>{}, c, vbuf, kt, s0, s1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!LAST) issue_q(c, h + 1);               // the head's last QK^T is done: qf is free (every wave, active or not)
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned pk[2][8];                                    // the context row pieces of this lane as packed halfs
+    if (wave_active) {
+      const float inv = 1.0f / l_run;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        half4 a, cc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = f2h_sat(o0[4 * q + j] * inv); cc[j] = f2h_sat(o1[4 * q + j] * inv); }
+        const auto au = __builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, a);
+        const auto cu = __builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, cc);
+        pk[0][2 * q] = au[0]; pk[0][2 * q + 1] = au[1];
+        pk[1][2 * q] = cu[0]; pk[1][2 * q + 1] = cu[1];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!LAST) {
+      wait_q();                                           // K_h+1 (DMA) and the table entry landed long ago; Q_h+1 from L2
+      sLut[((n + 1) & 1) * ATTD_LUT_N + c.tid] = lutreg * ATT_LOG2E;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave_active) {
+      // piece q of o0 holds d = 8 q + 4 hh .. +4.  Swapping (piece 0 | hh=1) <-> (piece 2 | hh=0) and (1 | 1) <-> (3 | 0)
+      // leaves d = 16 hh .. 16 hh + 16 contiguous in this lane: two 16-byte stores per 32-column half
+      half_t* dst = p.ctx + (size_t)(tok0 + (c.qpos < L ? c.qpos : L - 1)) * p.ldctx + h * 64 + 16 * c.hh;
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const auto x0 = __builtin_amdgcn_permlane32_swap(pk[o][0], pk[o][4], false, false);
+        const auto x1 = __builtin_amdgcn_permlane32_swap(pk[o][1], pk[o][5], false, false);
+        const auto y0 = __builtin_amdgcn_permlane32_swap(pk[o][2], pk[o][6], false, false);
+        const auto y1 = __builtin_amdgcn_permlane32_swap(pk[o][3], pk[o][7], false, false);
+        const attd_u32x4 lo = {x0[0], x1[0], x0[1], x1[1]};
+        const attd_u32x4 hi = {y0[0], y1[0], y0[1], y1[1]};
+        if (c.qpos < L) {
+          *(attd_u32x4*)(dst + 32 * o) = lo;
+          *(attd_u32x4*)(dst + 32 * o + 8) = hi;
+        }
+      }
+    }
+    if constexpr (!LAST) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): table written, every LDS read of this head retired
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const int t = kb; kb = nb; nb = vb; vb = t;         // K_h+1 becomes K; V_h+1 goes where K_h was; K_h+2 where V_h was
+    }
+  };
+  for (int n = 0; n + 1 < nh; ++n) head(std::integral_constant<bool, false>{}, n);
+  head(std::integral_constant<bool, true>{}, nh - 1);
 }
 
 // Decoder attention (self: causal + unidirectional bias; cross: zero bias, keys = encoder states of the same

@@ -105,7 +105,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 1, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1;
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
@@ -122,6 +122,9 @@ struct rk_engine {
   ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;
   float* d_gather[RK_SLOTS] = {nullptr}; float* h_gather[RK_SLOTS] = {nullptr}; size_t gather_cap = 0;
   hipEvent_t ev_gather[RK_SLOTS] = {nullptr}; bool gather_pending[RK_SLOTS] = {false}; int gather_n[RK_SLOTS] = {0};
+  // appended form (a rank's share scored in several engine calls): send buffer [gather_cap], result [world][gather_cap]
+  float *d_gsend = nullptr, *d_gall = nullptr, *h_gall = nullptr;
+  hipEvent_t ev_gall = nullptr, ev_append = nullptr; bool gall_pending = false, append_foreign = false; int gall_n = 0;
 };
 
 namespace {
@@ -475,8 +478,7 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
     {
       // L <= 192: pair kernel - a workgroup runs two heads of a sequence side by side and walks `ppw` head pairs, sized so
       // that the launch has at least one workgroup per CU; the per-(sequence, head) arithmetic does not depend on it.
-      // opt_attn_short: 1 = 4-wave short kernel, 2 = 6-wave short kernel, 3 = pair kernel, 0 = tiled kernel (bit-identical)
-      // opt_attn_short: 1 = pipelined kernel, one head at a time per workgroup; 3 = two heads side by side; 2 / 4 = plain
+      // opt_attn_short: 5 = DMA-staged kernel (default); 1 = register-prefetch pair kernel (round 2's default); 2 / 4 = plain
       // short kernels with 6 / 4 waves; 0 = tiled kernel.  All bit-identical.
       const int NG = 1;   // (a two-heads-side-by-side form, 12 waves, measured slower: 168-VGPR cap -> spills; not instantiated)
       const int npairs = (d.n_heads + NG - 1) / NG;
@@ -486,7 +488,16 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
       AttnEncArgs a{sl.qkv, sl.ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I, ppw, e->opt_attn_ko};
       const double att_flops = 4.0 * (double)sl.maxL * T * I;   // exact for uniform lengths, upper bound if ragged
       Bracket br(e, st, PC_ENC_ATTN, att_flops, (double)T * 4 * I * 2.0);
-      if (sl.maxL <= ATTS_MAXL && e->opt_attn_short == 1) {
+      if (sl.maxL <= ATTS_MAXL && e->opt_attn_short == 5) {
+        static std::atomic<uint64_t> attr_done{0};
+        ensure_dynamic_lds((const void*)attn_enc_dma_kernel, ATTD_LDS_BYTES, attr_done);
+        // heads per workgroup: 4 amortise a workgroup's pipeline fill best (159 us per launch at 320 x 184 tokens against 172
+        // at 2 and 195 at 1); fewer when that would leave some of the 2 x 256 workgroup slots of the chip empty
+        int hpw = 4;
+        while (hpw > 1 && (long)sl.n_seq * ((d.n_heads + hpw - 1) / hpw) < 2L * e->n_cu) hpw >>= 1;
+        a.heads_per_wg = e->opt_attn_heads_per_wg > 0 ? e->opt_attn_heads_per_wg : hpw;
+        hipLaunchKernelGGL(attn_enc_dma_kernel, dim3((d.n_heads + a.heads_per_wg - 1) / a.heads_per_wg, sl.n_seq), dim3(384), ATTD_LDS_BYTES, st, a);
+      } else if (sl.maxL <= ATTS_MAXL && e->opt_attn_short == 1) {
         hipLaunchKernelGGL(attn_enc_pair_kernel<1>, dim3((npairs + ppw - 1) / ppw, sl.n_seq), dim3(384), ATTP_GROUP_LDS, st, a);
       } else if (sl.maxL <= ATTS_MAXL && e->opt_attn_short == 2) {
         a.heads_per_wg = 1;
@@ -849,6 +860,12 @@ void comm_release(rk_engine* e) {
     if (e->ev_gather[i]) { hipEventDestroy(e->ev_gather[i]); e->ev_gather[i] = nullptr; }
     e->gather_pending[i] = false;
   }
+  if (e->d_gsend) { hipFree(e->d_gsend); e->d_gsend = nullptr; }
+  if (e->d_gall) { hipFree(e->d_gall); e->d_gall = nullptr; }
+  if (e->h_gall) { hipHostFree(e->h_gall); e->h_gall = nullptr; }
+  if (e->ev_gall) { hipEventDestroy(e->ev_gall); e->ev_gall = nullptr; }
+  if (e->ev_append) { hipEventDestroy(e->ev_append); e->ev_append = nullptr; }
+  e->gall_pending = false; e->append_foreign = false; e->gall_n = 0;
   e->gather_cap = 0; e->comm_world = 1; e->comm_rank = 0;
 }
 
@@ -1655,7 +1672,6 @@ int rk_comm_unique_id(uint8_t* out_id, int n_bytes) {
 int rk_comm_init(rk_engine* e, const uint8_t* id_bytes, int n_bytes, int rank, int world, int max_floats_per_rank) {
   if (!e || !id_bytes || n_bytes != RK_COMM_ID_BYTES) return fail(e, RK_ERR_INVALID, "bad unique id");
   if (world < 1 || rank < 0 || rank >= world || max_floats_per_rank <= 0) return fail(e, RK_ERR_INVALID, "bad rank %d / world %d / capacity %d", rank, world, max_floats_per_rank);
-  if ((size_t)max_floats_per_rank > e->scores_cap) return fail(e, RK_ERR_CAPACITY, "%d floats per rank exceed the score buffer (%zu)", max_floats_per_rank, e->scores_cap);
   if (!e->finalized) return fail(e, RK_ERR_STATE, "engine not finalized");
   int rc = set_device(e);
   if (rc) return rc;
@@ -1672,6 +1688,12 @@ int rk_comm_init(rk_engine* e, const uint8_t* id_bytes, int n_bytes, int rank, i
     HIPCHK(e, hipHostMalloc((void**)&e->h_gather[i], e->gather_cap * world * sizeof(float), hipHostMallocDefault));
     HIPCHK(e, hipEventCreateWithFlags(&e->ev_gather[i], hipEventDisableTiming));
   }
+  HIPCHK(e, hipMalloc((void**)&e->d_gsend, e->gather_cap * sizeof(float)));
+  HIPCHK(e, hipMemset(e->d_gsend, 0, e->gather_cap * sizeof(float)));
+  HIPCHK(e, hipMalloc((void**)&e->d_gall, e->gather_cap * world * sizeof(float)));
+  HIPCHK(e, hipHostMalloc((void**)&e->h_gall, e->gather_cap * world * sizeof(float), hipHostMallocDefault));
+  HIPCHK(e, hipEventCreateWithFlags(&e->ev_gall, hipEventDisableTiming));
+  HIPCHK(e, hipEventCreateWithFlags(&e->ev_append, hipEventDisableTiming));
   return RK_OK;
 }
 
@@ -1685,7 +1707,7 @@ int rk_comm_world(const rk_engine* e, int* out_rank, int* out_world) {
 int rk_comm_all_gather_slot(rk_engine* e, int slot, int n_floats) {
   if (!e || slot < 0 || slot >= RK_SLOTS) return RK_ERR_INVALID;
   if (!e->comm) return fail(e, RK_ERR_STATE, "rk_comm_init has not been called");
-  if (n_floats <= 0 || (size_t)n_floats > e->gather_cap) return fail(e, RK_ERR_CAPACITY, "n_floats %d out of range (capacity %zu)", n_floats, e->gather_cap);
+  if (n_floats <= 0 || (size_t)n_floats > e->gather_cap || (size_t)n_floats > e->scores_cap) return fail(e, RK_ERR_CAPACITY, "n_floats %d out of range (capacity %zu, score buffer %zu)", n_floats, e->gather_cap, e->scores_cap);
   int rc = set_device(e);
   if (rc) return rc;
   Slot& sl = e->slots[slot];
@@ -1705,6 +1727,52 @@ int rk_comm_read_gathered_slot(rk_engine* e, int slot, float* out, int n_floats_
   if (n_floats_total != e->gather_n[slot] * e->comm_world) return fail(e, RK_ERR_INVALID, "asked for %d floats, the last gather of slot %d holds %d", n_floats_total, slot, e->gather_n[slot] * e->comm_world);
   if (e->gather_pending[slot]) { HIPCHK(e, hipEventSynchronize(e->ev_gather[slot])); e->gather_pending[slot] = false; }
   memcpy(out, e->h_gather[slot], (size_t)n_floats_total * sizeof(float));
+  return RK_OK;
+}
+
+// Appended form: a rank whose share of a query's candidates needs several engine calls (more sequences or tokens than one
+// call holds) copies each call's scores behind the ones before - device to device, on the stream that produced them - and
+// ONE all_gather ships the whole share.  Every rank issues exactly one collective per query whatever its chunk count.
+int rk_comm_append_scores_slot(rk_engine* e, int slot, int n_floats, int dst_offset) {
+  if (!e || slot < 0 || slot >= RK_SLOTS) return RK_ERR_INVALID;
+  if (!e->comm) return fail(e, RK_ERR_STATE, "rk_comm_init has not been called");
+  if (n_floats < 0 || dst_offset < 0 || (size_t)n_floats + (size_t)dst_offset > e->gather_cap || (size_t)n_floats > e->scores_cap)
+    return fail(e, RK_ERR_CAPACITY, "append of %d floats at %d exceeds the send buffer (%zu) or the score buffer (%zu)", n_floats, dst_offset, e->gather_cap, e->scores_cap);
+  int rc = set_device(e);
+  if (rc) return rc;
+  if (n_floats == 0) return RK_OK;
+  Slot& sl = e->slots[slot];
+  hipStream_t sd = dec_stream(e, sl);
+  // the previous gather still reads the send buffer until its event has passed
+  if (e->gall_pending) { HIPCHK(e, hipEventSynchronize(e->ev_gall)); e->gall_pending = false; }
+  HIPCHK(e, hipMemcpyAsync(e->d_gsend + dst_offset, sl.d_scores, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToDevice, sd));
+  if (sd != dec_stream(e, e->slots[0])) { HIPCHK(e, hipEventRecord(e->ev_append, sd)); e->append_foreign = true; }
+  return mark_decoder_done(e, sl);      // the slot's score buffer stays busy until the copy has read it
+}
+
+int rk_comm_all_gather_appended(rk_engine* e, int n_floats) {
+  if (!e) return RK_ERR_INVALID;
+  if (!e->comm) return fail(e, RK_ERR_STATE, "rk_comm_init has not been called");
+  if (n_floats <= 0 || (size_t)n_floats > e->gather_cap) return fail(e, RK_ERR_CAPACITY, "n_floats %d out of range (capacity %zu)", n_floats, e->gather_cap);
+  int rc = set_device(e);
+  if (rc) return rc;
+  hipStream_t s0 = dec_stream(e, e->slots[0]);
+  if (e->gall_pending) { HIPCHK(e, hipEventSynchronize(e->ev_gall)); e->gall_pending = false; }
+  if (e->append_foreign) { HIPCHK(e, hipStreamWaitEvent(s0, e->ev_append, 0)); e->append_foreign = false; }
+  const ncclResult_t nrc = rccl_api()->AllGather(e->d_gsend, e->d_gall, (size_t)n_floats, ncclFloat, e->comm, s0);
+  if (nrc != ncclSuccess) return fail(e, RK_ERR_HIP, "ncclAllGather: %s", rccl_api()->GetErrorString(nrc));
+  HIPCHK(e, hipMemcpyAsync(e->h_gall, e->d_gall, (size_t)n_floats * e->comm_world * sizeof(float), hipMemcpyDeviceToHost, s0));
+  HIPCHK(e, hipEventRecord(e->ev_gall, s0));
+  e->gall_pending = true; e->gall_n = n_floats;
+  return RK_OK;
+}
+
+int rk_comm_read_appended(rk_engine* e, float* out, int n_floats_total) {
+  if (!e || !out) return RK_ERR_INVALID;
+  if (!e->comm) return fail(e, RK_ERR_STATE, "rk_comm_init has not been called");
+  if (n_floats_total != e->gall_n * e->comm_world) return fail(e, RK_ERR_INVALID, "asked for %d floats, the last appended gather holds %d", n_floats_total, e->gall_n * e->comm_world);
+  if (e->gall_pending) { HIPCHK(e, hipEventSynchronize(e->ev_gall)); e->gall_pending = false; }
+  memcpy(out, e->h_gall, (size_t)n_floats_total * sizeof(float));
   return RK_OK;
 }
 
@@ -1795,7 +1863,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
 #endif
   if (!strcmp(key, "attn_heads_per_wg")) { e->opt_attn_heads_per_wg = value; return RK_OK; }   // 0 auto
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
-  if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 1 pair kernel, 2 one-head kernel, 0 tiled
+  if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 5 DMA kernel, 1 pair kernel, 2 / 4 plain short kernels, 0 tiled
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
     if (set_device(e) || sync_all(e)) return RK_ERR_HIP;

@@ -66,6 +66,9 @@ ABI = {
     "rk_comm_world": (C.c_int, [C.c_void_p, _i32p, _i32p]),
     "rk_comm_all_gather_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rk_comm_read_gathered_slot": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.c_int]),
+    "rk_comm_append_scores_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "rk_comm_all_gather_appended": (C.c_int, [C.c_void_p, C.c_int]),
+    "rk_comm_read_appended": (C.c_int, [C.c_void_p, _f32p, C.c_int]),
     "rk_comm_destroy": (C.c_int, [C.c_void_p]),
     "rk_timer_begin": (C.c_int, [C.c_void_p]),
     "rk_timer_end": (C.c_int, [C.c_void_p, _f32p]),
@@ -279,6 +282,17 @@ class RkEngine:
         n = self._gather_n[slot]
         out = np.empty((self.comm_world, n), dtype=np.float32)
         self._chk(self.lib.rk_comm_read_gathered_slot(self.h, slot, out.ctypes.data_as(_f32p), out.size))
+        return out
+
+    def comm_append(self, n_floats: int, offset: int, slot: int = 0):
+        """Copy the slot's last n_floats scores to `offset` of the engine's send buffer (device to device, no sync)."""
+        self._chk(self.lib.rk_comm_append_scores_slot(self.h, slot, n_floats, offset))
+
+    def comm_all_gather_appended(self, n_floats: int) -> np.ndarray:
+        """ONE RCCL all_gather of the first n_floats of the send buffer -> [world, n_floats] float32 (waits for it)."""
+        self._chk(self.lib.rk_comm_all_gather_appended(self.h, n_floats))
+        out = np.empty((self.comm_world, n_floats), dtype=np.float32)
+        self._chk(self.lib.rk_comm_read_appended(self.h, out.ctypes.data_as(_f32p), out.size))
         return out
 
     def comm_destroy(self):

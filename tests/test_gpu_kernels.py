@@ -265,9 +265,14 @@ def test_flan_t5_large_dims_vs_oracle_and_properties():
     np.testing.assert_array_equal(v6, full[:8])          # 64x64 small-M tiles: and again
     np.testing.assert_array_equal(v1_regs, v1_glds)      # DMA and register staging run the same arithmetic
     np.testing.assert_array_equal(v1_glds, full)         # ... and so do all tile shapes (same K order per output)
-    eng.set_option("attn_short", 0)                      # tiled attention kernel instead of the whole-KV-in-LDS one
-    np.testing.assert_array_equal(eng.score(batch, [0], ids), full)
-    eng.set_option("attn_short", 1)
+    for mode in (0, 1, 2):                               # tiled / register-prefetch pair / plain short kernel instead of the DMA one
+        eng.set_option("attn_short", mode)
+        np.testing.assert_array_equal(eng.score(batch, [0], ids), full)
+    eng.set_option("attn_short", 5)
+    for hpw in (1, 2, 16):                               # heads per workgroup of the DMA kernel: same bits
+        eng.set_option("attn_heads_per_wg", hpw)
+        np.testing.assert_array_equal(eng.score(batch, [0], ids), full)
+    eng.set_option("attn_heads_per_wg", 0)
     # cross-attention: query-side form (default for <= 32 decoder rows) vs materialised K/V projections — same math,
     # different rounding points
     eng.set_option("xattn_direct", 0)
@@ -277,6 +282,36 @@ def test_flan_t5_large_dims_vs_oracle_and_properties():
     assert np.abs(_sigm(kv_path[:, 0] - kv_path[:, 1]) - _sigm(full[:, 0] - full[:, 1])).max() < SCORE_TOL
     assert np.abs(_sigm(kv_ragged[:, 0] - kv_ragged[:, 1]) - p_want).max() < SCORE_TOL
     eng.close()
+
+
+def test_encoder_attention_kernels_bit_identical_on_ragged_batches():
+    """Every encoder attention kernel (DMA-staged default, register-prefetch pair, plain short, tiled) writes the same
+    context rows for ragged lengths around the tile edges (1, 64, 65, 128, 129, 191, 192 ...), whatever the number of heads a
+    workgroup of the DMA kernel walks - a sequence's bits must not depend on the kernel its batch selects."""
+    from llmrankers import _synth
+    for dims, lens in ((_synth.TOY_GATED_UNTIED, [109, 5, 64, 192, 130, 1, 65, 128, 184, 191, 2, 33, 129]),
+                       (_synth.FLAN_T5_SMALL, [184, 20, 77, 192, 65, 129, 96, 1, 184, 127])):
+        state = _synth.synth_state_dict(dims, 3, gain=2.0)
+        eng = _engine(dims, state, max_tokens=4096, max_seqs=32, max_dec_len=4)
+        rs = np.random.RandomState(1)
+        seqs = [rs.randint(2, dims.vocab, size=n).tolist() for n in lens]
+        T, I = sum(lens), dims.n_heads * dims.d_kv
+
+        def ctx():
+            eng.score(seqs, [0], [3, 4])
+            return eng.debug_read("ctx", T * I).copy()
+        eng.set_option("attn_short", 2)
+        ref = ctx()
+        assert np.isfinite(ref).all()
+        for mode in (0, 1, 4):
+            eng.set_option("attn_short", mode)
+            np.testing.assert_array_equal(ctx(), ref, err_msg=f"attn_short={mode}")
+        eng.set_option("attn_short", 5)
+        for hpw in (0, 1, 2, 3, 16):
+            eng.set_option("attn_heads_per_wg", hpw)
+            np.testing.assert_array_equal(ctx(), ref, err_msg=f"DMA kernel, heads_per_wg={hpw}")
+        eng.set_option("attn_heads_per_wg", 0)
+        eng.close()
 
 
 def test_capacity_and_argument_errors(toy):

@@ -65,6 +65,35 @@ def test_attention_prefetch_registers_untouched_until_the_wait(isa):
     assert not any("scratch_" in l for l in body), "attention kernel spills"
 
 
+def test_dma_attention_keeps_its_dma_queue_and_its_asm_destinations(isa):
+    """attn_enc_dma_kernel: K/V rows travel by LDS-DMA across barriers and Q rows / table entries by inline-asm loads.  The
+    only vmcnt waits may be the kernel's own (inside ASM blocks) - a compiler-placed one means the waitcnt pass saw a
+    tracked load or a scratch access and drains the DMA queue; no spills; no register written by an asm load is touched
+    between its issue and the asm wait that follows it."""
+    body = kernel_body(isa, "_Z19attn_enc_dma_kernel11AttnEncArgs")
+    assert not any("scratch_" in l for l in body), "DMA attention kernel spills"
+    assert sum("global_load_lds_dwordx4" in l for l in body) == 16      # prologue K + {V, next K} + last head's V
+    assert sum("ds_read_b64_tr_b16" in l for l in body) == 64
+    pending, n_waits = set(), 0
+    for i, l in enumerate(body):
+        in_asm = i > 0 and "ASMSTART" in body[i - 1]
+        code = l.split(";")[0]
+        if "vmcnt" in code:
+            assert in_asm, f"compiler-placed vmcnt wait in the DMA attention kernel: {l.strip()}"
+            if re.search(r"vmcnt\(0\)", code):
+                pending.clear()
+            n_waits += 1
+            continue
+        m = re.match(r"\s*global_load_dword(?:x4)?\s+(v\[\d+:\d+\]|v\d+),", code)
+        if m and in_asm:
+            pending |= vregs(m.group(1))
+            continue
+        if not code.strip() or code.strip().startswith(".") or "ASM" in l:
+            continue
+        assert not (vregs(code) & pending), f"asm load destination touched before its wait: {l.strip()}"
+    assert n_waits >= 4
+
+
 # (epilogue kind, folded-RMSNorm row factors): every product instantiation of the ping-pong kernel
 @pytest.mark.parametrize("epi,rs", [(0, 0), (0, 1), (1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (4, 0)])
 def test_pingpong_gemm_k_loop_keeps_loads_in_flight(isa, epi, rs):

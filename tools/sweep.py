@@ -32,7 +32,7 @@ def main():
     eng = RkEngine(dims, device=0, max_tokens=max(8192, gmax * B * L), max_seqs=max(128, gmax * B), max_dec_len=4)
     eng.load_state(state.items())
     del state
-    known = {"gemm_persistent": 1, "attn_short": 1, "gemm_variant": 0,
+    known = {"gemm_persistent": 1, "attn_short": 5, "gemm_variant": 0,
              "xattn_direct": 1, "overlap": 1, "gemm_glds": 1, "attn_heads_per_wg": 0, "fold_norm": 1, "dec_graph": 1, "attn_tiled_occ": 2,
              "dec_fold_norm": 1, "gemm_s64_stages": 0, "attn_split": 1, "greedy_spec": 160}
     defaults = {}
