@@ -17,6 +17,15 @@ ENGINE itself (rk_comm_all_gather_slot: straight from the device score buffer, o
 torch.distributed ('gloo') only carries the host-side control plane: the RCCL id, the barrier, the max over ranks.
 value = passages all ranks scored / max-over-ranks time.
 
+`--mode shard` is the other multi-GPU mode north_star names: ONE query's candidate list (hits=100) is cut into contiguous
+shares over the ranks (13,13,13,13,12,12,12,12 at 8 GPUs), every rank scores its share and ONE engine-issued all_gather per
+query collects the scores; a step is then one QUERY, value = 100 x steps / time ("scaling": "strong" - the work per step is
+fixed as N grows), and after the timed region every rank re-scores the whole query locally and asserts that the gathered
+scores are bit-identical.  Latency-bound by design (M = 12-13 passages per GPU); the weak mode is the throughput mode.
+
+The timed region is repeated `--regions` times (default 3, each exactly --steps steps between fences, max over ranks) and the
+MEDIAN region is reported; all of them are listed in config.timed_regions_ms.
+
 Extra objects on the JSON line: `roofline` (the dominant kernel — the FFN-in + GEGLU GEMM — MFMA-bound: algorithmic
 2MNK flops per launch / average launch duration measured with HIP events on the engine's stream in a second, serial,
 profiled pass; the whole tiled-GEMM family beside it), `cpu_baseline` (the reference's CPU path — HF transformers
@@ -73,6 +82,12 @@ def parse_args():
     ap.add_argument("--glds", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1, help="1: decoder chain of step i overlaps encoder of step i+1 (two HIP streams)")
     ap.add_argument("--group", type=int, default=0, help="batches (steps) per engine launch sequence; 0 = auto (see auto_group)")
+    ap.add_argument("--mode", default="weak", choices=["weak", "shard"],
+                    help="weak: every rank scores its own batches (throughput); shard: one query's hits=100 candidates cut over the ranks, one gather per query")
+    ap.add_argument("--hits", type=int, default=100, help="shard mode: candidates per query")
+    ap.add_argument("--regions", type=int, default=3, help="timed regions of exactly --steps steps each; the median is reported")
+    ap.add_argument("--no_extras", action="store_true", help="skip the ragged (S2) and setwise (S3) legs after the timed region")
+    ap.add_argument("--cpu_batch", type=int, default=32, help="batch size of the cpu_baseline leg (BASELINE.md section 3: 32)")
     return ap.parse_args()
 
 
@@ -140,6 +155,68 @@ def timed_run(eng, pipe, steps, warmup, fence):
     ev_ms = eng.timer_end()                                    # HIP events on the engine's own streams
     fence()
     return time.perf_counter() - t_start, ev_ms
+
+
+class ShardPipeline:
+    """--mode shard: a step is one QUERY of `hits` candidates.  This rank's contiguous share of query q (llmrankers/_dist.py:
+    shard_bounds) is resident in slot q % n_slots; a step enqueues encoder + decoder + head for the share and, with more than
+    one rank, ONE all_gather of the slot's score buffer (share width x 2 label rows) behind them.  Slots alternate, so the
+    decoder chain and the gather of query i overlap the encoder of query i+1."""
+
+    def __init__(self, eng, slot_seqs, dec, out_ids, world, width):
+        self.eng, self.slot_seqs, self.dec, self.out_ids, self.world, self.width = eng, slot_seqs, dec, out_ids, world, width
+        self.n_slots = len(slot_seqs)
+        self.i = 0
+        self.last_slot = None
+
+    def stage_all(self):
+        for s in range(self.n_slots):
+            self.eng.stage(self.slot_seqs[s], slot=s)
+
+    def run(self, steps):
+        for _ in range(steps):
+            slot = self.i % self.n_slots
+            self.i += 1
+            self.eng.score_staged(self.dec, self.out_ids, slot=slot)
+            if self.world > 1:
+                self.eng.comm_all_gather(self.width * len(self.out_ids), slot=slot)
+            self.last_slot = slot
+
+
+def ragged_leg(eng, dims, B, G, n_slots):
+    """lengths ~ U{96..184} (seed 930), same grouped pipeline; passages/s, tokens/s and the fraction of the MFMA
+    peak by the algorithmic FLOPs of the actual lengths."""
+    from llmrankers import _synth
+    slot_seqs = [[s for j in range(G) for s in _synth.synth_token_batch(B, 96, 184, dims.vocab, seed=930 + 8 * sl + j)]
+                 for sl in range(n_slots)]
+    pipe = GroupPipeline(eng, slot_seqs, B, G, [0], [YES_ID, NO_ID])
+    pipe.stage_all()
+    steps = 2 * G
+    elapsed, _ = timed_run(eng, pipe, steps, G, eng.sync)
+    done = [slot_seqs[k % n_slots] for k in range(steps // G)]
+    n_pass = sum(len(g) for g in done)
+    n_tok = sum(len(s) for g in done for s in g)
+    gfl = sum(algorithmic_gflop_per_passage(dims, len(s)) for g in done for s in g)
+    return {"workload": f"S2 ragged: lengths U{{96..184}}, batch_size={B}, {G} batches per launch sequence, {steps} steps",
+            "passages_per_s": round(n_pass / elapsed, 1), "tokens_per_s": round(n_tok / elapsed, 1),
+            "mean_tokens_per_passage": round(n_tok / n_pass, 1), "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "algorithmic_tflops": round(gfl / 1e3 / elapsed, 1), "frac_of_mfma_peak": round(gfl / 1e3 / elapsed / MFMA_PEAK_TFLOPS, 4)}
+
+
+def setwise_leg(state):
+    """SURVEY 8d S3 / BASELINE configs[2]: one setwise heapsort query (hits=100, num_child=10, k=10) end to end through
+    SetwiseLlmRanker.rerank on its own engine (label rows of the head boosted so that generations are labels, as with a
+    trained checkpoint), both scorings; and four queries in lockstep (rerank_many).  tools/bench_setwise_query.py."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rk_bench_setwise", os.path.join(REPO, "tools", "bench_setwise_query.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(state=state, reps=2, many=4, one_by_one=False)
+    for v in res.values():
+        v.pop("top10", None)
+    res["workload"] = "S3: flan-t5-large dims, setwise heapsort, hits=100 num_child=10 k=10, 60-word passages (fixture tokenizer), " \
+                      "level-batched build phase; *_many4 = four queries ranked in lockstep (SetwiseLlmRanker.rerank_many)"
+    return res
 
 
 def profile_pass(eng, pipe, G, M_tokens):
@@ -297,9 +374,19 @@ def main():
     def group_batch(n_batches, seed):
         return [s for j in range(n_batches) for s in _synth.synth_token_batch(B, L, L, dims.vocab, seed=seed + j)]
     n_slots = eng.num_slots
-    slot_seqs = [group_batch(G, 929 + rank * 64 + 8 * s) for s in range(n_slots)]
-    seqs = slot_seqs[0][:B]
-    pipe = GroupPipeline(eng, slot_seqs, B, G, [0], [YES_ID, NO_ID], world)
+    shard = args.mode == "shard"
+    if shard:
+        from llmrankers._dist import shard_bounds
+        bounds = shard_bounds(args.hits, world)
+        width = max(b - a for a, b in bounds)
+        lo, hi = bounds[rank]
+        queries = [_synth.synth_token_batch(args.hits, L, L, dims.vocab, seed=4000 + q) for q in range(n_slots)]   # same on every rank
+        pipe = ShardPipeline(eng, [q[lo:hi] for q in queries], [0], [YES_ID, NO_ID], world, width)
+        seqs = queries[0][:B]
+    else:
+        slot_seqs = [group_batch(G, 929 + rank * 64 + 8 * s) for s in range(n_slots)]
+        seqs = slot_seqs[0][:B]
+        pipe = GroupPipeline(eng, slot_seqs, B, G, [0], [YES_ID, NO_ID], world)
     pipe.stage_all()
 
     def fence():
@@ -309,20 +396,53 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    elapsed, ev_ms = timed_run(eng, pipe, args.steps, args.warmup, fence)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        got = eng.comm_read_gathered(pipe.last_slot)       # [world, G*B*2]: every rank holds every rank's scores
-        assert got.shape[0] == world and np.isfinite(got[:, :2 * B]).all()
-    scores = eng.read_scores(0)[:B]
-    assert all(np.isfinite(eng.read_scores(s)).all() for s in range(n_slots))
+    regions, ev_regions = [], []
+    for r in range(max(1, args.regions)):
+        el, ev_ms = timed_run(eng, pipe, args.steps, args.warmup if r == 0 else 0, fence)
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        regions.append(el)
+        ev_regions.append(ev_ms)
+    order = sorted(range(len(regions)), key=lambda i: regions[i])
+    mid = order[len(order) // 2]
+    elapsed, ev_ms = regions[mid], ev_regions[mid]
+    gather_check = None
+    if shard:
+        # every rank re-scores the WHOLE last query itself: the gathered scores must be those bits (batch independence)
+        q = queries[pipe.last_slot]
+        if world > 1:
+            got = eng.comm_read_gathered(pipe.last_slot)       # [world, width * 2]
+            gathered = np.concatenate([got[r_, :(b_ - a_) * 2] for r_, (a_, b_) in enumerate(bounds)]).reshape(-1, 2)
+        else:
+            gathered = eng.read_scores(pipe.last_slot)
+        local_all = eng.score(q, [0], [YES_ID, NO_ID])
+        assert np.array_equal(gathered, local_all), f"rank {rank}: gathered scores differ from the locally recomputed ones"
+        gather_check = f"gathered == locally recomputed scores of all {args.hits} candidates on every rank (bit-exact)"
+        scores = local_all[:B]
+    else:
+        if world > 1:
+            got = eng.comm_read_gathered(pipe.last_slot)       # [world, G*B*2]: every rank holds every rank's scores
+            mine = eng.read_scores(pipe.last_slot).reshape(-1)
+            assert got.shape[0] == world and np.array_equal(got[rank, :len(mine)], mine), f"rank {rank}: its own gathered row differs from its scores"
+            gather_check = "every rank's gathered row of its own scores == its local score buffer (bit-exact)"
+        scores = eng.read_scores(0)[:B]
+        assert all(np.isfinite(eng.read_scores(s)).all() for s in range(n_slots))
+    if shard and not args.no_profile and rank == 0:
+        print("[bench] --mode shard: the roofline pass profiles the share-sized launches (M = %d tokens)" % ((hi - lo) * L), file=sys.stderr)
 
     roofline = None
     if not args.no_profile:
         pipe.stage_all()
-        roofline = profile_pass(eng, pipe, G, G * B * L)
+        roofline = profile_pass(eng, pipe, 1 if shard else G, (hi - lo) * L if shard else G * B * L)
+
+    extras = {}
+    if rank == 0 and world == 1 and not shard and not args.no_extras:
+        try:
+            extras["ragged"] = ragged_leg(eng, dims, B, G, n_slots)
+        except Exception as exc:                      # never take the headline number down
+            extras["ragged"] = {"error": repr(exc)[:300]}
 
     per_query = None
     if rank == 0 and world == 1 and not args.no_per_query:
@@ -332,7 +452,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             from oracle import hf_path
-            cpu = hf_path.time_cpu_baseline(dims, state, [list(s) for s in seqs], YES_ID, NO_ID,
+            cpu = hf_path.time_cpu_baseline(dims, state, [list(s) for s in seqs], YES_ID, NO_ID, sample_batch=args.cpu_batch,
                                               tokenizer_dir=os.path.join(REPO, "tests", "golden", "tok"))
             ref_logits = cpu.pop("logits")
             p_cpu = 1 / (1 + np.exp(-(ref_logits[:, 0] - ref_logits[:, 1])))
@@ -342,20 +462,33 @@ def main():
         except Exception as exc:                      # the baseline must never take the GPU number down with it
             cpu = {"value": None, "unit": "passages/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {exc!r}"}
 
+    if rank == 0 and world == 1 and not shard and not args.no_extras:
+        eng.close()                                   # the setwise leg builds its own engine (other head rows, other capacities)
+        try:
+            extras["setwise_query"] = setwise_leg(state)
+        except Exception as exc:
+            extras["setwise_query"] = {"error": repr(exc)[:300]}
+
     if rank == 0:
-        passages = args.steps * B * world
+        passages = args.steps * (args.hits if shard else B * world)
         gfl = algorithmic_gflop_per_passage(dims, L)
         value = passages / elapsed
         line = {
             "metric": "passages/sec (pointwise yes_no reranking, flan-t5-large shape)", "value": round(value, 1),
             "unit": "passages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if shard else "weak",
             "vs_baseline": None, "dtype": "f16 (MFMA inputs), f32 accumulate + residual stream", "data": "synthetic",
-            "config": {"engine_group": f"{G} batches ({G * B} passages) per engine launch sequence",
-                       "workload": f"{args.model} pointwise yes_no, hits=100 batch_size={B} (one step = one batch), "
-                                   f"L_e={L} (128-token passage + 32-token query + template), L_d=1, 2 label rows",
-                       "global_batch": B * world, "seq_len": L,
-                       "parallelism": f"dp{world} (candidate sharding; one engine-issued RCCL all_gather per launch sequence)",
+            "config": {"engine_group": (f"one query's share ({hi - lo} of {args.hits} candidates) per engine launch sequence" if shard
+                                        else f"{G} batches ({G * B} passages) per engine launch sequence"),
+                       "workload": (f"{args.model} pointwise yes_no, ONE query of hits={args.hits} candidates per step, cut over {world} rank(s) "
+                                    f"({', '.join(str(b_ - a_) for a_, b_ in bounds)}), L_e={L}, L_d=1, 2 label rows" if shard else
+                                    f"{args.model} pointwise yes_no, hits=100 batch_size={B} (one step = one batch), "
+                                    f"L_e={L} (128-token passage + 32-token query + template), L_d=1, 2 label rows"),
+                       "mode": args.mode, "global_batch": args.hits if shard else B * world, "seq_len": L,
+                       "parallelism": (f"dp{world}, candidates of each query sharded; one engine-issued RCCL all_gather per query" if shard else
+                                       f"dp{world} (every rank scores its own batches; one engine-issued RCCL all_gather per launch sequence)"),
+                       "gather_check": gather_check,
+                       "timed_regions_ms": [round(x * 1e3, 2) for x in regions], "region_reported": "median",
                        "weights": "synthetic N(0, HF-init std), seed 929", "engine_stream_ms_per_step": round(ev_ms / args.steps, 3),
                        "algorithmic_gflop_per_passage": round(gfl, 2),
                        "note_executed_flops": "throughput fractions use the reference's algorithmic FLOPs (SURVEY 8d); the engine skips "
@@ -363,11 +496,12 @@ def main():
                                               "the exact query-side form (DESIGN.md section 3)",
                        "whole_path_tflops_per_gpu": round(value / world * gfl / 1e3, 1),
                        "whole_path_frac_of_mfma_peak": round(value / world * gfl / 1e3 / MFMA_PEAK_TFLOPS, 4),
-                       "per_query": per_query},
+                       "per_query": per_query, "ragged": extras.get("ragged"), "setwise_query": extras.get("setwise_query")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    eng.close()
+    if eng.h:
+        eng.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -45,17 +45,32 @@ template <bool MASK, bool FIRST, class BiasFn, bool CHUNKED = false>
 __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m_run, float& l_run,
                                                   int key_base, int L, BiasFn bias) {
   float tmax = -1e30f;
+  // registers 4g .. 4g+3 of s0 / s1 hold keys tile0 + 8g (+32) .. +8 (both half-waves): a group that lies wholly inside the
+  // sequence needs no select - decided per group on wave-uniform values, as a real scalar branch (the empty asm keeps the
+  // compiler from turning it back into selects).  At L = 184 one group of eight is cut: 8 compare / select pairs instead
+  // of 64 on every last tile.  Same values either way.
+  const int tile0 = MASK ? (__builtin_amdgcn_readfirstlane(key_base) & ~63) : 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     if (CHUNKED && (r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
     s0[r] = fmaf(s0[r], ATT_LOG2E, bias(r, 0));
     s1[r] = fmaf(s1[r], ATT_LOG2E, bias(r, 1));
-    if (MASK) {
-      const int key0 = key_base + (r & 3) + 8 * (r >> 2);
-      s0[r] = key0 < L ? s0[r] : -1e30f;
-      s1[r] = key0 + 32 < L ? s1[r] : -1e30f;
+    if (MASK && (r & 3) == 3) {
+      const int g = r >> 2;
+      if (tile0 + 8 * g + 8 > L) {
+        asm volatile("");
+#pragma unroll
+        for (int j = 4 * g; j < 4 * g + 4; ++j) s0[j] = key_base + (j & 3) + 8 * g < L ? s0[j] : -1e30f;
+      }
+      if (tile0 + 8 * g + 40 > L) {
+        asm volatile("");
+#pragma unroll
+        for (int j = 4 * g; j < 4 * g + 4; ++j) s1[j] = key_base + (j & 3) + 8 * g + 32 < L ? s1[j] : -1e30f;
+      }
+#pragma unroll
+      for (int j = 4 * g; j < 4 * g + 4; ++j) tmax = fmaxf(tmax, fmaxf(s0[j], s1[j]));
     }
-    tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
+    if (!MASK) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
   }
   if (CHUNKED) __builtin_amdgcn_sched_barrier(0);
   tmax = fmaxf(tmax, __shfl_xor(tmax, 32));

@@ -139,20 +139,58 @@ class T5Runtime:
         return self
 
     # -- multi-GPU: scores are collected by the engine's own RCCL communicator (rk_comm_*) --------------------
+    COMM_FLOATS_PER_RANK = 65536      # send-buffer capacity (256 KB per rank): hits / world x outputs per passage
+
     def comm_ready(self) -> bool:
         return getattr(self.engine, "comm_world", 1) > 1
 
-    def comm_init_from_process_group(self, max_floats_per_rank: int = 4096):
+    def comm_init_from_process_group(self, max_floats_per_rank: int = 0):
         """One process per GPU under torchrun: take rank / world from the initialised torch.distributed group, use it
-        ONLY to hand rank 0's RCCL id to the other ranks, and build the engine's communicator."""
+        ONLY to hand rank 0's RCCL id to the other ranks, and build the engine's communicator (collective)."""
         import torch.distributed as dist
         rank, world = dist.get_rank(), dist.get_world_size()
         ids = [self.engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        self.engine.comm_init(ids[0], rank, world, max_floats_per_rank)
+        self.engine.comm_init(ids[0], rank, world, max_floats_per_rank or self.COMM_FLOATS_PER_RANK)
+        self.comm_capacity = max_floats_per_rank or self.COMM_FLOATS_PER_RANK
+
+    def ensure_comm(self) -> bool:
+        """Called by a candidate-sharding ranker before its first sharded query: under an initialised process group of
+        more than one rank the engine communicator is built once (every rank gets here - the call is collective).
+        Returns comm_ready().  A failure to bring RCCL up raises: there is no silent host-side substitute on a GPU run."""
+        if self.comm_ready():
+            return True
+        try:
+            import torch.distributed as dist
+        except Exception:
+            return False
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return False
+        self.comm_init_from_process_group()
+        return self.comm_ready()
+
+    def sharded_scores(self, kind: str, seqs, arg, out_ids, width_floats: int):
+        """This rank's share of one query -> (local raw outputs, allv [world, width_floats]) with ONE RCCL all_gather.
+        The share may take several engine calls (more than max_seqs sequences / max_tokens tokens): each call's scores are
+        appended to the engine's send buffer on the device (rk_comm_append_scores_slot), then the whole share is shipped.
+        Every rank issues exactly one collective per query whatever its chunk count (also with an empty share)."""
+        if width_floats > getattr(self, "comm_capacity", self.COMM_FLOATS_PER_RANK):
+            raise ValueError(f"{width_floats} floats per rank exceed the communicator's send buffer ({self.comm_capacity}); "
+                             "build it with comm_init_from_process_group(max_floats_per_rank=...)")
+        k = len(out_ids) if kind == "score" else 1
+        parts, off = [], 0
+        for chunk in self._chunks(seqs):
+            part = self.engine.qlm(chunk, arg) if kind == "qlm" else self.engine.score(chunk, arg, out_ids)
+            n = len(chunk) * k
+            self.engine.comm_append(n, off, slot=0)              # blocking calls leave their scores in slot 0
+            parts.append(np.asarray(part, dtype=np.float32).reshape(-1))
+            off += n
+        local = np.concatenate(parts) if parts else np.zeros(0, np.float32)
+        return local, self.engine.comm_all_gather_appended(width_floats)
 
     def all_gather_last_scores(self, n_floats: int) -> np.ndarray:
-        """[world, n_floats]: the first n_floats of slot 0's device score buffer of every rank (one RCCL all_gather)."""
+        """[world, n_floats]: the first n_floats of slot 0's device score buffer of every rank (one RCCL all_gather; a
+        share that fits ONE engine call - bench.py's grouped launches; rankers use sharded_scores)."""
         self.engine.comm_all_gather(n_floats, slot=0)
         return self.engine.comm_read_gathered(0)
 

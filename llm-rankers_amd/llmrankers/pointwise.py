@@ -117,26 +117,31 @@ class PointwiseLlmRanker(LlmRanker):
 
     def _rerank_sharded(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
         """One process per GPU: this rank scores its contiguous chunk of the candidates, ONE all_gather collects the
-        raw engine outputs of all ranks (engine-owned RCCL when the runtime has a communicator, torch.distributed
-        otherwise - the CPU tests), every rank finishes and sorts identically."""
+        raw engine outputs of all ranks - issued by the engine itself over RCCL (T5Runtime.ensure_comm builds the
+        communicator on the first sharded query; a share that needs several engine calls is appended on the device and
+        shipped whole), or through torch.distributed when the runtime has no communicator (the CPU test doubles) - and
+        every rank finishes and sorts identically.  Replaces accelerate's device_map='auto' layer placement of
+        ref: llmrankers/pointwise.py:20-24."""
         from . import _dist
         rank, ws = _dist.world()
         bounds = _dist.shard_bounds(len(ranking), ws)
         s, e = bounds[rank]
         width = max(b - a for a, b in bounds)
         self._reset()
+        if width == 0:                                           # no candidates at all: nothing to score or gather on any rank
+            return []
         spec = self._spec(query, ranking[s:e])
         if spec is None:
             return sorted(ranking, key=lambda x: x.score, reverse=True)
         prompts, kind, arg, out_ids, dec_len, finish = spec
         chunks = self._counted_batches(prompts, dec_len)
         k = len(out_ids) if kind == "score" else 1
-        if getattr(self.llm, "comm_ready", lambda: False)():
-            if e > s:                                            # the local chunk in ONE engine call on slot 0 ...
-                flat = [q for c in chunks for q in c]
-                local = self.llm.qlm(flat, arg) if kind == "qlm" else self.llm.score(flat, arg, out_ids)
-                assert len(local) == e - s
-            allv = self.llm.all_gather_last_scores(width * k).reshape(ws, width * k)   # ... gathered from its device buffer
+        # the engine builds its RCCL communicator on the first sharded query (collective: every rank is here)
+        if getattr(self.llm, "ensure_comm", lambda: False)():
+            flat = [q for c in chunks for q in c]
+            local, allv = self.llm.sharded_scores(kind, flat, arg, out_ids, width * k)
+            assert len(local) == (e - s) * k
+            allv = np.asarray(allv, dtype=np.float32).reshape(ws, width * k)
         else:
             local = self._raw(chunks, kind, arg, out_ids).reshape(-1)
             allv = _dist.all_gather_flat(local, width * k)

@@ -128,29 +128,33 @@ def dataloader_overhead(tokenizer_dir: str, hits: int, L: int, batch_size: int, 
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-def time_cpu_baseline(dims, state, seqs: List[Sequence[int]], yes_id: int, no_id: int, sample_batch: int = 8,
-                      n_timed: int = 3, tokenizer_dir: str = None) -> dict:
+def time_cpu_baseline(dims, state, seqs: List[Sequence[int]], yes_id: int, no_id: int, sample_batch: int = 32,
+                      n_timed: int = 3, tokenizer_dir: str = None, budget_s: float = 75.0) -> dict:
     """HF fp32 on the host CPU, torch threads = physical cores, 1 warm-up batch, median of
-    `n_timed` batches.  The sample is deliberately SMALLER than the bench's batch of 32 (sample_batch sequences of the
-    same length; CPU throughput per passage is flat in the batch size at these sizes) so that the leg stays within
-    ~30 s; `sample` says so.  Also reports the reference-faithful per-query figure: the same forward time plus the
-    fixed cost of the 4-worker DataLoader the reference forks in every rerank() call."""
+    `n_timed` batches of `sample_batch` sequences (32 = the bench's batch, the procedure BASELINE.md names).  The leg is
+    bounded: if the warm-up batch shows that the timed batches would not fit `budget_s`, fewer are timed (at least one) and
+    `sample` says so.  Also reports the reference-faithful per-query figure: the same forward time plus the fixed cost of
+    the 4-worker DataLoader the reference forks in every rerank() call."""
     import torch
     cores = _physical_cores()
     torch.set_num_threads(cores)
     model = build_hf_model(dims, state)
     chunk = [list(s) for s in seqs[:sample_batch]]
+    t0 = time.perf_counter()
     logits = pointwise_yes_no(model, chunk, len(chunk), yes_id, no_id)            # warm-up (also the parity sample)
+    warm = time.perf_counter() - t0
+    n_eff = max(1, min(n_timed, int((budget_s - warm) // max(warm, 1e-3))))
     times = []
-    for _ in range(n_timed):
+    for _ in range(n_eff):
         t0 = time.perf_counter()
         pointwise_yes_no(model, chunk, len(chunk), yes_id, no_id)
         times.append(time.perf_counter() - t0)
     per_batch = float(np.median(times))
     value = len(chunk) / per_batch
     res = {"value": value, "unit": "passages/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
-           "sample": f"1 warm-up + median of {n_timed} batches of {len(chunk)} x L={len(chunk[0])} (the bench batch is 32 of the same "
-                     f"length; shrunk to bound the leg) through HF transformers fp32, torch {torch.__version__} CPU, "
+           "sample": f"1 warm-up ({warm:.1f} s) + median of {n_eff} batch(es) of {len(chunk)} x L={len(chunk[0])} "
+                     f"(BASELINE.md section 3: B=32, median of >= 3" + ("" if n_eff >= 3 and len(chunk) == 32 else f"; bounded here to {budget_s:.0f} s of CPU work") +
+                     f") through HF transformers fp32, torch {torch.__version__} CPU, "
                      f"{cores} threads = physical cores; {per_batch:.2f} s/batch (min {min(times):.2f}, max {max(times):.2f})",
            "logits": logits}
     if tokenizer_dir:

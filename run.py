@@ -12,6 +12,14 @@ path this build accelerates and are rejected with a clear message.  
 accepted as well:  --query_file (TSV `qid<TAB>text` or JSONL {"qid"|"query_id"|"_id", "text"|"query"}) and
 --doc_file (TSV `docid<TAB>text` or JSONL {"docid"|"doc_id"|"_id", "text"|"contents", ["title"]}).
 
+Multi-GPU (one process per GPU; the reference's only multi-GPU mode is accelerate's device_map='auto' layer placement,
+ref: llmrankers/pointwise.py:20-24, README.md:357): `--num_gpus N` re-executes the command under torch.distributed.run with N
+ranks on this node (or run it under torchrun yourself).  Pointwise rankers then shard every query's CANDIDATES over the ranks
+(hits=100 over 8 GPUs -> 13,13,13,13,12,12,12,12) and the engine collects the scores with one RCCL all_gather per query
+(`--shard_candidates`, the default for pointwise under more than one rank); setwise / pairwise sorts are dependency chains, so
+their QUERIES are dealt to the ranks instead (replicas) and rank 0 collects the rankings.  Rank 0 writes the run file and
+prints the averages.
+
 Long runs (the reference's Rank-R1 driver, ref: Rank-R1/run_setwise.py:79-87, 266-300): `--resume` appends each query's
 ranking to --save_path as soon as it is done and skips the qids already in the file when restarted;
 `--dataset_number_of_shards` / `--dataset_shard_index` cut the query list into contiguous shards (one process per GPU,
@@ -21,6 +29,7 @@ run with a self-contained NDCG (trec_eval / pyserini are not available offline).
 import argparse
 import json
 import logging
+import os
 import random
 import sys
 import time
@@ -134,13 +143,40 @@ def _read_kv_file(path, id_keys, text_keys):
     return out
 
 
+def dist_env():
+    """(rank, world) of the launcher's environment (torchrun / torch.distributed.run), (0, 1) without one."""
+    return int(os.environ.get("RANK", "0") or 0), int(os.environ.get("WORLD_SIZE", "1") or 1)
+
+
+def self_spawn(num_gpus, argv=None):
+    """`run.py run --num_gpus N ...` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
+    127.0.0.1), exactly like bench.py --gpus N."""
+    if num_gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={num_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv))
+    print("[run] --num_gpus %d without a launcher: re-executing as\n      %s" % (num_gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    os.execv(sys.executable, cmd)
+
+
+def candidates_sharded(args, world):
+    """Pointwise under more than one rank shards the candidates of every query (one RCCL gather per query) unless
+    --shard_candidates 0 asks for query-level replicas; the sorting rankers are always replicas."""
+    flag = getattr(args.run, "shard_candidates", None)
+    return bool(args.pointwise) and world > 1 and (flag is None or int(flag) != 0)
+
+
 def build_ranker(args):
     if args.pointwise:
         from llmrankers.pointwise import MonoT5LlmRanker, PointwiseLlmRanker
         cls = MonoT5LlmRanker if "monot5" in args.run.model_name_or_path else PointwiseLlmRanker
         return cls(model_name_or_path=args.run.model_name_or_path, tokenizer_name_or_path=args.run.tokenizer_name_or_path,
                    device=args.run.device, cache_dir=args.run.cache_dir, method=args.pointwise.method,
-                   batch_size=args.pointwise.batch_size)
+                   batch_size=args.pointwise.batch_size, shard_candidates=candidates_sharded(args, dist_env()[1]))
     if args.setwise:
         if args.run.openai_key:
             raise NotImplementedError("OpenAI rankers are remote HTTP calls, not part of the MI355X hot path; use the reference")
@@ -150,6 +186,9 @@ def build_ranker(args):
                                 scoring=args.run.scoring, method=args.setwise.method,
                                 num_permutation=args.setwise.num_permutation, k=args.setwise.k)
     if args.pairwise:
+        if args.pairwise.method != "allpair":                    # ref: run.py:88-90
+            args.pairwise.batch_size = 2
+            logger.info("Setting batch_size to 2.")
         if args.run.openai_key or "duot5" in args.run.model_name_or_path:
             raise NotImplementedError("OpenAI / duoT5 pairwise rankers are not part of this build; use the reference")
         from llmrankers.pairwise import PairwiseLlmRanker
@@ -192,6 +231,11 @@ def load_queries_and_docs(args, ranker):
 
 
 def main(args):
+    rank, world = dist_env()
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():                     # host-side control plane only; scores travel over the engine's RCCL
+            dist.init_process_group(backend="gloo")
     ranker = build_ranker(args)
     query_map, get_doc = load_queries_and_docs(args, ranker)
     logger.info(f"Loading first stage run from {args.run.run_path}.")
@@ -220,6 +264,12 @@ def main(args):
 
     if getattr(args.run, "dataset_number_of_shards", 1) > 1:        # one process per GPU, each takes a contiguous shard of the queries
         first_stage = split_into_shards(first_stage, args.run.dataset_number_of_shards)[args.run.dataset_shard_index]
+    shard_cands = candidates_sharded(args, world)
+    replicas = world > 1 and not shard_cands                         # ranks take whole queries; rank 0 collects the rankings
+    all_qids = [qid for qid, _, _ in first_stage]
+    if replicas:
+        first_stage = split_into_shards(first_stage, world)[rank]
+    writer = rank == 0                                               # candidate sharding: every rank holds every ranking
     resume = bool(getattr(args.run, "resume", False))
     done = set(read_run_qids(args.run.save_path)) if resume else set()
     if done:
@@ -232,6 +282,10 @@ def main(args):
     # same rankings and counters as one query at a time, the engine's batched throughput instead of its per-query one
     per_call = max(1, int(getattr(args.run, "queries_per_call", 1) or 1))
     if per_call > 1 and not hasattr(ranker, "rerank_many"):
+        per_call = 1
+    if per_call > 1 and args.run.shuffle_ranking == "random" and getattr(ranker, "num_permutation", 1) > 1:
+        # permutation voting draws from the same global RNG as --shuffle_ranking random: queued queries would be shuffled
+        # before earlier ones have drawn their permutations - a different random sequence than one query at a time
         per_call = 1
     pending = []
 
@@ -250,7 +304,7 @@ def main(args):
             n_cmp += c
             n_prompt += p
             n_compl += t
-        if resume:                                                   # durable after every call (ref: Rank-R1/run_setwise.py:79-87)
+        if resume and writer and not replicas:                       # durable after every call (ref: Rank-R1/run_setwise.py:79-87)
             write_run_file(args.run.save_path, results[-len(pending):], "LLMRankers", mode="a")
         pending.clear()
 
@@ -267,12 +321,33 @@ def main(args):
             flush()
     flush()
     toc = time.time()
+    if replicas:
+        # every rank ranked its share of the queries: rank 0 collects (rankings are small: docid + score per line)
+        import torch.distributed as dist
+        mine = ([(qid, query, [(d.docid, d.score) for d in res]) for qid, query, res in results], n_cmp, n_prompt, n_compl, toc - tic)
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(mine, parts, dst=0)
+        if rank == 0:
+            by_qid, n_cmp, n_prompt, n_compl, wall = {}, 0, 0, 0, 0.0
+            for rows, c, p_, t_, w in parts:
+                for qid, query, docs in rows:
+                    by_qid[qid] = (qid, query, [SearchResult(docid=d, score=sc, text=None) for d, sc in docs])
+                n_cmp, n_prompt, n_compl, wall = n_cmp + c, n_prompt + p_, n_compl + t_, max(wall, w)
+            results = [by_qid[q] for q in all_qids if q in by_qid]          # first-stage order, like a single process
+            tic, toc = 0.0, wall
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    if not writer:
+        return
     n = max(len(results), 1)
     print(f"Avg comparisons: {n_cmp / n}")
     print(f"Avg prompt tokens: {n_prompt / n}")
     print(f"Avg completion tokens: {n_compl / n}")
     print(f"Avg time per query: {(toc - tic) / n}")
-    if not resume:
+    if replicas and resume:
+        write_run_file(args.run.save_path, results, "LLMRankers", mode="a")
+    elif not resume:
         write_run_file(args.run.save_path, results, "LLMRankers")
     if getattr(args.run, "qrels", None):
         qrels = read_qrels(args.run.qrels)
@@ -309,6 +384,11 @@ def build_parser():
     rp.add_argument("--dataset_number_of_shards", type=int, default=1)
     rp.add_argument("--dataset_shard_index", type=int, default=0)
     rp.add_argument("--qrels", type=str, default=None, help="TREC qrels file: print NDCG@10 of the input and the reranked run")
+    rp.add_argument("--num_gpus", type=int, default=1,
+                    help="ranks (one process per GPU) on this node; > 1 without a launcher re-executes under torch.distributed.run")
+    rp.add_argument("--shard_candidates", type=int, default=None, choices=[0, 1],
+                    help="pointwise under several ranks: 1 (default) shards every query's candidates and gathers the scores over "
+                         "RCCL, 0 deals whole queries to the ranks")
     rp.add_argument("--queries_per_call", type=int, default=1,
                     help="pointwise / setwise: queries handed to the engine together (same rankings and counters as one at a time)")
     pw = commands.add_parser("pointwise")
@@ -343,4 +423,5 @@ if __name__ == "__main__":
     _parser, _commands = build_parser()
     _args = parse_args(_parser, _commands)
     validate(_args)
+    self_spawn(int(getattr(_args.run, "num_gpus", 1) or 1))
     main(_args)

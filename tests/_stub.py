@@ -46,3 +46,63 @@ class OracleLlamaRuntime:
 
     def last_logits(self, seqs, out_ids):
         return self.orc.last_logits(seqs, out_ids)
+
+
+class FakeCommEngine:
+    """Stands in for RkEngine behind the REAL T5Runtime (T5Runtime.from_engine) in the multi-process CPU tests: the oracle
+    computes the scores, a numpy array plays the device send buffer of rk_comm_append_scores_slot, and gloo carries what
+    RCCL carries on the GPU box.  Capacities are tiny on purpose, so that a rank's share of a query takes several calls."""
+
+    def __init__(self, dims, state, max_seqs=3, max_tokens=100000):
+        from types import SimpleNamespace
+        self.dims, self.orc = dims, T5Oracle(dims, state)
+        self.desc = SimpleNamespace(max_tokens=max_tokens, max_seqs=max_seqs)
+        self.comm_rank, self.comm_world = 0, 1
+        self.calls = {"score": 0, "qlm": 0, "append": 0, "gather": 0, "init": 0}
+        self._last = np.zeros(0, np.float32)
+        self._send = None
+
+    def score(self, seqs, dec_prefix, out_ids):
+        assert 0 < len(seqs) <= self.desc.max_seqs
+        self.calls["score"] += 1
+        out = np.asarray(self.orc.score_last(seqs, dec_prefix, out_ids), dtype=np.float32)
+        self._last = out.reshape(-1).copy()          # "slot 0's device score buffer" is overwritten by every call
+        return out
+
+    def qlm(self, seqs, labels):
+        assert 0 < len(seqs) <= self.desc.max_seqs
+        self.calls["qlm"] += 1
+        out = np.asarray(self.orc.qlm(seqs, labels), dtype=np.float32)
+        self._last = out.reshape(-1).copy()
+        return out
+
+    # staged form used by T5Runtime.score_batches (single-process pipelining): one slot, evaluated at read time
+    num_slots = 1
+
+    def stage(self, seqs, slot=0):
+        self._staged = [list(x) for x in seqs]
+
+    def score_staged(self, dec_prefix, out_ids, slot=0):
+        self._staged_args = (list(dec_prefix), list(out_ids))
+
+    def read_scores(self, slot=0):
+        return self.score(self._staged, *self._staged_args)
+
+    def comm_unique_id(self):
+        return bytes(range(128))
+
+    def comm_init(self, uid, rank, world, cap):
+        assert uid == bytes(range(128)), "the id did not travel from rank 0"
+        self.calls["init"] += 1
+        self.comm_rank, self.comm_world = rank, world
+        self._send = np.full(cap, np.nan, np.float32)
+
+    def comm_append(self, n, offset, slot=0):
+        assert slot == 0 and n <= len(self._last)
+        self.calls["append"] += 1
+        self._send[offset:offset + n] = self._last[:n]
+
+    def comm_all_gather_appended(self, n):
+        from llmrankers import _dist
+        self.calls["gather"] += 1
+        return _dist.all_gather_flat(np.nan_to_num(self._send[:n], nan=-777.0), n)

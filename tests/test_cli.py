@@ -235,3 +235,82 @@ def test_queries_per_call_gives_the_same_run_and_statistics(runmod, tmp_path, ck
         assert (rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens) == counters[-1]
     assert PointwiseLlmRanker.from_runtime(OracleRuntime(dims, state), tok, method="yes_no", batch_size=3).rerank_many([]) == ([], [])
     assert MonoT5LlmRanker.rerank_many is PointwiseLlmRanker.rerank_many
+
+
+RUN_WORKER = r'''
+import importlib.util, json, os, sys
+repo = sys.argv[1]
+sys.path[:0] = [os.path.join(repo, "llm-rankers_amd"), repo, os.path.join(repo, "tests")]
+spec = importlib.util.spec_from_file_location("rk_run", os.path.join(repo, "run.py"))
+runmod = importlib.util.module_from_spec(spec); spec.loader.exec_module(runmod)
+from conftest import load_state
+from _stub import FakeCommEngine
+from llmrankers._runtime import T5Runtime
+from llmrankers.pointwise import PointwiseLlmRanker
+from transformers import T5Tokenizer
+ck = sys.argv[2]
+dims, state = load_state(ck)
+tok = T5Tokenizer.from_pretrained(ck)
+engines = []
+def make(args):
+    eng = FakeCommEngine(dims, state, max_seqs=2)
+    engines.append(eng)
+    return PointwiseLlmRanker.from_runtime(T5Runtime.from_engine(eng, dims), tok, method=args.pointwise.method, batch_size=args.pointwise.batch_size,
+                                           shard_candidates=runmod.candidates_sharded(args, runmod.dist_env()[1]))
+runmod.build_ranker = make
+parser, commands = runmod.build_parser()
+args = runmod.parse_args(parser, commands, json.loads(sys.argv[3]))
+runmod.validate(args)
+runmod.main(args)
+print("CALLS " + json.dumps(engines[0].calls))
+'''
+
+
+@pytest.mark.parametrize("shard_flag", ["1", "0"])
+def test_two_rank_run_py_matches_single_process(runmod, tmp_path, ckpt_dirs, shard_flag):
+    """run.py under a 2-rank launcher environment (gloo): candidate sharding (--shard_candidates 1: every query's candidates
+    split over the ranks, engine gather path, several engine calls per share) and query replicas (0: ranks take whole
+    queries, rank 0 collects) both write exactly the run file of a single process; only rank 0 writes."""
+    import json
+    import socket
+    import subprocess
+    ck = ckpt_dirs["ckpt_gated_untied"]
+    (tmp_path / "q.tsv").write_text("q1\tneural ranking model\nq2\twater river mountain\nq3\tmusic art film\n")
+    (tmp_path / "d.tsv").write_text("\n".join(f"d{i}\t{w}" for i, w in enumerate(
+        ["search engine index", "river water city", "music art film", "vaccine covid virus", "bank money trade",
+         "neural model answer", "mountain river water", "film music topic"])) + "\n")
+    lines = [f"{q} Q0 d{i} {r + 1} {10 - r} bm25" for q in ("q1", "q2", "q3") for r, i in enumerate([0, 1, 2, 3, 4, 5, 6])]
+    (tmp_path / "in.trec").write_text("\n".join(lines) + "\n")
+    (tmp_path / "worker.py").write_text(RUN_WORKER)
+
+    def argv(save):
+        return ["run", "--model_name_or_path", ck, "--run_path", str(tmp_path / "in.trec"), "--save_path", str(save),
+                "--query_file", str(tmp_path / "q.tsv"), "--doc_file", str(tmp_path / "d.tsv"), "--hits", "7",
+                "--shard_candidates", shard_flag, "pointwise", "--method", "yes_no", "--batch_size", "3"]
+
+    base_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    single = subprocess.run([sys.executable, str(tmp_path / "worker.py"), REPO, ck, json.dumps(argv(tmp_path / "single.trec"))],
+                            capture_output=True, text=True, env=dict(base_env, OMP_NUM_THREADS="2"), timeout=600)
+    assert single.returncode == 0, single.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, str(tmp_path / "worker.py"), REPO, ck, json.dumps(argv(tmp_path / "multi.trec"))],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(base_env, OMP_NUM_THREADS="2", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))) for r in range(2)]
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(out)
+    assert "Avg comparisons" in outs[0] and "Avg comparisons" not in outs[1]       # rank 0 reports
+    a = [l.split("\t") for l in (tmp_path / "single.trec").read_text().splitlines()]
+    b = [l.split("\t") for l in (tmp_path / "multi.trec").read_text().splitlines()]
+    assert [x[:4] + x[5:] for x in a] == [x[:4] + x[5:] for x in b] and len(a) == 21
+    assert max(abs(float(x[4]) - float(y[4])) for x, y in zip(a, b)) < 1e-6
+    calls = [json.loads(next(l for l in o.splitlines() if l.startswith("CALLS "))[6:]) for o in outs]
+    if shard_flag == "1":       # 7 candidates -> shares of 4 and 3, two passages per engine call: 2 calls each, one gather per query
+        assert all(c["init"] == 1 and c["gather"] == 3 and c["append"] == 6 for c in calls), calls
+    else:                       # replicas: no communicator, no gather
+        assert all(c["init"] == 0 and c["gather"] == 0 for c in calls), calls

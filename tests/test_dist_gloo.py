@@ -70,3 +70,73 @@ def test_two_rank_sharded_rerank_matches_reference(ckpt_dirs, tmp_path):
     assert outs[0] == outs[1]                                          # every rank holds the same final ranking
     assert [d for d, _ in outs[0]] == [d for d, _ in case["result"]]   # = the reference's order
     np.testing.assert_allclose([s for _, s in outs[0]], [s for _, s in case["result"]], atol=2e-5)
+
+
+WORKER_ENGINE = r'''
+import json, os, sys
+sys.path[:0] = [os.path.join(sys.argv[1], "llm-rankers_amd"), sys.argv[1], os.path.join(sys.argv[1], "tests")]
+import torch.distributed as dist
+from conftest import load_state
+from _stub import FakeCommEngine
+from llmrankers._runtime import T5Runtime
+from llmrankers.rankers import SearchResult
+from llmrankers.pointwise import PointwiseLlmRanker
+from transformers import T5Tokenizer
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=int(sys.argv[4]))
+ck = sys.argv[5]
+dims, state = load_state(ck)
+case = json.load(open(sys.argv[6]))
+tok = T5Tokenizer.from_pretrained(ck)
+eng = FakeCommEngine(dims, state, max_seqs=3)
+rt = T5Runtime.from_engine(eng, dims)                 # the REAL runtime: ensure_comm / sharded_scores / chunking
+rk = PointwiseLlmRanker.from_runtime(rt, tok, method=case["method"], batch_size=case["batch_size"], shard_candidates=True)
+out = []
+for rep in range(2):                                  # two queries: the communicator is built once, one gather each
+    ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+    res = rk.rerank(case["query"], ranking)
+    out.append([[r.docid, r.score] for r in res])
+print("RESULT " + json.dumps({"rankings": out, "calls": eng.calls, "empty": rk.rerank(case["query"], [])}))
+dist.destroy_process_group()
+'''
+
+
+def _run_two_ranks(tmp_path, worker_src, ckpt, case):
+    cpath = tmp_path / "case.json"
+    cpath.write_text(json.dumps(case))
+    wpath = tmp_path / "worker.py"
+    wpath.write_text(worker_src)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(wpath), REPO, str(port), str(r), "2", ckpt, str(cpath)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(json.loads(next(l for l in out.splitlines() if l.startswith("RESULT "))[7:]))
+    return outs
+
+
+def test_two_rank_engine_gather_path_with_multi_chunk_shards(ckpt_dirs, tmp_path):
+    """The branch a GPU run takes: PointwiseLlmRanker(shard_candidates=True) -> T5Runtime.ensure_comm builds the engine
+    communicator from the process group on the first sharded query -> T5Runtime.sharded_scores scores the local share in
+    SEVERAL engine calls (max_seqs = 3 here, shares of 7 + 6 and 5 + 5 passages), appends each call's scores to the send buffer and
+    ships the whole share with ONE gather.  (Round 2's path gathered slot 0's buffer after the last call only: every chunk
+    but the last was lost.)  Same ranking and scores as the reference on every rank."""
+    with open(os.path.join(GOLD, "rerank_cases.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["kind"] == "pointwise" and c["ckpt"] == "ckpt_gated_untied"]
+    for method, n_docs in (("yes_no", 13), ("qlm", 10)):
+        case = next(c for c in cases if c["method"] == method and len(c["input"]) == n_docs)
+        outs = _run_two_ranks(tmp_path, WORKER_ENGINE, ckpt_dirs["ckpt_gated_untied"], case)
+        assert outs[0]["rankings"] == outs[1]["rankings"]
+        for rank, o in enumerate(outs):
+            n_local = (n_docs + 1 - rank) // 2               # 13 -> 7, 6;  10 -> 5, 5
+            n_chunks = -(-n_local // 3)
+            assert o["calls"]["init"] == 1 and o["calls"]["gather"] == 2, o["calls"]
+            assert o["calls"]["append"] == 2 * n_chunks and o["calls"]["qlm" if method == "qlm" else "score"] == 2 * n_chunks, o["calls"]
+            assert o["empty"] == []
+            for ranking in o["rankings"]:
+                assert [d for d, _ in ranking] == [d for d, _ in case["result"]]
+                np.testing.assert_allclose([s for _, s in ranking], [s for _, s in case["result"]], atol=2e-5, rtol=1e-5)

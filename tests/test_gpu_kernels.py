@@ -610,6 +610,115 @@ def test_comm_two_ranks_gather(tmp_path):
     np.testing.assert_array_equal(a0[1][:12].reshape(6, 2), np.array(outs[1]["local"]))
 
 
+def test_comm_single_rank_appended_gather_of_a_multi_chunk_share(toy):
+    """A rank's share that needs SEVERAL engine calls (here max_seqs = 4 against 11 passages: 3 calls): each call's scores
+    are appended to the engine's send buffer on the device (rk_comm_append_scores_slot) and ONE all_gather ships the whole
+    share - through the real T5Runtime.sharded_scores, for yes_no logits and for qlm, with a one-rank RCCL communicator.
+    (Round 2 gathered slot 0's buffer after the last call: everything but the last chunk was lost.)"""
+    from llmrankers import _synth
+    from llmrankers._runtime import T5Runtime
+    dims, state, _ = toy["ckpt_gated_untied"]
+    eng = _engine(dims, state, max_tokens=2048, max_seqs=4, max_dec_len=8)
+    rt = T5Runtime.from_engine(eng, dims)
+    eng.comm_init(eng.comm_unique_id(), 0, 1, 256)
+    rt.comm_capacity = 256
+    try:
+        seqs = _synth.synth_token_batch(11, 4, 60, dims.vocab, seed=5)
+        want = np.concatenate([eng.score(seqs[i:i + 4], [0], [21, 22]) for i in range(0, 11, 4)])
+        local, allv = rt.sharded_scores("score", seqs, [0], [21, 22], 13 * 2)
+        np.testing.assert_array_equal(local.reshape(11, 2), want)
+        np.testing.assert_array_equal(np.asarray(allv).reshape(-1)[:22].reshape(11, 2), want)
+        labels = [0, 5, 9, 17]
+        want_q = np.concatenate([eng.qlm(seqs[i:i + 4], labels) for i in range(0, 11, 4)])
+        local_q, allv_q = rt.sharded_scores("qlm", seqs, labels, None, 13)
+        np.testing.assert_array_equal(local_q, want_q)
+        np.testing.assert_array_equal(np.asarray(allv_q).reshape(-1)[:11], want_q)
+    finally:
+        eng.comm_destroy()
+        eng.close()
+
+
+TWO_RANK_API_WORKER = r'''
+import json, os, sys
+repo, ck = sys.argv[1], sys.argv[2]
+sys.path[:0] = [os.path.join(repo, "llm-rankers_amd"), repo]
+import torch
+import torch.distributed as dist
+dist.init_process_group("gloo")                       # host control plane; the scores travel over the engine's RCCL
+from llmrankers.pointwise import PointwiseLlmRanker
+from llmrankers.rankers import SearchResult
+case = json.load(open(sys.argv[3]))
+rk = PointwiseLlmRanker(ck, ck, "cuda", method=case["method"], batch_size=case["batch_size"], shard_candidates=True)
+rk.llm.max_seqs = 3                                   # a share of 7 / 6 passages then takes three / two engine calls
+out = []
+for rep in range(2):
+    ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+    res = rk.rerank(case["query"], ranking)
+    out.append([[r.docid, r.score] for r in res])
+print("RESULT " + json.dumps({"rankings": out, "comm_world": rk.llm.engine.comm_world}))
+dist.destroy_process_group()
+'''
+
+
+def _two_gpu_env(port):
+    return dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+
+
+def test_two_ranks_pointwise_ranker_and_run_py_shard_candidates(tmp_path, ckpt_dirs):
+    """The product path of BASELINE configs[3] on two GPUs: PointwiseLlmRanker(shard_candidates=True) builds the engine's
+    RCCL communicator itself on the first sharded query, multi-call shares are gathered whole, both ranks return the
+    reference's ranking; then run.py --num_gpus 2 (self-spawned) writes the run file of a single-GPU run.  Skipped on a
+    1-GPU box (ready for the driver's 8-GPU tier)."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from conftest import GOLD, REPO
+    with open(os.path.join(GOLD, "rerank_cases.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["kind"] == "pointwise" and c["ckpt"] == "ckpt_gated_untied"]
+    ck = ckpt_dirs["ckpt_gated_untied"]
+    (tmp_path / "worker.py").write_text(TWO_RANK_API_WORKER)
+    for method, n_docs in (("yes_no", 13), ("qlm", 10)):
+        case = next(c for c in cases if c["method"] == method and len(c["input"]) == n_docs)
+        (tmp_path / "case.json").write_text(json.dumps(case))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = [subprocess.Popen([sys.executable, str(tmp_path / "worker.py"), REPO, ck, str(tmp_path / "case.json")],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                  env=dict(_two_gpu_env(port), RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+        outs = []
+        for p in procs:
+            out, err = p.communicate(timeout=900)
+            assert p.returncode == 0, err[-2000:]
+            outs.append(json.loads(next(l for l in out.splitlines() if l.startswith("RESULT "))[7:]))
+        assert outs[0]["rankings"] == outs[1]["rankings"] and all(o["comm_world"] == 2 for o in outs)
+        for ranking in outs[0]["rankings"]:
+            assert [d for d, _ in ranking] == [d for d, _ in case["result"]]
+            np.testing.assert_allclose([s for _, s in ranking], [s for _, s in case["result"]], atol=SCORE_TOL if method == "yes_no" else 5e-2)
+    # run.py: --num_gpus 2 against a single-GPU run of the same command
+    (tmp_path / "q.tsv").write_text("q1\tneural ranking model\nq2\twater river mountain\n")
+    (tmp_path / "d.tsv").write_text("\n".join(f"d{i}\t{w}" for i, w in enumerate(
+        ["search engine index", "river water city", "music art film", "vaccine covid virus", "bank money trade",
+         "neural model answer", "mountain river water"])) + "\n")
+    (tmp_path / "in.trec").write_text("\n".join(f"{q} Q0 d{i} {r + 1} {10 - r} bm25" for q in ("q1", "q2") for r, i in enumerate(range(7))) + "\n")
+
+    def run(save, extra):
+        cmd = [sys.executable, os.path.join(REPO, "run.py"), "run", "--model_name_or_path", ck, "--run_path", str(tmp_path / "in.trec"),
+               "--save_path", str(save), "--query_file", str(tmp_path / "q.tsv"), "--doc_file", str(tmp_path / "d.tsv"), "--hits", "7",
+               *extra, "pointwise", "--method", "yes_no", "--batch_size", "3"]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [l.split("\t") for l in open(save).read().splitlines()]
+    a = run(tmp_path / "one.trec", [])
+    b = run(tmp_path / "two.trec", ["--num_gpus", "2"])
+    assert [x[:4] + x[5:] for x in a] == [x[:4] + x[5:] for x in b] and len(a) == 14
+    assert [x[4] for x in a] == [x[4] for x in b]             # bit-identical scores: a passage's bits do not depend on its batch
+
+
 def test_qlm_flan_t5_xl_dims_vs_oracle_and_batch_independence():
     """BASELINE.json configs[3] model shape (flan-t5-xl: d_model 2048, 32 heads, d_ff 5120, 24+24 layers), pointwise qlm:
     3 ragged passages x 33 label positions vs the fp32 oracle (relative 5e-4 on sums of ~33 log-probs), then the call

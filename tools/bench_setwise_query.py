@@ -38,7 +38,8 @@ class EngineRuntime:
         return toks
 
 
-def main():
+def run(state=None, reps=3, many=None, one_by_one=True):
+    """-> dict of timings.  `state`: the synthetic flan-t5-large state dict if the caller already has it (bench.py)."""
     from transformers import T5Tokenizer
     tok = T5Tokenizer.from_pretrained(os.path.join(REPO, "tests", "golden", "tok"))
     dims = _synth.FLAN_T5_LARGE
@@ -47,7 +48,9 @@ def main():
     # (tests/golden/setwise_large.json) the lm_head rows of the passage labels a prompt can hold (A .. K at num_child = 10)
     # and EOS are scaled x6, so that a generation is "<label> </s>" as with a trained checkpoint - the case the product
     # path is built for
-    state = _synth.synth_state_dict(dims, seed=929, threads=min(32, os.cpu_count() or 8))
+    if state is None:
+        state = _synth.synth_state_dict(dims, seed=929, threads=min(32, os.cpu_count() or 8))
+    state = dict(state)
     label_ids = [tok.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1] for c in SetwiseLlmRanker.CHARACTERS[:11]]
     head = state["lm_head.weight"].copy()
     ids = np.asarray(sorted(set(label_ids + [tok.eos_token_id])), dtype=np.int64)
@@ -62,16 +65,16 @@ def main():
     rt = EngineRuntime(eng, dims)
     import bench
     rs = random.Random(3)
-    vocab = [tok.convert_ids_to_tokens(i).replace("▁", "") for i in range(10, 200)]
+    vocab = [tok.convert_ids_to_tokens(i).replace("\u2581", "") for i in range(10, 200)]
     vocab = [w for w in vocab if w.isalpha()] or ["a", "b", "c"]
     docs = [(f"d{i}", float(100 - i), " ".join(rs.choice(vocab) for _ in range(60))) for i in range(100)]
     out = {}
     for scoring in ("likelihood", "generation"):
-        for batched in (False, True):
+        for batched in ((False, True) if one_by_one else (True,)):
             rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring=scoring, method="heapsort")
             rk.batch_independent_compares = batched
             best, res0 = None, None
-            for rep in range(3):
+            for rep in range(reps):
                 ranking = [SearchResult(docid=d, score=s, text=rk.truncate(t, 128)) for d, s, t in docs]
                 rk.total_compare = rk.total_prompt_tokens = rk.total_completion_tokens = 0
                 t0 = time.perf_counter()
@@ -88,12 +91,12 @@ def main():
                 "avg_prompt_tokens": round(rk.total_prompt_tokens / max(rk.total_compare, 1), 1), "top10": res0}
     # several queries at once (SetwiseLlmRanker.rerank_many / run.py --queries_per_call): the dependency chains of NQ queries
     # advance in lockstep, their pending compares share an engine call; identical rankings, amortised time per query
-    NQ = int(os.environ.get("RK_MANY", "4"))
+    NQ = int(os.environ.get("RK_MANY", "4")) if many is None else many
     qtexts = ["which passage mentions the most relevant words"] + [" ".join(rs.choice(vocab) for _ in range(7)) for _ in range(NQ - 1)]
-    for scoring in ("likelihood", "generation"):
+    for scoring in (("likelihood", "generation") if NQ > 1 else ()):
         rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring=scoring, method="heapsort")
-        best, res0 = None, None
-        for rep in range(3):
+        best, res0, n_tok = None, None, 0
+        for rep in range(reps):
             items = [(q, [SearchResult(docid=d, score=s, text=rk.truncate(t, 128)) for d, s, t in docs]) for q in qtexts]
             t0 = time.perf_counter()
             with contextlib.redirect_stdout(io.StringIO()):
@@ -102,8 +105,11 @@ def main():
             best = dt if best is None else min(best, dt)
             res0 = [r.docid for r in res[0]][:10]
         assert res0 == out[f"{scoring}_batched"]["top10"], "rerank_many changed the ranking of the first query"
-        out[f"{scoring}_many{NQ}"] = {"ms_per_query": round(best * 1e3 / NQ, 1), "queries_per_call": NQ,
-                                      "compares": sum(c[0] for c in counters)}
+        n_cmp = sum(c[0] for c in counters)
+        avg_len = sum(c[1] for c in counters) / max(n_cmp, 1)
+        tf = n_cmp * bench.algorithmic_gflop_per_passage(dims, avg_len, 2) / 1e3 / best
+        out[f"{scoring}_many{NQ}"] = {"ms_per_query": round(best * 1e3 / NQ, 1), "queries_per_call": NQ, "compares": n_cmp,
+                                      "algorithmic_tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / 2500.0, 4)}
     if os.environ.get("RK_HOSTPROF"):                       # where the host time of one query goes (stderr)
         import cProfile, pstats
         rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring="generation", method="heapsort")
@@ -113,9 +119,15 @@ def main():
             rk.rerank("which passage mentions the most relevant words", ranking)
         pr.disable()
         pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(25)
-    for scoring in ("likelihood", "generation"):
-        assert out[f"{scoring}_batched"]["top10"] == out[f"{scoring}_one_by_one"]["top10"], "batched build phase changed the ranking"
-    print(json.dumps(out))
+    if one_by_one:
+        for scoring in ("likelihood", "generation"):
+            assert out[f"{scoring}_batched"]["top10"] == out[f"{scoring}_one_by_one"]["top10"], "batched build phase changed the ranking"
+    eng.close()
+    return out
+
+
+def main():
+    print(json.dumps(run()))
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc
 rm -rf $OUT; mkdir -p $OUT
-CMD="python $PWD/bench.py --steps ${PMC_STEPS:-16} --warmup 8 --no_cpu_baseline --no_profile"
+CMD="python $PWD/bench.py --steps ${PMC_STEPS:-16} --warmup 8 --no_cpu_baseline --no_profile --no_per_query --no_extras --regions 1"
 IFS=';' read -ra SETS <<< "${PMC_SETS:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE}"
 cd /tmp
 i=0
@@ -14,7 +14,7 @@ for set in "${SETS[@]}"; do
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT -o pass$i -- $CMD > $OUT/pass${i}_stdout.txt 2>&1
   echo "pass $i ($set) rc=$?"
 done
-KERNELS="${KERNELS:-attn_enc_short|gemm_pp2|rmsnorm}" python - <<'PY'
+KERNELS="${KERNELS:-attn_enc|gemm_pp2|xattn|gemm_skinny}" python - <<'PY'
 import csv, glob, os, re, collections, json
 out = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/pmc"
 pat = re.compile(os.environ["KERNELS"])

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 STEPS=${PROF_STEPS:-20}; WARM=${PROF_WARMUP:-10}   # a whole group of 10: every launch of the run then has the same M
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARM --no_cpu_baseline --no_profile --no_per_query --overlap 0"   # one stream: kernels run one at a time, so durations and counters belong to one kernel
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup $WARM --no_cpu_baseline --no_profile --no_per_query --no_extras --regions 1 --overlap 0"   # one stream: kernels run one at a time, so durations and counters belong to one kernel
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- $CMD > $OUT/bench_stdout.txt 2> $OUT/bench_stderr.txt
 echo "rocprofv3 stats rc=$?"
