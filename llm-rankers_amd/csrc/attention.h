@@ -672,18 +672,33 @@ __device__ __forceinline__ void attd_issue_vt(half4 (&d)[4], const unsigned (&va
 #ifndef ATTD_MINW
 #define ATTD_MINW 3
 #endif
-__global__ __launch_bounds__(384, ATTD_MINW) void attn_enc_dma_kernel(AttnEncArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char attd_smem[];
+// NG = 2 (the production form): a 768-thread workgroup runs TWO such six-wave groups side by side, each on its own heads
+// and its own 75 KiB of LDS.  Why not two 384-thread workgroups per CU, which LDS (2 x 75 KiB) and registers (166 -> three
+// waves per SIMD) allow and the occupancy API promises: the dispatcher places the six waves of a workgroup 2,2,1,1 over
+// the four SIMDs from a start of its own choosing, a second workgroup then needs exactly the complementary 1,1,2,2, and
+// it does not look for it - tools/probes/probe_resid.hip: 384-thread workgroups with >= 160 VGPRs run ONE per CU (the
+// kernel measured the same at 256 and at 512 workgroups).  Twelve waves of ONE workgroup always fit three per SIMD.  The
+// two groups share only the workgroup barriers (same sequence in both: same sequence length, same head count).
+template <int NG>
+__global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnEncArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char attd_smem_all[];
+  const int grp = NG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= 384));
+  unsigned char* const attd_smem = attd_smem_all + grp * ATTD_LDS_BYTES;
   half_t* const sbuf = (half_t*)attd_smem;                                  // three [192][64] row images
   float* const sLut = (float*)(attd_smem + 3 * ATTD_BUF_HALFS * 2);         // two bias tables (this head's / the next one's)
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(((int)threadIdx.x - grp * 384) >> 6);
   const int b = blockIdx.y;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;
   const int H = p.I >> 6;
-  const int h_first = blockIdx.x * p.heads_per_wg;
-  const int nh = min(H, h_first + p.heads_per_wg) - h_first;
+  // heads [h_first, h_first + nh_own) belong to this group; every group of the workgroup walks nh heads (group 0's count,
+  // the largest) so that all waves meet the same barriers - a group short of heads (H not a multiple of NG x heads_per_wg)
+  // repeats its last valid head, or head H-1, without storing
+  const int h_wg = blockIdx.x * NG * p.heads_per_wg;
+  const int nh = min(H - h_wg, p.heads_per_wg);
   if (nh <= 0 || L <= 0) return;                                            // uniform for the whole block
+  const int h_first = min(h_wg + grp * p.heads_per_wg, H - 1);
+  const int nh_own = max(0, min(H - (h_wg + grp * p.heads_per_wg), p.heads_per_wg));
   const int nkt = (L + 63) >> 6, nrows = nkt * 64;
   const bool dma_wave = 32 * wave < nrows;                                  // this wave's 32 rows exist (wave-uniform)
   const int q0 = wave * 32;
@@ -855,7 +870,9 @@ __global__ __launch_bounds__(384, ATTD_MINW) void attn_enc_dma_kernel(AttnEncArg
   int kb = 0, vb = 1, nb = 2;                             // buffers of K_h, V_h, K_h+1
   auto head = [&](auto lastc, int n) {
     constexpr bool LAST = decltype(lastc)::value;
-    const int h = h_first + n;
+    const int h = min(h_first + n, H - 1);
+    const int h_next = min(h_first + n + 1, H - 1);
+    const bool store_ok = n < nh_own;
     const int lane = opaque_lane();
     const LaneCtx c = lane_ctx(lane);
     const half_t* kbuf = sbuf + kb * ATTD_BUF_HALFS;
@@ -864,9 +881,9 @@ __global__ __launch_bounds__(384, ATTD_MINW) void attn_enc_dma_kernel(AttnEncArg
     // everyone is past the barrier that ended head h-1: its K and V buffers are free
     if (dma_wave) issue_rows(lane, 2, vb, h);
     if constexpr (!LAST) {
-      if (dma_wave) issue_rows(lane, 1, nb, h + 1);
+      if (dma_wave) issue_rows(lane, 1, nb, h_next);
       __builtin_amdgcn_sched_barrier(0);
-      issue_warm(c, h + 1);
+      issue_warm(c, h_next);
     }
     __builtin_amdgcn_sched_barrier(0);
     f32x16 s0, s1;
@@ -896,7 +913,7 @@ __global__ __launch_bounds__(384, ATTD_MINW) void attn_enc_dma_kernel(AttnEncArg
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!LAST) issue_q(c, h + 1);               // the head's last QK^T is done: qf is free (every wave, active or not)
+    if constexpr (!LAST) issue_q(c, h_next);              // the head's last QK^T is done: qf is free (every wave, active or not)
     __builtin_amdgcn_sched_barrier(0);
     unsigned pk[2][8];                                    // the context row pieces of this lane as packed halfs
     if (wave_active) {
@@ -930,7 +947,7 @@ __global__ __launch_bounds__(384, ATTD_MINW) void attn_enc_dma_kernel(AttnEncArg
         const auto y1 = __builtin_amdgcn_permlane32_swap(pk[o][3], pk[o][7], false, false);
         const attd_u32x4 lo = {x0[0], x1[0], x0[1], x1[1]};
         const attd_u32x4 hi = {y0[0], y1[0], y0[1], y1[1]};
-        if (c.qpos < L) {
+        if (c.qpos < L && store_ok) {
           *(attd_u32x4*)(dst + 32 * o) = lo;
           *(attd_u32x4*)(dst + 32 * o + 8) = hi;
         }

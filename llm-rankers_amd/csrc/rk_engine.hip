@@ -337,6 +337,8 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
     const dim3 b(SKINNY_THREADS);
     const unsigned gy = (unsigned)batch, gz = (unsigned)((M + 31) / 32);
     a.nb = (N + 31) / 32; a.nb_in = (K + 31) / 32;             // this kernel's producer blocks are 32 columns wide
+    // (tried and dropped, round 3: a 1-D launch that runs all row slabs of a column block on ONE XCD, so that a weight row is
+    // fetched into one L2 only - dec_gemm 0.337 vs 0.328 ms per step at 320 rows: the slabs are not bound by weight traffic)
     switch (epi) {
       case EPI_STORE_F16: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_STORE_F16, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
       case EPI_RESID_F32: hipLaunchKernelGGL((gemm_skinny_kernel<EPI_RESID_F32, 1>), dim3((N + 31) / 32, gy, gz), b, 0, st, a); break;
@@ -488,15 +490,23 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
       AttnEncArgs a{sl.qkv, sl.ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I, ppw, e->opt_attn_ko};
       const double att_flops = 4.0 * (double)sl.maxL * T * I;   // exact for uniform lengths, upper bound if ragged
       Bracket br(e, st, PC_ENC_ATTN, att_flops, (double)T * 4 * I * 2.0);
-      if (sl.maxL <= ATTS_MAXL && e->opt_attn_short == 5) {
-        static std::atomic<uint64_t> attr_done{0};
-        ensure_dynamic_lds((const void*)attn_enc_dma_kernel, ATTD_LDS_BYTES, attr_done);
-        // heads per workgroup: 4 amortise a workgroup's pipeline fill best (159 us per launch at 320 x 184 tokens against 172
-        // at 2 and 195 at 1); fewer when that would leave some of the 2 x 256 workgroup slots of the chip empty
+      if (sl.maxL <= ATTS_MAXL && (e->opt_attn_short == 5 || e->opt_attn_short == 6)) {
+        // 5: two six-wave groups per 768-thread workgroup (two head ranges side by side on a CU); 6: one group per workgroup.
+        // heads per group: 4 amortise a group's pipeline fill best; fewer when that would leave CUs without a workgroup
+        const int ng = e->opt_attn_short == 5 ? 2 : 1;
         int hpw = 4;
-        while (hpw > 1 && (long)sl.n_seq * ((d.n_heads + hpw - 1) / hpw) < 2L * e->n_cu) hpw >>= 1;
+        while (hpw > 1 && (long)sl.n_seq * ((d.n_heads + ng * hpw - 1) / (ng * hpw)) < (long)e->n_cu) hpw >>= 1;
         a.heads_per_wg = e->opt_attn_heads_per_wg > 0 ? e->opt_attn_heads_per_wg : hpw;
-        hipLaunchKernelGGL(attn_enc_dma_kernel, dim3((d.n_heads + a.heads_per_wg - 1) / a.heads_per_wg, sl.n_seq), dim3(384), ATTD_LDS_BYTES, st, a);
+        const dim3 grid((d.n_heads + ng * a.heads_per_wg - 1) / (ng * a.heads_per_wg), sl.n_seq);
+        if (ng == 2) {
+          static std::atomic<uint64_t> attr_done{0};
+          ensure_dynamic_lds((const void*)attn_enc_dma_kernel<2>, 2 * ATTD_LDS_BYTES, attr_done);
+          hipLaunchKernelGGL(attn_enc_dma_kernel<2>, grid, dim3(768), 2 * ATTD_LDS_BYTES, st, a);
+        } else {
+          static std::atomic<uint64_t> attr_done{0};
+          ensure_dynamic_lds((const void*)attn_enc_dma_kernel<1>, ATTD_LDS_BYTES, attr_done);
+          hipLaunchKernelGGL(attn_enc_dma_kernel<1>, grid, dim3(384), ATTD_LDS_BYTES, st, a);
+        }
       } else if (sl.maxL <= ATTS_MAXL && e->opt_attn_short == 1) {
         hipLaunchKernelGGL(attn_enc_pair_kernel<1>, dim3((npairs + ppw - 1) / ppw, sl.n_seq), dim3(384), ATTP_GROUP_LDS, st, a);
       } else if (sl.maxL <= ATTS_MAXL && e->opt_attn_short == 2) {
@@ -1863,7 +1873,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
 #endif
   if (!strcmp(key, "attn_heads_per_wg")) { e->opt_attn_heads_per_wg = value; return RK_OK; }   // 0 auto
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
-  if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 5 DMA kernel, 1 pair kernel, 2 / 4 plain short kernels, 0 tiled
+  if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 5 DMA kernel (two groups per workgroup), 6 DMA kernel (one group), 1 pair kernel, 2 / 4 plain short kernels, 0 tiled
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
     if (set_device(e) || sync_all(e)) return RK_ERR_HIP;
@@ -1941,6 +1951,12 @@ int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_fl
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_pp2_kernel<EPI_STORE_F16, 0>, 512, 163840); out[3] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_kernel<1>, 256, 0); out[4] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rmsnorm_kernel<4>, 256, 0); out[5] = (float)n;
+    if (max_floats >= 10) {
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_dma_kernel<1>, 384, ATTD_LDS_BYTES); out[6] = (float)n;
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_dma_kernel<2>, 768, 2 * ATTD_LDS_BYTES); out[7] = (float)n;
+      out[8] = out[9] = 0.f;
+      return 10;
+    }
     return 6;
   }
   const Slot& sl = e->slots[0];

@@ -268,10 +268,11 @@ def test_flan_t5_large_dims_vs_oracle_and_properties():
     for mode in (0, 1, 2):                               # tiled / register-prefetch pair / plain short kernel instead of the DMA one
         eng.set_option("attn_short", mode)
         np.testing.assert_array_equal(eng.score(batch, [0], ids), full)
-    eng.set_option("attn_short", 5)
-    for hpw in (1, 2, 16):                               # heads per workgroup of the DMA kernel: same bits
-        eng.set_option("attn_heads_per_wg", hpw)
-        np.testing.assert_array_equal(eng.score(batch, [0], ids), full)
+    for mode in (6, 5):                                  # DMA kernel with one / two head groups per workgroup,
+        eng.set_option("attn_short", mode)
+        for hpw in (1, 2, 16):                           # ... heads per group: same bits
+            eng.set_option("attn_heads_per_wg", hpw)
+            np.testing.assert_array_equal(eng.score(batch, [0], ids), full)
     eng.set_option("attn_heads_per_wg", 0)
     # cross-attention: query-side form (default for <= 32 decoder rows) vs materialised K/V projections — same math,
     # different rounding points
@@ -306,11 +307,13 @@ def test_encoder_attention_kernels_bit_identical_on_ragged_batches():
         for mode in (0, 1, 4):
             eng.set_option("attn_short", mode)
             np.testing.assert_array_equal(ctx(), ref, err_msg=f"attn_short={mode}")
-        eng.set_option("attn_short", 5)
-        for hpw in (0, 1, 2, 3, 16):
-            eng.set_option("attn_heads_per_wg", hpw)
-            np.testing.assert_array_equal(ctx(), ref, err_msg=f"DMA kernel, heads_per_wg={hpw}")
+        for mode in (5, 6):                              # two / one six-wave group(s) per workgroup
+            eng.set_option("attn_short", mode)
+            for hpw in (0, 1, 2, 3, 16):                 # (3 heads: a group short of heads repeats one without storing)
+                eng.set_option("attn_heads_per_wg", hpw)
+                np.testing.assert_array_equal(ctx(), ref, err_msg=f"DMA kernel {mode}, heads_per_wg={hpw}")
         eng.set_option("attn_heads_per_wg", 0)
+        eng.set_option("attn_short", 5)
         eng.close()
 
 

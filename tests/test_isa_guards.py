@@ -65,13 +65,16 @@ def test_attention_prefetch_registers_untouched_until_the_wait(isa):
     assert not any("scratch_" in l for l in body), "attention kernel spills"
 
 
-def test_dma_attention_keeps_its_dma_queue_and_its_asm_destinations(isa):
+@pytest.mark.parametrize("ng", [1, 2])
+def test_dma_attention_keeps_its_dma_queue_and_its_asm_destinations(isa, ng):
     """attn_enc_dma_kernel: K/V rows travel by LDS-DMA across barriers and Q rows / table entries by inline-asm loads.  The
     only vmcnt waits may be the kernel's own (inside ASM blocks) - a compiler-placed one means the waitcnt pass saw a
     tracked load or a scratch access and drains the DMA queue; no spills; no register written by an asm load is touched
     between its issue and the asm wait that follows it."""
-    body = kernel_body(isa, "_Z19attn_enc_dma_kernel11AttnEncArgs")
+    body = kernel_body(isa, f"_Z19attn_enc_dma_kernelILi{ng}EEv11AttnEncArgs")
     assert not any("scratch_" in l for l in body), "DMA attention kernel spills"
+    m = re.search(r"NumVgprs: (\d+)", "\n".join(isa[isa.index(body[-1]):isa.index(body[-1]) + 400]))
+    assert m and int(m.group(1)) <= 168, "more than 168 VGPRs: three waves per SIMD (two groups per CU) no longer fit"
     assert sum("global_load_lds_dwordx4" in l for l in body) == 16      # prologue K + {V, next K} + last head's V
     assert sum("ds_read_b64_tr_b16" in l for l in body) == 64
     pending, n_waits = set(), 0

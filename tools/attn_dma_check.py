@@ -38,14 +38,14 @@ def exactness():
         eng.set_option("attn_short", 0)
         tiled = ctx_of(eng, seqs, T, I)
         off = np.cumsum([0] + lens)
-        for hpw in (1, 2, 3, 16):
-            eng.set_option("attn_short", 5)
+        for mode, hpw in [(m, h) for m in (5, 6) for h in (1, 2, 3, 16)]:
+            eng.set_option("attn_short", mode)
             eng.set_option("attn_heads_per_wg", hpw)
             got = ctx_of(eng, seqs, T, I)
             d = np.abs(got - ref).reshape(T, dims.n_heads, 64).max(axis=2)
             same = bool(np.array_equal(got, ref))
             ok &= same
-            rec = {"check": "dma_vs_short", "heads": dims.n_heads, "heads_per_wg": hpw, "bit_identical": same,
+            rec = {"check": "dma_vs_short", "mode": mode, "heads": dims.n_heads, "heads_per_wg": hpw, "bit_identical": same,
                    "max_abs_diff": float(d.max()), "tiled_vs_short_identical": bool(np.array_equal(tiled, ref))}
             if not same:
                 rec["per_seq_head_max"] = [[float(f"{d[off[b]:off[b + 1], h].max():.3g}") for h in range(dims.n_heads)] for b in range(len(lens))]
@@ -71,7 +71,7 @@ def timing():
     slot_seqs = [[s for j in range(G) for s in _synth.synth_token_batch(B, L, L, dims.vocab, seed=929 + 8 * sl + j)]
                  for sl in range(eng.num_slots)]
     ref_scores = None
-    variants = [("pair", 1, 0)] + [("dma", 5, h) for h in (1, 2, 4, 8, 16)]
+    variants = [("pair", 1, 0)] + [("dma1", 6, h) for h in (2, 4)] + [("dma2", 5, h) for h in (1, 2, 4, 8)]
     for name, mode, hpw in variants:
         eng.set_option("attn_short", mode)
         eng.set_option("attn_heads_per_wg", hpw)
@@ -94,7 +94,7 @@ def timing():
                           "total_ms_per_step": round(sum(v["ms"] for v in rep.values()) / (2 * G), 3)}), flush=True)
     # whole-pipeline passages/s, interleaved A/B (two rounds)
     for rnd in range(2):
-        for name, mode, hpw in (("pair", 1, 0), ("dma", 5, 2), ("dma", 5, 4), ("dma", 5, 1)):
+        for name, mode, hpw in (("pair", 1, 0), ("dma1", 6, 4), ("dma2", 5, 2), ("dma2", 5, 4), ("dma2", 5, 1)):
             eng.set_option("attn_short", mode)
             eng.set_option("attn_heads_per_wg", hpw)
             pipe = bench.GroupPipeline(eng, slot_seqs, B, G, [0], [bench.YES_ID, bench.NO_ID])
