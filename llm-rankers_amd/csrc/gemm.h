@@ -20,7 +20,8 @@
 #include <type_traits>
 
 enum GemmEpi { EPI_STORE_F16 = 0, EPI_RESID_F32 = 1, EPI_GEGLU_F16 = 2, EPI_RELU_F16 = 3, EPI_STORE_F32 = 4, EPI_SWIGLU_F16 = 5,
-               EPI_ARGMAX_F32 = 6 };   // weight-streaming kernel only: per 32-column block the row maximum and its first index
+               EPI_ARGMAX_F32 = 6,     // weight-streaming kernel only: per 32-column block the row maximum and its first index
+               EPI_LSE_F32 = 7 };      // tiled kernels only (qlm head): per 32-column block (max, sum exp(x - max)) + the label's logit
 // gated epilogues: gate / up rows interleaved in groups of 32 by the weight packer, out = act(gate) * up
 #define EPI_IS_GATED(E) ((E) == EPI_GEGLU_F16 || (E) == EPI_SWIGLU_F16)
 
@@ -46,6 +47,9 @@ struct GemmArgs {
   const float* ssq_in; int nb_in; float eps_in;
   // EPI_ARGMAX_F32 (greedy head): C = float [M, ldc] block maxima, amax_idx = int [M, ldc] their first column (ldc = blocks)
   int* amax_idx;
+  // EPI_LSE_F32 (qlm head): C = float2 [M, ldc] (block max, sum of exp(x - block max)) per 32-column block (ldc = blocks);
+  // row m scores label lse_labels[m % lse_npos], whose logit goes to lse_xlab[m].  The logits never reach memory.
+  const int* lse_labels; int lse_npos; float* lse_xlab;
 };
 
 #define GEMM_BM 128
@@ -220,9 +224,51 @@ __device__ __forceinline__ void gemm_prefetch_residual(const GemmArgs& p, f32x16
 // Producer side of the folded RMSNorm (p.xraw != nullptr, fp32 residual epilogue only): next to the new fp32 rows the
 // epilogue writes them once more as fp16 x p.xs (the next GEMM's A operand) and the sum of their squares per row and
 // 64-column block (one wave = one block; fixed in-lane + DPP order, so any tile shape writes the same bits).
+// qlm head (ref: llmrankers/pointwise.py:73-79: logits -> CrossEntropyLoss): instead of [rows, vocab] fp32 logits (written and
+// read back: 2 x 4 x vocab bytes per row) the epilogue leaves, per row and 32-column MFMA fragment, the fragment's maximum
+// and sum of exp(x - maximum), plus the logit of the row's label; qlm_lse_kernel (misc_kernels.h) merges the blocks of a
+// row in block order.  A lane holds 16 of a fragment's 32 columns of its row, its partner (lane ^ 32) the others: fixed
+// in-lane order + one exchange, so every tile shape writes the same bits.
+template <int NI, int MI>
+__device__ __forceinline__ void gemm_epilogue_lse(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase, int lane,
+                                                  const float (&rsc)[MI]) {
+  const int l31 = lane & 31, hh = lane >> 5;
+  float2* stats = (float2*)p.C;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = mbase + mi * 32 + l31;
+    const bool row_ok = m < p.M;
+    const int label = row_ok ? p.lse_labels[m % p.lse_npos] : -1;
+    const float sc = rsc[mi];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n0 = nbase + ni * 32;
+      if (n0 >= p.N) continue;                              // uniform
+      float v[16], mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        v[r] = n < p.N ? acc[ni][mi][r] * sc : -INFINITY;
+        mx = fmaxf(mx, v[r]);
+        if (n == label) p.lse_xlab[m] = v[r];
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float se = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) se += __expf(v[r] - mx);
+      se += __shfl_xor(se, 32);
+      if (hh == 0 && row_ok) stats[(size_t)m * p.ldc + (n0 >> 5)] = make_float2(mx, se);
+    }
+  }
+}
+
 template <int EPI, int NI, int MI, bool RESID_IN_ACC = false, int ROWS = 32, int DEPTH = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase,
                                                      int lane, unsigned char* stage, const float (&rsc)[MI]) {
+  if constexpr (EPI == EPI_LSE_F32) {
+    gemm_epilogue_lse<NI, MI>(p, acc, mbase, nbase, lane, rsc);
+    return;
+  }
   const int l31 = lane & 31, hh = lane >> 5;
   constexpr bool GEGLU = EPI_IS_GATED(EPI);
   constexpr bool F32 = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32;

@@ -136,31 +136,32 @@ __global__ __launch_bounds__(256) void argmax_blocks_kernel(const float* __restr
   }
 }
 
-// QLM score (ref: pointwise.py:77-79): out[b] = -sum_t ( logsumexp(logits[b,t,:]) - logits[b,t,label_t] ).
-// One block per sequence; positions are summed in order (deterministic).
-__global__ __launch_bounds__(256) void qlm_ce_kernel(const float* __restrict__ logits, int ld, int n_cols,
-                                                     const int* __restrict__ labels, int n_pos,
-                                                     float* __restrict__ out) {
+// QLM score (ref: llmrankers/pointwise.py:77-79) from the fused head (gemm.h: EPI_LSE_F32): stats [rows, nblk] = (block max, sum exp(x - block max)), xlab [rows] =
+// the label's logit.  out[b] = -sum_t ( logsumexp_t - xlab[b, t] ), logsumexp_t = M + log(sum_blocks s * exp(m - M)).
+// One block per sequence; the blocks of a position are merged in a fixed order, the positions summed in order (deterministic).
+__global__ __launch_bounds__(256) void qlm_lse_kernel(const float2* __restrict__ stats, int nblk, const float* __restrict__ xlab,
+                                                      int n_pos, float* __restrict__ out) {
   __shared__ float sred[4];
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float total = 0.f;
   for (int t = 0; t < n_pos; ++t) {
-    const float* src = logits + (size_t)(b * n_pos + t) * ld;
+    const size_t row = (size_t)b * n_pos + t;
+    const float2* src = stats + row * nblk;
     float mx = -INFINITY;
-    for (int c = tid; c < n_cols; c += 256) mx = fmaxf(mx, src[c]);
+    for (int c = tid; c < nblk; c += 256) mx = fmaxf(mx, src[c].x);
     mx = wave_max(mx);
     if (lane == 0) sred[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
     __syncthreads();
     float se = 0.f;
-    for (int c = tid; c < n_cols; c += 256) se += expf(src[c] - mx);
+    for (int c = tid; c < nblk; c += 256) { const float2 v = src[c]; se += v.y * expf(v.x - mx); }
     se = wave_sum(se);
     if (lane == 0) sred[wave] = se;
     __syncthreads();
     se = sred[0] + sred[1] + sred[2] + sred[3];
     __syncthreads();
-    total += (mx + logf(se)) - src[labels[t]];
+    total += (mx + logf(se)) - xlab[row];
   }
   if (tid == 0) out[b] = -total;
 }

@@ -100,7 +100,8 @@ struct rk_engine {
   std::vector<EncLayerW> enc;
   std::vector<DecLayerW> dec;
   float *enc_final_ln = nullptr, *dec_final_ln = nullptr, *lut_enc = nullptr, *lut_dec = nullptr;
-  float* logits = nullptr; size_t logits_cap = 0;              // full-vocabulary logits (qlm); slot 0 only
+  float* logits = nullptr; size_t logits_cap = 0;              // qlm head: per-block (max, sum exp) pairs [rows, vocab/32] + label logits [rows]; slot 0 only
+  const int* lse_labels = nullptr; int lse_npos = 0; float* lse_xlab = nullptr;   // arguments of the next EPI_LSE_F32 launch
   float* amax_val = nullptr; int* amax_idx = nullptr; size_t amax_rows = 0;   // greedy head: per-row block maxima / first columns
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
@@ -356,6 +357,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
     case EPI_GEGLU_F16: launch_gemm_epi<EPI_GEGLU_F16>(e, st, a); break;
     case EPI_SWIGLU_F16: launch_gemm_epi<EPI_SWIGLU_F16>(e, st, a); break;
     case EPI_RELU_F16: launch_gemm_epi<EPI_RELU_F16>(e, st, a); break;
+    case EPI_LSE_F32: a.lse_labels = e->lse_labels; a.lse_npos = e->lse_npos; a.lse_xlab = e->lse_xlab; launch_gemm_epi<EPI_LSE_F32>(e, st, a); break;
     default: launch_gemm_epi<EPI_STORE_F32>(e, st, a); break;
   }
 }
@@ -691,7 +693,9 @@ int sync_all(rk_engine* e) {
 }
 
 int ensure_logits(rk_engine* e, size_t rows) {
-  const size_t need_elems = rows * (size_t)e->d.vocab;
+  // fused qlm head: rows x ceil(vocab / 32) float2 block statistics, then rows floats of label logits (the [rows, vocab]
+  // fp32 logits this buffer used to hold are never materialised)
+  const size_t need_elems = rows * (2 * ((size_t)(e->d.vocab + 31) / 32) + 1);
   if (need_elems <= e->logits_cap) return RK_OK;
   int rc = sync_all(e);
   if (rc) return rc;
@@ -1277,9 +1281,11 @@ int rk_t5_qlm(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, i
   if ((rc = encoder_then_handoff(e, sl, n_labels))) return rc;
   if ((rc = run_decoder(e, sl, n_labels))) return rc;
   rmsnorm(e, sd, sl.dhidden, e->dec_final_ln, sl.dxn, nullptr, M, head_scale(e));
-  gemm(e, sd, PC_HEAD, EPI_STORE_F32, sl.dxn, e->d.d_model, e->lm_head, e->d.d_model, e->logits, e->d.vocab, M, e->d.vocab, e->d.d_model);
-  hipLaunchKernelGGL(qlm_ce_kernel, dim3(n_seq), dim3(256), 0, sd, e->logits, e->d.vocab, e->d.vocab, sl.d_labels,
-                     n_labels, sl.d_scores);
+  // head GEMM with the log-sum-exp fused into its epilogue: per row and 32-column block (max, sum exp) + the label's logit
+  const int nblk = (e->d.vocab + 31) / 32;
+  e->lse_labels = sl.d_labels; e->lse_npos = n_labels; e->lse_xlab = e->logits + (size_t)M * nblk * 2;
+  gemm(e, sd, PC_HEAD, EPI_LSE_F32, sl.dxn, e->d.d_model, e->lm_head, e->d.d_model, e->logits, nblk, M, e->d.vocab, e->d.d_model);
+  hipLaunchKernelGGL(qlm_lse_kernel, dim3(n_seq), dim3(256), 0, sd, (const float2*)e->logits, nblk, e->lse_xlab, n_labels, sl.d_scores);
   HIPCHK(e, hipMemcpyAsync(sl.h_scores, sl.d_scores, (size_t)n_seq * sizeof(float), hipMemcpyDeviceToHost, sd));
   if ((rc = mark_decoder_done(e, sl))) return rc;
   if ((rc = sync_all(e))) return rc;
