@@ -121,6 +121,12 @@ typedef struct rk_llama_desc {
   int32_t max_tokens, max_seqs;      /* capacity: prompt tokens per call (sum), prompts per call */
 } rk_llama_desc;
 int rk_llama_create(const rk_llama_desc* desc, int device_ordinal, rk_engine** out);
+/* rope type "llama3" (Llama-3.1 / 3.2 checkpoints; hf: modeling_rope_utils.py _compute_llama3_parameters, reached through
+ * AutoModelForCausalLM.from_pretrained at ref: llmrankers/setwise.py:65-69): inverse frequencies whose wavelength exceeds
+ * original_max_pos / low_freq_factor are divided by factor, those between original_max_pos / high_freq_factor and that are
+ * interpolated.  Call between rk_llama_create and rk_engine_finalize (the rotary tables are built there); never calling
+ * it = the default rope type. */
+int rk_llama_set_rope_scaling(rk_engine* e, float factor, float low_freq_factor, float high_freq_factor, int original_max_pos);
 /* next token of every prompt: first arg-max over the whole vocabulary of the logits at its last position */
 int rk_llama_greedy1(rk_engine* e, const int32_t* tokens, const int32_t* seq_offsets, int n_seq, int32_t* out_tokens);
 /* the same logits for a few vocabulary rows only -> out_logits[n_seq][n_out] fp32 (label scoring, tests) */

@@ -679,6 +679,10 @@ __device__ __forceinline__ void attd_issue_vt(half4 (&d)[4], const unsigned (&va
 // it does not look for it - tools/probes/probe_resid.hip: 384-thread workgroups with >= 160 VGPRs run ONE per CU (the
 // kernel measured the same at 256 and at 512 workgroups).  Twelve waves of ONE workgroup always fit three per SIMD.  The
 // two groups share only the workgroup barriers (same sequence in both: same sequence length, same head count).
+// (Tried and dropped, round 3: a full-prefetch form of the one-group kernel - four row buffers, K AND V of the next head
+// landing a whole head ahead, the next Q rows in registers of their own, context rows stored a head later, ONE barrier per
+// head, 178 VGPRs - bit-identical, 177 us per launch against 161 for the one-group and 145 for the two-group form: the
+// time of a head is the instruction latency of its own waves, not the memory waits the form removes.)
 template <int NG>
 __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnEncArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char attd_smem_all[];

@@ -115,6 +115,7 @@ struct rk_engine {
   // decoder-only family (rk_llama_*): family 1 reuses `d` for the shared fields (vocab, d_model = hidden, d_ff =
   // intermediate, eps, capacities) so that the helpers below serve both families
   int family = 0; rk_llama_desc ld{};
+  float rope_factor = 0.f, rope_low = 1.f, rope_high = 4.f; int rope_orig = 0;   // rope type llama3 when rope_factor > 0
   std::vector<LlamaLayerW> ll; float *l_final_ln = nullptr, *rope_cos = nullptr, *rope_sin = nullptr; int* d_pos = nullptr;
   // decoder chains as HIP graphs: key = everything the launch parameters of a chain depend on
   struct GraphEntry { int seen = 0; bool failed = false; hipGraphExec_t exec = nullptr; };
@@ -1562,11 +1563,19 @@ static int llama_finalize(rk_engine* e) {
     RC(upload(e, &w.down, H(p + ".mlp.down_proj.weight").data(), (size_t)dm * F));
   }
   e->host.clear();
-  {   // rotary tables, float32 like hf: modeling_llama.py:94-127 (default rope type): freq_i = theta^(-2i/128)
+  {   // rotary tables, float32 like hf: modeling_llama.py:94-127: freq_i = theta^(-2i/128), then the llama3 rope type's
+      // wavelength-dependent scaling (hf: modeling_rope_utils.py _compute_llama3_parameters) when it was asked for
     const size_t Tc = l.max_tokens;
     std::vector<float> c(Tc * 64), sn(Tc * 64);
     for (int i = 0; i < 64; ++i) {
-      const float inv = 1.0f / powf(l.rope_theta, (float)(2 * i) / 128.0f);
+      float inv = 1.0f / powf(l.rope_theta, (float)(2 * i) / 128.0f);
+      if (e->rope_factor > 0.f) {
+        const float orig = (float)e->rope_orig, wavelen = 6.283185307179586f / inv;
+        const float scaled = wavelen > orig / e->rope_low ? inv / e->rope_factor : inv;
+        const float smooth = (orig / wavelen - e->rope_low) / (e->rope_high - e->rope_low);
+        const bool medium = !(wavelen < orig / e->rope_high) && !(wavelen > orig / e->rope_low);
+        inv = medium ? (1.0f - smooth) * scaled / e->rope_factor + smooth * scaled : scaled;
+      }
       for (size_t t = 0; t < Tc; ++t) { const float a = (float)t * inv; c[t * 64 + i] = cosf(a); sn[t * 64 + i] = sinf(a); }
     }
     RC(upload(e, &e->rope_cos, c.data(), c.size())); RC(upload(e, &e->rope_sin, sn.data(), sn.size()));
@@ -1652,6 +1661,16 @@ int rk_llama_last_logits(rk_engine* e, const int32_t* tokens, const int32_t* seq
   HIPCHK(e, hipStreamSynchronize(st));
   HIPCHK(e, hipGetLastError());
   memcpy(out_logits, sl.h_scores, (size_t)n_seq * n_out * sizeof(float));
+  return RK_OK;
+}
+
+int rk_llama_set_rope_scaling(rk_engine* e, float factor, float low_freq_factor, float high_freq_factor, int original_max_pos) {
+  if (!e) return RK_ERR_INVALID;
+  if (e->family != 1) return fail(e, RK_ERR_STATE, "rope scaling applies to Llama engines (rk_llama_create)");
+  if (e->finalized) return fail(e, RK_ERR_STATE, "rk_llama_set_rope_scaling must precede rk_engine_finalize (the rotary tables are built there)");
+  if (!(factor > 0.f) || !(high_freq_factor > low_freq_factor) || !(low_freq_factor > 0.f) || original_max_pos <= 0)
+    return fail(e, RK_ERR_INVALID, "bad llama3 rope scaling (factor %g, low %g, high %g, original_max_position_embeddings %d)", factor, low_freq_factor, high_freq_factor, original_max_pos);
+  e->rope_factor = factor; e->rope_low = low_freq_factor; e->rope_high = high_freq_factor; e->rope_orig = original_max_pos;
   return RK_OK;
 }
 

@@ -59,6 +59,7 @@ ABI = {
     "rk_t5_read_scores": (C.c_int, [C.c_void_p, _f32p, C.c_int]),
     "rk_t5_scores_device_ptr": (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
     "rk_llama_create": (C.c_int, [_P(RkLlamaDesc), C.c_int, _P(C.c_void_p)]),
+    "rk_llama_set_rope_scaling": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int]),
     "rk_llama_greedy1": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, _i32p]),
     "rk_llama_last_logits": (C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, _i32p, C.c_int, _f32p]),
     "rk_comm_unique_id": (C.c_int, [_P(C.c_uint8), C.c_int]),
@@ -370,6 +371,9 @@ class RkLlamaEngine(RkEngine):
         self.h = h
         self.device = device
         self.comm_rank, self.comm_world = 0, 1
+        if getattr(dims, "rope_scaling", None) is not None:          # rope type llama3: before finalize builds the rotary tables
+            f, lo, hi, orig = dims.rope_scaling
+            self._chk(self.lib.rk_llama_set_rope_scaling(self.h, float(f), float(lo), float(hi), int(orig)))
 
     def greedy1(self, seqs: Sequence[Sequence[int]]) -> np.ndarray:
         tok, off = pack_ragged(seqs)

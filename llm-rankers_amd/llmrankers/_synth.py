@@ -13,7 +13,7 @@ the oracle (fp32 math) and the engine (fp16 MFMA inputs) see is the same set of 
 from __future__ import annotations
 
 from dataclasses import dataclass, asdict
-from typing import Dict, Iterator, Tuple
+from typing import Dict, Iterator, Optional, Tuple
 
 import numpy as np
 
@@ -111,13 +111,21 @@ class LlamaDims:
     tied_head: bool = False
     bos_token_id: int = 1
     eos_token_id: int = 2
+    # rope_type "llama3" (Llama-3.1 / 3.2 checkpoints; hf: modeling_rope_utils.py _compute_llama3_parameters):
+    # (factor, low_freq_factor, high_freq_factor, original_max_position_embeddings), None = default rope type
+    rope_scaling: Optional[Tuple[float, float, float, int]] = None
 
     def to_hf_config(self) -> dict:
+        scaling = None
+        if self.rope_scaling is not None:
+            f, lo, hi, orig = self.rope_scaling
+            scaling = {"rope_type": "llama3", "factor": float(f), "low_freq_factor": float(lo), "high_freq_factor": float(hi),
+                       "original_max_position_embeddings": int(orig)}
         return {
             "architectures": ["LlamaForCausalLM"], "model_type": "llama", "vocab_size": self.vocab,
             "hidden_size": self.hidden, "intermediate_size": self.intermediate, "num_hidden_layers": self.n_layers,
             "num_attention_heads": self.n_heads, "num_key_value_heads": self.n_kv_heads, "head_dim": self.head_dim,
-            "hidden_act": "silu", "rms_norm_eps": self.eps, "rope_theta": self.rope_theta, "rope_scaling": None,
+            "hidden_act": "silu", "rms_norm_eps": self.eps, "rope_theta": self.rope_theta, "rope_scaling": scaling,
             "max_position_embeddings": 8192, "attention_bias": False, "mlp_bias": False,
             "tie_word_embeddings": bool(self.tied_head), "bos_token_id": self.bos_token_id, "eos_token_id": self.eos_token_id,
             "use_cache": True,
@@ -129,8 +137,12 @@ class LlamaDims:
             raise NotImplementedError("only bias-free SwiGLU Llama configurations are supported by the MI355X engine")
         rope = cfg.get("rope_parameters") or {}
         scaling = cfg.get("rope_scaling") or ({k: v for k, v in rope.items() if k != "rope_theta"} if rope.get("rope_type", "default") != "default" else None)
+        rs = None
         if scaling and scaling.get("rope_type", scaling.get("type", "default")) != "default":
-            raise NotImplementedError(f"rope scaling {scaling} is not supported by the MI355X engine (Llama-3-8B uses plain RoPE)")
+            if scaling.get("rope_type", scaling.get("type")) != "llama3":
+                raise NotImplementedError(f"rope scaling {scaling} is not supported by the MI355X engine (default and llama3 rope types are)")
+            rs = (float(scaling["factor"]), float(scaling["low_freq_factor"]), float(scaling["high_freq_factor"]),
+                  int(scaling.get("original_max_position_embeddings") or cfg.get("max_position_embeddings")))
         heads = cfg["num_attention_heads"]
         eos = cfg.get("eos_token_id", 2)
         return LlamaDims(vocab=cfg["vocab_size"], hidden=cfg["hidden_size"], n_heads=heads,
@@ -139,13 +151,18 @@ class LlamaDims:
                          intermediate=cfg["intermediate_size"], n_layers=cfg["num_hidden_layers"],
                          rope_theta=float(cfg.get("rope_theta") or rope.get("rope_theta") or 10000.0),
                          eps=cfg.get("rms_norm_eps", 1e-6), tied_head=bool(cfg.get("tie_word_embeddings", False)),
-                         bos_token_id=cfg.get("bos_token_id", 1) or 1, eos_token_id=eos[0] if isinstance(eos, list) else eos)
+                         bos_token_id=cfg.get("bos_token_id", 1) or 1, eos_token_id=eos[0] if isinstance(eos, list) else eos,
+                         rope_scaling=rs)
 
 
 LLAMA_3_8B = LlamaDims(vocab=128256, hidden=4096, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336, n_layers=32,
                        bos_token_id=128000, eos_token_id=128001)
 # toy: kernel-friendly (head_dim 128 like every Llama-3), grouped-query (4 q heads on 2 kv heads), q width != hidden
 TOY_LLAMA = LlamaDims(vocab=256, hidden=256, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=512, n_layers=2)
+# the same with Llama-3.1's rope type; a short original context and a small base so that most of the 64 frequencies fall in
+# the scaled and the interpolated bands at toy sequence lengths
+TOY_LLAMA3ROPE = LlamaDims(vocab=256, hidden=256, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=512, n_layers=2,
+                           rope_theta=10000.0, rope_scaling=(8.0, 1.0, 4.0, 32))
 
 
 def llama_tensor_specs(d: "LlamaDims") -> Iterator[Tuple[str, Tuple[int, ...], float, bool]]:
@@ -170,7 +187,7 @@ def llama_tensor_specs(d: "LlamaDims") -> Iterator[Tuple[str, Tuple[int, ...], f
 NAMED_DIMS = {
     "flan-t5-small": FLAN_T5_SMALL, "flan-t5-base": FLAN_T5_BASE, "flan-t5-large": FLAN_T5_LARGE,
     "flan-t5-xl": FLAN_T5_XL, "toy-gated-untied": TOY_GATED_UNTIED, "toy-relu-tied": TOY_RELU_TIED, "toy-monot5": TOY_MONOT5,
-    "llama-3-8b": LLAMA_3_8B, "toy-llama": TOY_LLAMA,
+    "llama-3-8b": LLAMA_3_8B, "toy-llama": TOY_LLAMA, "toy-llama3rope": TOY_LLAMA3ROPE,
 }
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)

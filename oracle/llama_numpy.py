@@ -21,9 +21,26 @@ def rmsnorm(x: np.ndarray, w: np.ndarray, eps: float) -> np.ndarray:
     return w * (x * (1.0 / np.sqrt(var + np.float32(eps))))
 
 
-def rope_tables(n_pos: int, head_dim: int, theta: float):
-    """hf: modeling_llama.py:94-127 (default rope type): cos / sin [n_pos, head_dim], fp32 like the reference's CPU path."""
+def rope_inv_freq(head_dim: int, theta: float, scaling=None) -> np.ndarray:
+    """Inverse frequencies [head_dim / 2], fp32.  scaling = (factor, low_freq_factor, high_freq_factor,
+    original_max_position_embeddings): rope type "llama3" (hf: modeling_rope_utils.py _compute_llama3_parameters) -
+    wavelengths above original/low are divided by factor, those between original/high and original/low interpolated;
+    None: the default rope type (hf: modeling_llama.py:94-127)."""
     inv_freq = (1.0 / (np.float32(theta) ** (np.arange(0, head_dim, 2, dtype=np.float32) / np.float32(head_dim)))).astype(np.float32)
+    if scaling is not None:
+        factor, low, high, orig = (np.float32(scaling[0]), np.float32(scaling[1]), np.float32(scaling[2]), np.float32(scaling[3]))
+        wavelen = (np.float32(2.0 * np.pi) / inv_freq).astype(np.float32)
+        scaled = np.where(wavelen > orig / low, inv_freq / factor, inv_freq).astype(np.float32)
+        smooth = ((orig / wavelen - low) / (high - low)).astype(np.float32)
+        smoothed = ((np.float32(1.0) - smooth) * scaled / factor + smooth * scaled).astype(np.float32)
+        medium = ~(wavelen < orig / high) & ~(wavelen > orig / low)
+        inv_freq = np.where(medium, smoothed, scaled).astype(np.float32)
+    return inv_freq
+
+
+def rope_tables(n_pos: int, head_dim: int, theta: float, scaling=None):
+    """hf: modeling_llama.py:94-127: cos / sin [n_pos, head_dim], fp32 like the reference's CPU path."""
+    inv_freq = rope_inv_freq(head_dim, theta, scaling)
     freqs = np.arange(n_pos, dtype=np.float32)[:, None] * inv_freq[None, :]
     emb = np.concatenate([freqs, freqs], axis=-1)
     return np.cos(emb).astype(np.float32), np.sin(emb).astype(np.float32)
@@ -47,7 +64,7 @@ class LlamaOracle:
         d = self.d
         L = len(ids)
         h = self.w["model.embed_tokens.weight"][np.asarray(ids, dtype=np.int64)]
-        cos, sin = rope_tables(L, d.head_dim, d.rope_theta)
+        cos, sin = rope_tables(L, d.head_dim, d.rope_theta, getattr(d, "rope_scaling", None))
         causal = np.where(np.arange(L)[None, :] > np.arange(L)[:, None], np.float32(np.finfo(np.float32).min), np.float32(0.0))
         rep = d.n_heads // d.n_kv_heads
         for i in range(d.n_layers):

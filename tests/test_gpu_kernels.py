@@ -855,3 +855,86 @@ def test_llama_3_8b_widths_one_compare_vs_oracle():
     np.testing.assert_array_equal(eng.last_logits(seqs[:1], labels)[0], got[0])
     np.testing.assert_array_equal(eng.last_logits(seqs[1:], labels)[0], got[1])
     eng.close()
+
+
+def test_llama3_rope_scaling_on_the_engine_vs_hf_golden():
+    """rope type "llama3" (Llama-3.1 / 3.2 checkpoints; rk_llama_set_rope_scaling before finalize): last-position logits of
+    ragged prompts vs HF LlamaForCausalLM (tests/golden/model_llama3rope.npz) and vs the oracle; the default rope type on
+    the same weights must NOT match (a scaling that is silently ignored would)."""
+    from llmrankers import _synth
+    from llmrankers._engine import RkLlamaEngine
+    g = np.load(os.path.join(GOLD, "model_llama3rope.npz"))
+    dims = _synth.NAMED_DIMS["toy-llama3rope"]
+    state = _synth.synth_state_dict(dims, seed=int(g["seed"]), gain=float(g["gain"]))
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    seqs = [g["tokens"][off[i]:off[i + 1]].astype(np.int32) for i in range(len(g["lens"]))]
+    want = g["last_logits"]
+    ids = list(range(dims.vocab))
+    eng = RkLlamaEngine(dims, device=0, max_tokens=2048, max_seqs=8).load_state(state.items())
+    got = eng.last_logits(seqs, ids)
+    scale = float(np.abs(want).max())
+    assert np.abs(got - want).max() < 8e-3 * scale, (np.abs(got - want).max(), scale)
+    np.testing.assert_array_equal(eng.greedy1(seqs)[np.sort(want, axis=1)[:, -1] - np.sort(want, axis=1)[:, -2] > 0.05 * scale],
+                                  np.argmax(want, axis=1)[np.sort(want, axis=1)[:, -1] - np.sort(want, axis=1)[:, -2] > 0.05 * scale])
+    eng.close()
+    plain = _synth.LlamaDims(**{**dims.__dict__, "rope_scaling": None})
+    eng2 = RkLlamaEngine(plain, device=0, max_tokens=2048, max_seqs=8).load_state(state.items())
+    assert np.abs(eng2.last_logits(seqs, ids) - want).max() > 5 * 8e-3 * scale
+    eng2.close()
+
+
+def test_llama_3_8b_full_depth_vs_oracle_golden():
+    """BASELINE.json configs[4] at FULL depth: Llama-3-8B dimensions, all 32 layers, one 700-token setwise-sized prompt; the
+    label logits and the greedy token against the fp32 oracle's (tests/golden/llama8b_full_depth.json, generated once by
+    tools/make_llama8b_golden.py - 32 GB of fp32 weights do not fit a test run on the host).  The 8 G synthetic weights are
+    regenerated here from their counters and streamed into the engine."""
+    from llmrankers import _synth
+    from llmrankers._engine import RkLlamaEngine
+    path = os.path.join(GOLD, "llama8b_full_depth.json")
+    if not os.path.exists(path):
+        pytest.skip("golden not generated")
+    with open(path) as f:
+        gold = json.load(f)
+    dims = _synth.NAMED_DIMS[gold["dims"]]
+    eng = RkLlamaEngine(dims, device=0, max_tokens=2048, max_seqs=4)
+    eng.load_state(_synth.synth_tensors(dims, seed=gold["seed"], threads=min(48, os.cpu_count() or 8)))
+    ids = _synth.synth_token_batch(1, gold["prompt_len"], gold["prompt_len"], dims.vocab, seed=gold["prompt_seed"])
+    got = eng.last_logits(ids, gold["label_ids"])[0]
+    want = np.asarray(gold["label_logits"], dtype=np.float32)
+    scale = gold["logit_abs_max"]
+    err = float(np.abs(got - want).max())
+    print(f"[llama8b full depth] max |label logit - oracle| = {err:.4f} at logit scale {scale:.3f}")
+    assert err < 2e-2 * scale, (err, scale)
+    top = eng.last_logits(ids, gold["top_ids"])[0]
+    assert np.abs(top - np.asarray(gold["top_logits"], dtype=np.float32)).max() < 2e-2 * scale
+    if gold["top_logits"][0] - gold["top_logits"][1] > 4e-2 * scale:
+        assert int(eng.greedy1(ids)[0]) == gold["top_ids"][0]
+    eng.close()
+
+
+def test_flan_t5_large_full_batch_vs_hf_golden():
+    """BASELINE.json configs[1] at full size against the reference's arithmetic: the whole bench batch (32 x 184 tokens) and
+    a ragged batch (32 passages of 96..184 tokens, the S2 workload) at flan-t5-large dimensions vs HF fp32 logits generated
+    once in the build container (tools/make_large_batch_golden.py): probabilities within 1e-3 (north_star's tolerance),
+    same order wherever the reference's adjacent scores differ by more than the tolerance."""
+    from llmrankers import _synth
+    path = os.path.join(GOLD, "config2_large_batch.npz")
+    if not os.path.exists(path):
+        pytest.skip("golden not generated")
+    g = np.load(path)
+    dims = _synth.FLAN_T5_LARGE
+    eng = _engine(dims, _synth.synth_state_dict(dims, seed=int(g["seed"]), threads=16), max_tokens=8192, max_seqs=32, max_dec_len=4)
+    ids = g["ids"].tolist()
+    for tag in ("uniform", "ragged"):
+        n, lo, hi, seed = (int(x) for x in g[f"{tag}.args"])
+        seqs = _synth.synth_token_batch(n, lo, hi, dims.vocab, seed=seed)
+        got, want = eng.score(seqs, [0], ids), g[f"{tag}.logits"]
+        p_got, p_want = _sigm(got[:, 0] - got[:, 1]), _sigm(want[:, 0] - want[:, 1])
+        err = float(np.abs(p_got - p_want).max())
+        print(f"[{tag}] max |P(yes) - HF fp32| over {n} passages = {err:.2e}")
+        assert err < SCORE_TOL, (tag, err)
+        order_got, order_want = np.argsort(-p_got, kind="stable"), np.argsort(-p_want, kind="stable")
+        gaps = np.abs(np.diff(p_want[order_want]))
+        if gaps.min() > 2 * SCORE_TOL:
+            np.testing.assert_array_equal(order_got, order_want)
+    eng.close()

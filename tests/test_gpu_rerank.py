@@ -249,8 +249,8 @@ def test_config3_full_size_setwise_query_flan_t5_large():
 
 def test_rerank_many_equals_one_query_at_a_time_on_the_engine(cases, stack):
     """rerank_many on the HIP engine: the recorded reference cases of one checkpoint handed over together - pointwise: all
-    batches in one launch sequence; setwise heapsort: the queries' sift-down chains in lockstep, one engine call per step -
-    give per query exactly (bit for bit: scores, order, caller lists, counters) what rerank() gives alone."""
+    batches in one launch sequence; setwise heapsort and bubblesort: the queries' sort chains in lockstep, one engine call
+    per step - give per query exactly (bit for bit: scores, order, caller lists, counters) what rerank() gives alone."""
     from llmrankers.rankers import SearchResult
 
     def key(c):
@@ -258,7 +258,7 @@ def test_rerank_many_equals_one_query_at_a_time_on_the_engine(cases, stack):
 
     groups = {}
     for c in cases:
-        if c.get("raises") or (c["kind"] == "setwise" and (c["method"] != "heapsort" or c["num_permutation"] != 1)):
+        if c.get("raises") or (c["kind"] == "setwise" and c["num_permutation"] != 1):     # heapsort AND bubblesort drivers
             continue
         groups.setdefault(key(c), []).append(c)
     checked = 0
@@ -284,7 +284,7 @@ def test_rerank_many_equals_one_query_at_a_time_on_the_engine(cases, stack):
         if base["kind"] == "setwise":
             assert [[r.docid for r in ranking] for ranking in rankings] == lists
         checked += 1
-    assert checked >= 6
+    assert checked >= 8 and any(k[2] == "bubblesort" for k in groups)
 
 
 def tokenize_ids(rk, query, window):

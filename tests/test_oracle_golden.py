@@ -116,3 +116,30 @@ def test_llama_oracle_matches_hf_llama_logits():
     full = orc.hidden_states(seqs[1]) @ head.T
     assert np.abs(full - g["full_logits_seq1"]).max() < 2e-4 * max(1.0, np.abs(g["full_logits_seq1"]).max())
     np.testing.assert_array_equal(orc.greedy1(seqs), np.argmax(g["last_logits"], axis=-1))
+
+
+def test_llama3_rope_scaling_oracle_matches_hf():
+    """rope type "llama3" (Llama-3.1 / 3.2 checkpoints the reference loads through AutoModelForCausalLM, ref: setwise.py:65-69):
+    oracle/llama_numpy.py's scaled inverse frequencies equal HF's rotary_emb.inv_freq, and its logits equal HF
+    LlamaForCausalLM's on a toy checkpoint whose frequencies fall in all three bands (tools/make_goldens.py
+    --only-llama3rope); the config round trip keeps the scaling."""
+    from llmrankers import _synth
+    from oracle.llama_numpy import LlamaOracle, rope_inv_freq
+    g = np.load(os.path.join(GOLD, "model_llama3rope.npz"))
+    dims = _synth.NAMED_DIMS["toy-llama3rope"]
+    assert _synth.LlamaDims.from_hf_config(dims.to_hf_config()).rope_scaling == dims.rope_scaling
+    assert _synth.LlamaDims.from_hf_config(_synth.TOY_LLAMA.to_hf_config()).rope_scaling is None
+    np.testing.assert_allclose(rope_inv_freq(dims.head_dim, dims.rope_theta, dims.rope_scaling), g["inv_freq"], rtol=2e-6)
+    assert not np.allclose(g["inv_freq"], rope_inv_freq(dims.head_dim, dims.rope_theta), rtol=1e-3)    # the scaling is not a no-op
+    state = _synth.synth_state_dict(dims, seed=int(g["seed"]), gain=float(g["gain"]))
+    orc = LlamaOracle(dims, state)
+    off = np.concatenate([[0], np.cumsum(g["lens"])])
+    seqs = [g["tokens"][off[i]:off[i + 1]] for i in range(len(g["lens"]))]
+    got = orc.last_logits(seqs)
+    assert np.abs(got - g["last_logits"]).max() < 2e-4 * max(1.0, np.abs(g["last_logits"]).max())
+    full = orc.hidden_states(seqs[3]) @ orc.w["lm_head.weight"].T
+    assert np.abs(full - g["full_logits_seq3"]).max() < 2e-4 * max(1.0, np.abs(g["full_logits_seq3"]).max())
+    # the default rope type on the same weights gives different logits: the test would notice a scaling that is ignored
+    plain = LlamaOracle(_synth.LlamaDims(**{**dims.__dict__, "rope_scaling": None}), state).last_logits(seqs)
+    assert np.abs(plain - g["last_logits"]).max() > 50 * 2e-4
+

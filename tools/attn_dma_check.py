@@ -71,7 +71,7 @@ def timing():
     slot_seqs = [[s for j in range(G) for s in _synth.synth_token_batch(B, L, L, dims.vocab, seed=929 + 8 * sl + j)]
                  for sl in range(eng.num_slots)]
     ref_scores = None
-    variants = [("pair", 1, 0)] + [("dma1", 6, h) for h in (2, 4)] + [("dma2", 5, h) for h in (1, 2, 4, 8)]
+    variants = [("pair", 1, 0)] + [("dma1", 6, 4)] + [("dma2", 5, h) for h in (1, 2, 4)]
     for name, mode, hpw in variants:
         eng.set_option("attn_short", mode)
         eng.set_option("attn_heads_per_wg", hpw)
@@ -94,7 +94,7 @@ def timing():
                           "total_ms_per_step": round(sum(v["ms"] for v in rep.values()) / (2 * G), 3)}), flush=True)
     # whole-pipeline passages/s, interleaved A/B (two rounds)
     for rnd in range(2):
-        for name, mode, hpw in (("pair", 1, 0), ("dma1", 6, 4), ("dma2", 5, 2), ("dma2", 5, 4), ("dma2", 5, 1)):
+        for name, mode, hpw in (("pair", 1, 0), ("dma1", 6, 4), ("dma2", 5, 2), ("dma2", 5, 4)):
             eng.set_option("attn_short", mode)
             eng.set_option("attn_heads_per_wg", hpw)
             pipe = bench.GroupPipeline(eng, slot_seqs, B, G, [0], [bench.YES_ID, bench.NO_ID])

@@ -494,6 +494,37 @@ def llama_goldens(ref_rankers, ref_setwise, ckpt_dir):
     print(f"[llama_cases] {len(cases)} cases, outputs seen: {outs[:12]}; reference printed 'Unexpected output' {sink.getvalue().count('Unexpected output')}x")
 
 
+def add_llama3rope():
+    """Incremental: HF LlamaForCausalLM logits of the toy checkpoint with rope type "llama3" (Llama-3.1 / 3.2's scaling,
+    hf: modeling_rope_utils.py _compute_llama3_parameters) -> tests/golden/model_llama3rope.npz.  Pins oracle/llama_numpy.py's
+    rope_tables(scaling=...) and, through it, the engine's rk_llama_set_rope_scaling."""
+    import tempfile
+    import torch
+    from transformers import AutoModelForCausalLM
+    spec = {"dims": "toy-llama3rope", "seed": 23, "gain": 2.0}
+    tmp = tempfile.mkdtemp(prefix="rk_gold_")
+    ck = os.path.join(tmp, "ckpt_llama3rope")
+    _synth.write_checkpoint(ck, spec)
+    model = AutoModelForCausalLM.from_pretrained(ck, torch_dtype=torch.float32).eval()
+    rp = getattr(model.config, "rope_parameters", None) or getattr(model.config, "rope_scaling", None)
+    assert rp and rp.get("rope_type") == "llama3", rp
+    inv = model.model.rotary_emb.inv_freq.numpy()
+    rs = np.random.RandomState(909)
+    lens = [9, 40, 1, 150, 64]
+    seqs = [rs.randint(6, model.config.vocab_size, size=n).astype(np.int64) for n in lens]
+    out = {"lens": np.array(lens), "tokens": np.concatenate(seqs), "inv_freq": inv, "seed": np.array(spec["seed"]), "gain": np.array(spec["gain"])}
+    last = []
+    with torch.no_grad():
+        for i, s_ in enumerate(seqs):
+            lg = model(input_ids=torch.tensor(s_)[None]).logits[0].numpy()
+            last.append(lg[-1])
+            if i == 3:
+                out["full_logits_seq3"] = lg
+    out["last_logits"] = np.stack(last)
+    np.savez_compressed(os.path.join(GOLD, "model_llama3rope.npz"), **out)
+    print(f"[model_llama3rope] inv_freq[:4]={inv[:4]}, [-4:]={inv[-4:]}; last-position logits range {out['last_logits'].min():.3f}..{out['last_logits'].max():.3f}")
+
+
 def add_llama():
     """Incremental: Llama tokenizer, checkpoint recipe, HF logits and reference setwise cases."""
     import tempfile
@@ -581,6 +612,8 @@ def main():
         return add_monot5()
     if "--only-pairwise" in sys.argv:
         return add_pairwise()
+    if "--only-llama3rope" in sys.argv:
+        return add_llama3rope()
     if "--only-llama" in sys.argv:
         return add_llama()
     keep = {}                                  # fixtures made by other tools survive a full regeneration
