@@ -871,7 +871,9 @@ def test_llama3_rope_scaling_on_the_engine_vs_hf_golden():
     want = g["last_logits"]
     ids = list(range(dims.vocab))
     eng = RkLlamaEngine(dims, device=0, max_tokens=2048, max_seqs=8).load_state(state.items())
-    got = eng.last_logits(seqs, ids)
+    def all_logits(e):                                   # rk_llama_last_logits takes up to 64 vocabulary rows per call
+        return np.concatenate([e.last_logits(seqs, ids[c:c + 64]) for c in range(0, len(ids), 64)], axis=1)
+    got = all_logits(eng)
     scale = float(np.abs(want).max())
     assert np.abs(got - want).max() < 8e-3 * scale, (np.abs(got - want).max(), scale)
     np.testing.assert_array_equal(eng.greedy1(seqs)[np.sort(want, axis=1)[:, -1] - np.sort(want, axis=1)[:, -2] > 0.05 * scale],
@@ -879,7 +881,7 @@ def test_llama3_rope_scaling_on_the_engine_vs_hf_golden():
     eng.close()
     plain = _synth.LlamaDims(**{**dims.__dict__, "rope_scaling": None})
     eng2 = RkLlamaEngine(plain, device=0, max_tokens=2048, max_seqs=8).load_state(state.items())
-    assert np.abs(eng2.last_logits(seqs, ids) - want).max() > 5 * 8e-3 * scale
+    assert np.abs(all_logits(eng2) - want).max() > 5 * 8e-3 * scale
     eng2.close()
 
 
@@ -904,9 +906,9 @@ def test_llama_3_8b_full_depth_vs_oracle_golden():
     scale = gold["logit_abs_max"]
     err = float(np.abs(got - want).max())
     print(f"[llama8b full depth] max |label logit - oracle| = {err:.4f} at logit scale {scale:.3f}")
-    assert err < 2e-2 * scale, (err, scale)
+    assert err < 4e-3 * scale, (err, scale)            # measured 6e-4 of the scale: 32 layers of fp16 operands, fp32 stream
     top = eng.last_logits(ids, gold["top_ids"])[0]
-    assert np.abs(top - np.asarray(gold["top_logits"], dtype=np.float32)).max() < 2e-2 * scale
+    assert np.abs(top - np.asarray(gold["top_logits"], dtype=np.float32)).max() < 4e-3 * scale
     if gold["top_logits"][0] - gold["top_logits"][1] > 4e-2 * scale:
         assert int(eng.greedy1(ids)[0]) == gold["top_ids"][0]
     eng.close()
