@@ -88,9 +88,22 @@ class WordSpliceTokenizer:
         suffix = self.suffix
         return [list(chain.from_iterable(map(words.__getitem__, ws))) + suffix for ws in pieces]
 
+    @staticmethod
+    def _plain(prompt: str) -> bool:
+        """Only prompts of printable ASCII and newlines are spliced: for them the tokenizers' normaliser (NFKC, the
+        control-character rules) is the identity and cannot reach across a word boundary; anything else - combining marks,
+        other blanks, NUL ... - goes to the tokenizer itself."""
+        return prompt.isascii() and all(ch == "\n" or " " <= ch <= "~" for ch in prompt)
+
     def __call__(self, prompts: Sequence[str]) -> List[List[int]]:
         if not self.enabled:
             return _tokenize_full(self.tokenizer, prompts)
+        plain = [self._plain(p) for p in prompts]
+        if not all(plain):
+            rest = [p for p, ok in zip(prompts, plain) if not ok]
+            rest_ids = iter(_tokenize_full(self.tokenizer, rest))
+            plain_ids = iter(self([p for p, ok in zip(prompts, plain) if ok]) if any(plain) else [])
+            return [next(plain_ids) if ok else next(rest_ids) for ok in plain]
         out = self._splice(prompts)
         for i in range(len(prompts)):
             n = self.seen + i

@@ -41,11 +41,23 @@ def resolve_checkpoint(model_name_or_path: str, cache_dir=None) -> str:
         return model_name_or_path
     try:
         from huggingface_hub import snapshot_download
-        patterns = ["config.json", "*.safetensors", "*.safetensors.index.json", "pytorch_model*.bin", "pytorch_model.bin.index.json"]
-        try:
-            return snapshot_download(model_name_or_path, cache_dir=cache_dir, allow_patterns=patterns, local_files_only=True)
-        except Exception:
-            return snapshot_download(model_name_or_path, cache_dir=cache_dir, allow_patterns=patterns)
+        st = ["config.json", "*.safetensors", "*.safetensors.index.json"]
+        pt = ["config.json", "pytorch_model*.bin", "pytorch_model.bin.index.json"]
+
+        def has_weights(d):
+            names = os.listdir(d)
+            return any(n.endswith(".safetensors") or (n.startswith("pytorch_model") and n.endswith(".bin")) for n in names)
+        # safetensors first; the .bin files only when the repository has none (hub models that ship both are not fetched
+        # twice).  A cache hit that holds config.json but no weights falls through to the online download.
+        for kw in ({"local_files_only": True}, {}):
+            for patterns in (st, pt):
+                try:
+                    d = snapshot_download(model_name_or_path, cache_dir=cache_dir, allow_patterns=patterns, **kw)
+                except Exception:
+                    continue
+                if has_weights(d):
+                    return d
+        raise FileNotFoundError("no weight files (model*.safetensors / pytorch_model*.bin) found locally or on the hub")
     except Exception as exc:
         raise FileNotFoundError(
             f"{model_name_or_path!r} is neither a local checkpoint directory nor a hub model reachable from here ({exc})") from None

@@ -6,7 +6,9 @@ contract (two prompts, A/B and B/A, decoded generations returned), counters and 
 same primitive the setwise ranker uses: greedy continuation of "<pad> Passage" by two tokens (rk_t5_greedy), here for
 the two orderings of a pair in one engine call, and for `allpair` for as many pairs as fit the engine's capacity at
 once (the reference's batch_size only shapes its host loop and the padded-shape counters, reproduced arithmetically).
-Llama-family models raise NotImplementedError as in the other rankers.
+Llama-family checkpoints (ref: pairwise.py:60-77, 104-129) take the decoder-only path of the setwise ranker: chat-template
+prompt + " Passage:", prefill and ONE greedy token per ordering (rk_llama_greedy1), outputs "Passage <token>"; `allpair`
+is T5-only there too (it reads `self.decoder_input_ids`, which the reference only sets for T5: AttributeError).
 """
 from itertools import combinations
 from typing import List
@@ -25,15 +27,25 @@ class PairwiseLlmRanker(LlmRanker):
 
     def __init__(self, model_name_or_path, tokenizer_name_or_path, device, method="allpair", batch_size=2, k=10,
                  cache_dir=None):
-        # ref: pairwise.py:30-82
-        from transformers import T5Tokenizer
-        from ._runtime import T5Runtime
+        # ref: pairwise.py:30-82: T5 or Llama family by config.model_type, NotImplementedError otherwise
+        from ._runtime import load_runtime
         try:
-            runtime = T5Runtime(model_name_or_path, device, cache_dir=cache_dir)
+            runtime = load_runtime(model_name_or_path, device, cache_dir=cache_dir)
         except NotImplementedError as exc:
             raise NotImplementedError(f"{exc} (pairwise)") from None
-        tokenizer = T5Tokenizer.from_pretrained(
-            tokenizer_name_or_path if tokenizer_name_or_path is not None else model_name_or_path, cache_dir=cache_dir)
+        if runtime.model_type == "llama":
+            from transformers import AutoTokenizer
+            from .setwise import VICUNA_TEMPLATE
+            tokenizer = AutoTokenizer.from_pretrained(model_name_or_path, cache_dir=cache_dir)   # (the reference ignores tokenizer_name_or_path here)
+            tokenizer.use_default_system_prompt = False
+            if 'v1.5' in model_name_or_path:       # the reference's `'vicuna' and 'v1.5' in name` (ref :62)
+                tokenizer.chat_template = VICUNA_TEMPLATE
+            tokenizer.pad_token = "[PAD]"          # ref :65-66 (never used: both orderings of a pair are scored unpadded)
+            tokenizer.padding_side = "left"
+        else:
+            from transformers import T5Tokenizer
+            tokenizer = T5Tokenizer.from_pretrained(
+                tokenizer_name_or_path if tokenizer_name_or_path is not None else model_name_or_path, cache_dir=cache_dir)
         self._setup(runtime, tokenizer, device, method, batch_size, k)
 
     @classmethod
@@ -48,9 +60,11 @@ class PairwiseLlmRanker(LlmRanker):
         self.prompt = PROMPT
         self.llm, self.tokenizer = runtime, tokenizer
         self.config = getattr(runtime, "config", None)
-        self.decoder_input_ids = self.tokenizer.encode("<pad> Passage", add_special_tokens=False)
-        # the two labels a generation normally starts with: hint for the one-pass two-token greedy (rk_t5_greedy2)
-        self._label_ids = [self.tokenizer.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1] for c in "AB"]
+        self.model_type = getattr(runtime, "model_type", "t5")
+        if self.model_type == "t5":                         # (ref :53-56: only the T5 branch has a decoder prompt)
+            self.decoder_input_ids = self.tokenizer.encode("<pad> Passage", add_special_tokens=False)
+            # the two labels a generation normally starts with: hint for the one-pass two-token greedy (rk_t5_greedy2)
+            self._label_ids = [self.tokenizer.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1] for c in "AB"]
         self.total_compare = 0
         self.total_completion_tokens = 0
         self.total_prompt_tokens = 0
@@ -79,6 +93,19 @@ class PairwiseLlmRanker(LlmRanker):
         self.total_compare += 1
         texts = [self.prompt.format(query=query, doc1=docs[0], doc2=docs[1]),
                  self.prompt.format(query=query, doc1=docs[1], doc2=docs[0])]
+        if self.model_type == "llama":
+            # ref :104-129: chat template + " Passage:", one greedy token per ordering.  The reference tokenises the two prompts
+            # into ONE tensor without padding - they hold the same words in another order and normally the same number of
+            # tokens (it raises when they do not; here the counters then take the longer one, as a padded batch would)
+            ids = []
+            for t in texts:
+                prompt = self.tokenizer.apply_chat_template([{"role": "user", "content": t}], tokenize=False, add_generation_prompt=True)
+                ids.append(list(self.tokenizer(prompt + " Passage:")["input_ids"]))
+            width = max(len(x) for x in ids)
+            self.total_prompt_tokens += len(ids) * width
+            toks = self.llm.greedy1(ids)
+            self.total_completion_tokens += len(ids) * (width + 1)      # generate() returns prompt + new token
+            return [f"Passage {self.tokenizer.decode([int(t)], skip_special_tokens=True).strip().upper()}" for t in toks]
         ids = tokenize_prompts(self.tokenizer, texts)
         self.total_prompt_tokens += padded_token_count(ids)                 # padding='longest' (ref :93-97)
         out, lens = self._generate(ids)

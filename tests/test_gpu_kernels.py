@@ -940,3 +940,31 @@ def test_flan_t5_large_full_batch_vs_hf_golden():
         if gaps.min() > 2 * SCORE_TOL:
             np.testing.assert_array_equal(order_got, order_want)
     eng.close()
+
+
+def test_llama_pairwise_reference_cases_on_the_engine(ckpt_dirs):
+    """PairwiseLlmRanker on a Llama-family checkpoint through its PUBLIC constructor (checkpoint directory -> rk_llama engine):
+    the reference's heapsort / bubblesort queries (tests/golden/llama_pairwise_cases.json, ref: pairwise.py:60-77, 104-129) -
+    every compare's two outputs, rankings and counters; allpair raises as in the reference."""
+    from llmrankers.pairwise import PairwiseLlmRanker
+    from llmrankers.rankers import SearchResult
+    with open(os.path.join(GOLD, "llama_pairwise_cases.json")) as f:
+        gold = json.load(f)
+    ck = ckpt_dirs["ckpt_llama"]
+    n = 0
+    for case in gold["cases"]:
+        rk = PairwiseLlmRanker(ck, ck, "cuda", method=case["method"], batch_size=2, k=case["k"])
+        log, orig = [], rk.compare
+        rk.compare = lambda q, d, _o=orig, _l=log: (_l.append([list(d)]), _l[-1].append(_o(q, d)))[1] or _l[-1][1]
+        ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+        if case["raises"]:
+            with pytest.raises(AttributeError):
+                rk.rerank(case["query"], ranking)
+        else:
+            res = rk.rerank(case["query"], ranking)
+            assert log == case["compares"], case["method"]
+            assert [[r.docid, r.score] for r in res] == case["result"]
+            assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"]
+            n += 1
+        rk.llm.engine.close()
+    assert n >= 4

@@ -193,6 +193,36 @@ def test_llama_setwise_reference_cases_cpu(ckpt_dirs):
     assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"]
 
 
+def test_llama_pairwise_reference_cases_cpu(ckpt_dirs):
+    """PairwiseLlmRanker on a Llama-family checkpoint vs the reference's own class (ref: pairwise.py:60-77, 104-129): every
+    compare's two outputs ("Passage <token>", decoded / stripped / upper-cased), rankings and counters of heapsort and
+    bubblesort queries; `allpair` is T5-only in the reference (AttributeError) and here."""
+    from transformers import AutoTokenizer
+    from _stub import OracleLlamaRuntime
+    from llmrankers.pairwise import PairwiseLlmRanker
+    with open(os.path.join(GOLD, "llama_pairwise_cases.json")) as f:
+        gold = json.load(f)
+    dims, state = load_state(ckpt_dirs["ckpt_llama"])
+    tok = AutoTokenizer.from_pretrained(ckpt_dirs["ckpt_llama"])
+    rt = OracleLlamaRuntime(dims, state)
+    n = 0
+    for case in gold["cases"]:
+        rk = PairwiseLlmRanker.from_runtime(rt, tok, method=case["method"], batch_size=2, k=case["k"])
+        log, orig = [], rk.compare
+        rk.compare = lambda q, d, _o=orig, _l=log: (_l.append([list(d)]), _l[-1].append(_o(q, d)))[1] or _l[-1][1]
+        ranking = [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]]
+        if case["raises"]:
+            with pytest.raises(AttributeError):
+                rk.rerank(case["query"], ranking)
+            continue
+        res = rk.rerank(case["query"], ranking)
+        assert log == case["compares"], case["method"]
+        assert [[r.docid, r.score] for r in res] == case["result"]
+        assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == case["counters"]
+        n += 1
+    assert n >= 4
+
+
 def test_fp16_score_mode_reproduces_the_reference_cuda_quantisation(runtimes):
     """PointwiseLlmRanker.fp16_scores: logits and probabilities rounded the way the reference's fp16 'cuda' path rounds
     them (torch: half logits -> softmax in fp32 -> half) - saturated scores tie exactly and keep their input order."""

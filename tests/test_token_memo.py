@@ -92,3 +92,21 @@ def test_self_check_switches_the_memo_off_on_the_first_difference(tok):
     assert got == fake(["some magic here", "more words"])["input_ids"]      # the caller still gets the tokenizer's ids
     assert not memo.enabled and w and "switched off" in str(w[0].message)
     assert memo(["some magic here"]) == fake(["some magic here"])["input_ids"]
+
+
+def test_non_plain_prompts_bypass_the_memo():
+    """Only printable-ASCII prompts are spliced from the word memo; a prompt with a combining mark, a no-break space or a tab
+    goes to the tokenizer itself (the normaliser may act across a word boundary there) - results equal the tokenizer's for
+    every prompt of a mixed batch, in order."""
+    from transformers import T5Tokenizer
+    from llmrankers._batching import WordSpliceTokenizer, _tokenize_full
+    tok = T5Tokenizer.from_pretrained(os.path.join(GOLD, "tok"))
+    memo = WordSpliceTokenizer(tok)
+    assert memo.enabled
+    prompts = ["neural ranking model", "cafe\u0301 river water", "search\u00a0engine index", "music\tart film", "plain again\nnext line"]
+    assert [memo._plain(p) for p in prompts] == [True, False, False, False, True]
+    calls = []
+    orig = memo._splice
+    memo._splice = lambda ps: (calls.append(list(ps)), orig(ps))[1]
+    assert memo(prompts) == _tokenize_full(tok, prompts)
+    assert calls and all(memo._plain(p) for c in calls for p in c)

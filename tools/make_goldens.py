@@ -494,6 +494,54 @@ def llama_goldens(ref_rankers, ref_setwise, ckpt_dir):
     print(f"[llama_cases] {len(cases)} cases, outputs seen: {outs[:12]}; reference printed 'Unexpected output' {sink.getvalue().count('Unexpected output')}x")
 
 
+def add_llama_pairwise():
+    """Incremental: the reference's PairwiseLlmRanker on the Llama fixture checkpoint (ref: pairwise.py:60-77, 104-129: chat
+    template + " Passage:", one greedy token per ordering) - heapsort and bubblesort queries with every compare logged, and
+    `allpair` (T5-only in the reference: AttributeError) -> tests/golden/llama_pairwise_cases.json"""
+    import tempfile
+    tok_dir = os.path.join(GOLD, "tok_llama")
+    with open(os.path.join(GOLD, "ckpts.json")) as f:
+        specs = json.load(f)
+    tmp = tempfile.mkdtemp(prefix="rk_goldens_")
+    ck = os.path.join(tmp, "ckpt_llama")
+    assert write_ckpt(ck, specs["ckpt_llama"], tok_dir) == specs["ckpt_llama"]["sha256"]
+    ref_rankers, _, _ = import_reference()
+    import llmrankers.pairwise as ref_pairwise
+    assert ref_pairwise.__file__.startswith(REF)
+    rs = np.random.RandomState(77)
+    queries = [rand_text(rs, 3, 8) for _ in range(2)]
+    doc_pool = [rand_text(rs, 8, 30) for _ in range(24)]
+    cases, sink = [], io.StringIO()
+    for method, k, n in (("heapsort", 4, 9), ("bubblesort", 3, 7), ("allpair", 3, 4)):
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            rk = ref_pairwise.PairwiseLlmRanker(ck, ck, device="cpu", method=method, batch_size=2, k=k)
+            log, orig = [], rk.compare
+
+            def logged(query, docs, _o=orig, _l=log):
+                out_ = _o(query, docs)
+                _l.append([list(docs), out_])
+                return out_
+
+            rk.compare = logged
+            for qi, q in enumerate(queries):
+                ranking = [ref_rankers.SearchResult(docid=f"P{5 * qi + i}", score=float(50 - i), text=doc_pool[(5 * qi + i) % 24]) for i in range(n)]
+                inp = [[r.docid, r.score, r.text] for r in ranking]
+                del log[:]
+                raises = None
+                try:
+                    res = rk.rerank(q, ranking)
+                except AttributeError:
+                    raises, res = "AttributeError", []
+                cases.append({"kind": "pairwise-llama", "ckpt": "ckpt_llama", "method": method, "k": k, "query": q, "input": inp,
+                              "raises": raises, "result": [[r.docid, r.score] for r in res], "compares": list(log),
+                              "counters": [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens]})
+    with open(os.path.join(GOLD, "llama_pairwise_cases.json"), "w") as f:
+        json.dump({"cases": cases}, f)
+    outs = sorted({o for c_ in cases for _, out in c_["compares"] for o in out})
+    print(f"[llama_pairwise_cases] {len(cases)} cases, {sum(len(c_['compares']) for c_ in cases)} compares, outputs seen: {outs[:10]}")
+    shutil.rmtree(tmp)
+
+
 def add_llama3rope():
     """Incremental: HF LlamaForCausalLM logits of the toy checkpoint with rope type "llama3" (Llama-3.1 / 3.2's scaling,
     hf: modeling_rope_utils.py _compute_llama3_parameters) -> tests/golden/model_llama3rope.npz.  Pins oracle/llama_numpy.py's
@@ -612,6 +660,8 @@ def main():
         return add_monot5()
     if "--only-pairwise" in sys.argv:
         return add_pairwise()
+    if "--only-llama-pairwise" in sys.argv:
+        return add_llama_pairwise()
     if "--only-llama3rope" in sys.argv:
         return add_llama3rope()
     if "--only-llama" in sys.argv:
