@@ -7,6 +7,7 @@ ragged token lists, so nothing is padded and nothing is forked; only the integer
 derives from the padded shape (total_prompt_tokens, ref: pointwise.py:107,114) is reproduced here.
 """
 import json
+import re
 import os
 import warnings
 import weakref
@@ -16,6 +17,9 @@ from typing import Iterator, List, Sequence, Tuple
 
 def _tokenize_full(tokenizer, prompts: Sequence[str]) -> List[List[int]]:
     return [list(ids) for ids in tokenizer(list(prompts))["input_ids"]]
+
+
+_PLAIN_RE = re.compile(r"[\x20-\x7e\n]*")      # printable ASCII and newlines (one C-level scan per prompt)
 
 
 class WordSpliceTokenizer:
@@ -93,7 +97,7 @@ class WordSpliceTokenizer:
         """Only prompts of printable ASCII and newlines are spliced: for them the tokenizers' normaliser (NFKC, the
         control-character rules) is the identity and cannot reach across a word boundary; anything else - combining marks,
         other blanks, NUL ... - goes to the tokenizer itself."""
-        return prompt.isascii() and all(ch == "\n" or " " <= ch <= "~" for ch in prompt)
+        return _PLAIN_RE.fullmatch(prompt) is not None
 
     def __call__(self, prompts: Sequence[str]) -> List[List[int]]:
         if not self.enabled:
