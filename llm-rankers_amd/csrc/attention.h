@@ -1195,6 +1195,126 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
   }
 }
 
+// MFMA form of the chunk kernel (round 3; the production path).  The kernel above forms the weighted sums of the raw encoder
+// rows on the VALU (v_dot2_f32_f16: 2048 dots per thread and chunk - at 320 rows x 3 chunks the pointwise decoder spent 58 us
+// per layer here, its largest kernel).  They are a small GEMM - [16 heads x 64 keys] x [64 keys x d] - whose B operand is
+// key-strided in memory.  Here the scores are computed exactly as above; then every wave walks ITS quarter of the columns in
+// sub-slabs of 64: the [64 keys][64 columns] piece goes to a wave-private 8 KiB of LDS by DMA (eight 1-KiB instructions, the
+// wave's own vmcnt(0), no workgroup barrier) and the sums run on mfma_f32_16x16x32_f16 with the E^T fragments read by
+// ds_read_b64_tr_b16.  LDS image per wave: 128-byte rows, two per bank row; the 32-byte column pairs are XOR-swizzled by
+// key bits (1, 3), which with the row parity puts the eight keys of one transposing read (4 + 4 of two k groups) into the
+// eight 32-byte slots of the bank row.  35 KiB per workgroup: four per CU, whose DMA waits hide each other.
+// (First form, dropped: one loader wave staging the whole [64][1024] chunk, 131 KiB = one workgroup per CU: 82 us per layer
+// against 72 for the VALU pair - the scores phase lost the three co-resident workgroups that had hidden its load latency.)
+// Always 16 heads per workgroup (H > 16: blockIdx.z).  grid = (nch, M, ceil(H / 16)); 256 threads.
+#define XAM_PSTR 72                                            // sP row stride in halfs: 144 B -> the 16 head rows start in 16 different 16-byte slots
+#define XAM_LDS_BYTES (4 * 64 * 64 * 2 + 16 * XAM_PSTR * 2 + 2 * 4 * 16 * 4)
+#define XAM_F(key) ((((key) >> 1) & 1) | ((((key) >> 3) & 1) << 1))   // XOR on the 32-byte pair index (4 pairs per 128-byte row)
+__global__ __launch_bounds__(256) void xattn_part_mfma_kernel(XAttnArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char xam_smem[XAM_LDS_BYTES];
+  half_t* sP = (half_t*)(xam_smem + 4 * 64 * 64 * 2);
+  float (*sRed)[4][16] = (float (*)[4][16])(xam_smem + 4 * 64 * 64 * 2 + 16 * XAM_PSTR * 2);
+  const int ck = blockIdx.x, m = blockIdx.y, hg = blockIdx.z;
+  const int b = p.row_seq ? p.row_seq[p.row0 + m] : (p.row0 + m) / p.Ld;
+  const int tok0 = p.seq_off[b];
+  const int L = p.seq_off[b + 1] - tok0;
+  const int t0 = ck * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nh = min(16, p.H - hg * 16);
+  float* stat = p.stat + (((size_t)m * p.nch + ck) * p.H + hg * 16) * 2;
+  if (t0 >= L) {     // this row has no keys here: mark the chunk empty for the combine step
+    if (tid < nh) { stat[tid * 2] = -1e30f; stat[tid * 2 + 1] = 0.f; }
+    return;
+  }
+  // ---- scores: S[h][t] = qk[h] . e_t  by MFMA 16x16x32 (A = the 16 head rows of qk, B = 16 encoder rows per wave) ----
+  const int hrow = min(hg * 16 + l15, p.H - 1);
+  const half_t* ap = p.qk + ((size_t)m * p.H + hrow) * p.d + 8 * g;
+  const int t = t0 + wave * 16 + l15;
+  const half_t* bp = p.enc + (size_t)(tok0 + min(t, L - 1)) * p.d + 8 * g;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int c0 = 0; c0 < p.d; c0 += 32)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8*)(ap + c0), *(const half8*)(bp + c0), acc, 0, 0, 0);
+  // lane holds heads 4g..4g+3 for key t (C layout: col = lane&15, row = 4*(lane>>4) + r)
+  float mx[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (t >= L) acc[r] = -1e30f;
+    mx[r] = row16_max(acc[r]);
+  }
+  if (l15 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[0][wave][4 * g + r] = mx[r];
+  }
+  __syncthreads();
+  float sm[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int h = 4 * g + r;
+    mx[r] = fmaxf(fmaxf(sRed[0][0][h], sRed[0][1][h]), fmaxf(sRed[0][2][h], sRed[0][3][h]));
+    const float e = __expf(acc[r] - mx[r]);
+    sP[h * XAM_PSTR + wave * 16 + l15] = (half_t)e;            // [head][key of the chunk]
+    sm[r] = row16_sum_f(e);
+  }
+  if (l15 == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sRed[1][wave][4 * g + r] = sm[r];
+  }
+  __syncthreads();
+  if (tid < nh) {
+    stat[tid * 2] = fmaxf(fmaxf(sRed[0][0][tid], sRed[0][1][tid]), fmaxf(sRed[0][2][tid], sRed[0][3][tid]));
+    stat[tid * 2 + 1] = (sRed[1][0][tid] + sRed[1][1][tid]) + (sRed[1][2][tid] + sRed[1][3][tid]);
+  }
+  // ---- partial weighted sums: O[h][c] = sum_key P[h][key] E[key][c] on the matrix cores ----
+  float* part = p.part + (((size_t)m * p.nch + ck) * p.H + hg * 16) * p.d;
+  half8 pa[2];                                                 // P fragments of the two k32 steps: head l15, keys 32 kk + 8 g .. +8
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) pa[kk] = *(const half8*)(sP + l15 * XAM_PSTR + 32 * kk + 8 * g);
+  half_t* sE = (half_t*)xam_smem + wave * (64 * 64);           // this wave's [64 keys][64 columns] piece
+  // DMA piece i fills LDS slots i * 64 + lane of the piece: key row r = slot >> 3, 16-byte chunk c = slot & 7; it fetches
+  // global chunk c ^ (F(r) << 1).  Byte offsets of the eight source rows from the piece's first column:
+  unsigned soff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int slot = i * 64 + lane, r = slot >> 3, c = slot & 7;
+    soff[i] = ((unsigned)(tok0 + min(t0 + r, L - 1)) * (unsigned)p.d + ((c ^ (XAM_F(r) << 1)) << 3)) * 2u;   // clamped rows carry weight 0
+  }
+  // this lane's share of a transposing read: key 8 g + (i16 >> 2) (+ 32 kk, + 4 for the second read), columns 4 (i16 & 3)
+  // .. +4 of a 16-column block; F depends on key bits 1 and 3 only: (kj >> 1) | (g & 1) << 1
+  const int i16 = lane & 15, kj = i16 >> 2;
+  const int fsw = ((kj >> 1) & 1) | ((g & 1) << 1);
+  const int wcols = p.d >> 2;                                  // columns of this wave
+  for (int cs = 0; cs < wcols; cs += 64) {
+    const char* src = (const char*)(p.enc + wave * wcols + cs);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
+                                       (__attribute__((address_space(3))) void*)(sE + i * 512), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's piece has landed (wave-private: no barrier)
+#pragma unroll
+    for (int cb = 0; cb < 64; cb += 16) {
+      const int col = cb + 4 * (i16 & 3);                      // column (within the piece) this lane's read starts at
+      const int coff = ((((col >> 4) ^ fsw) << 4) | (col & 15));
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const half_t* r0 = sE + (32 * kk + 8 * g + kj) * 64 + coff;
+        const half4 e0 = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) attd_fp16x4*)r0));
+        const half4 e1 = __builtin_bit_cast(half4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) attd_fp16x4*)(r0 + 4 * 64)));
+        const half8 eb = {e0[0], e0[1], e0[2], e0[3], e1[0], e1[1], e1[2], e1[3]};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(pa[kk], eb, o, 0, 0, 0);
+      }
+      const int cout = wave * wcols + cs + cb + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * g + r < nh) part[(size_t)(4 * g + r) * p.d + cout] = o[r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every read of the piece has returned before the next DMA overwrites it
+  }
+}
+
 // grid = (H, M); 256 threads: merge the chunks of one (row, head) in chunk order and normalise.  The chunks that hold keys
 // are exactly 0 .. ceil(L / 64) - 1, so the loops run over that prefix without per-chunk branches: the weights go through
 // LDS once and the partial-sum loads of a thread are independent (16 in flight) - the branchy form paid one L2 round trip

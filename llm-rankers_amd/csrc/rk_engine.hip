@@ -106,7 +106,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1;
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
@@ -564,6 +564,10 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
 // common prefix.  rows = row count, Ld = longest position count; device arrays: keys[r * Ld + j] = row at position j of
 // row r's sequence, pos[r] = position of row r, seq[r] = its encoder sequence.  Query-side cross-attention only.
 struct DecTree { int rows; const int* keys; const int* pos; const int* seq; };
+// (Tried and dropped, round 3: the single-position pass of 320 rows as TWO or THREE chains of 32-row-aligned row ranges on
+// helper streams, fork / join by events (parallel branches of the decoder graph) - bit-identical, but 6.4-6.6k passages/s
+// against 7.3k: what the decoder costs the encoder running beside it is every one of its kernels delaying the persistent
+// GEMM it meets, so more, smaller decoder kernels cost more, not less.  The lever is fewer and shorter decoder kernels.)
 int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
   const rk_model_desc& d = e->d;
   hipStream_t st = dec_stream(e, sl);
@@ -629,7 +633,12 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
         XAttnArgs xa{sl.xqk, sl.enc_out, sl.d_seq_off, sl.xpart, sl.xstat, sl.xctx, Ld, H, dm, nch, r0, tree ? tree->seq : nullptr};
         {
           Bracket br(e, st, PC_DEC_ATTN, 4.0 * nr * (double)sl.maxL * H * dm, (double)sl.T * dm * 2.0 * 2);
-          if ((long)nch * nr * ((H + 15) / 16) >= 2 * e->n_cu)
+          // MFMA form (weighted sums on the matrix cores, the chunk's encoder rows staged in LDS by a loader wave) whenever
+          // the model width allows its LDS image; the VALU form otherwise.  The choice depends on the MODEL only, never on the
+          // batch (the two round differently).
+          if (e->opt_xattn_mfma && dm % 256 == 0) {             // (every wave takes whole 64-column pieces of its quarter)
+            hipLaunchKernelGGL(xattn_part_mfma_kernel, dim3(nch, nr, (H + 15) / 16), dim3(256), 0, st, xa);
+          } else if ((long)nch * nr * ((H + 15) / 16) >= 2 * e->n_cu)
             hipLaunchKernelGGL(xattn_part_kernel<16>, dim3(nch, nr, (H + 15) / 16), dim3(256), 0, st, xa);
           else
             hipLaunchKernelGGL(xattn_part_kernel<4>, dim3(nch, nr, (H + 3) / 4), dim3(256), 0, st, xa);
@@ -1896,6 +1905,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
 #ifdef RK_MEASURE
   if (!strcmp(key, "attn_ko")) { e->opt_attn_ko = value; return RK_OK; }   // timing-only knock-outs, see AttnEncArgs
 #endif
+  if (!strcmp(key, "xattn_mfma")) { e->opt_xattn_mfma = value != 0; ++e->opt_epoch; return RK_OK; }   // query-side cross-attention: weighted sums on the matrix cores (1) or the VALU form (0)
   if (!strcmp(key, "attn_heads_per_wg")) { e->opt_attn_heads_per_wg = value; return RK_OK; }   // 0 auto
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
   if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 5 DMA kernel (two groups per workgroup), 6 DMA kernel (one group), 1 pair kernel, 2 / 4 plain short kernels, 0 tiled
