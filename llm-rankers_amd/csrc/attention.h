@@ -50,11 +50,25 @@ __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16
   // compiler from turning it back into selects).  At L = 184 one group of eight is cut: 8 compare / select pairs instead
   // of 64 on every last tile.  Same values either way.
   const int tile0 = MASK ? (__builtin_amdgcn_readfirstlane(key_base) & ~63) : 0;
+  // CHUNKED: the table entries of register group q + 1 are requested before group q is used (LDS reads return in order, so
+  // the counted wait in front of group q leaves them in flight): 16 values in flight, one exposed LDS round trip per tile
+  float bq[2][4][2];
+  if (CHUNKED) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bq[0][j][0] = bias(j, 0); bq[0][j][1] = bias(j, 1); }
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    if (CHUNKED && (r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-    s0[r] = fmaf(s0[r], ATT_LOG2E, bias(r, 0));
-    s1[r] = fmaf(s1[r], ATT_LOG2E, bias(r, 1));
+    if (CHUNKED && (r & 3) == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (r < 12) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bq[((r >> 2) + 1) & 1][j][0] = bias(r + 4 + j, 0); bq[((r >> 2) + 1) & 1][j][1] = bias(r + 4 + j, 1); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    s0[r] = fmaf(s0[r], ATT_LOG2E, CHUNKED ? bq[(r >> 2) & 1][r & 3][0] : bias(r, 0));
+    s1[r] = fmaf(s1[r], ATT_LOG2E, CHUNKED ? bq[(r >> 2) & 1][r & 3][1] : bias(r, 1));
     if (MASK && (r & 3) == 3) {
       const int g = r >> 2;
       if (tile0 + 8 * g + 8 > L) {

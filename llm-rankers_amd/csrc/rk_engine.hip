@@ -497,8 +497,15 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
         // 5: two six-wave groups per 768-thread workgroup (two head ranges side by side on a CU); 6: one group per workgroup.
         // heads per group: 4 amortise a group's pipeline fill best; fewer when that would leave CUs without a workgroup
         const int ng = e->opt_attn_short == 5 ? 2 : 1;
-        int hpw = 4;
-        while (hpw > 1 && (long)sl.n_seq * ((d.n_heads + ng * hpw - 1) / (ng * hpw)) < (long)e->n_cu) hpw >>= 1;
+        // heads per group: the value in {4, 2, 1} that needs the fewest head-times on the busiest CU (workgroups run one per CU:
+        // rounds x heads per workgroup), the larger one on a tie (fewer pipeline fills).  320 sequences x 16 heads: 2
+        // (1280 workgroups = 5 rounds of 2 heads; 4 would be 3 rounds of 4: 145 against 155 us per launch)
+        int hpw = 4; long best = -1;
+        for (int cand = 4; cand >= 1; cand >>= 1) {
+          const long wgs = (long)sl.n_seq * ((d.n_heads + ng * cand - 1) / (ng * cand));
+          const long cost = ((wgs + e->n_cu - 1) / e->n_cu) * cand;
+          if (best < 0 || cost < best) { best = cost; hpw = cand; }
+        }
         a.heads_per_wg = e->opt_attn_heads_per_wg > 0 ? e->opt_attn_heads_per_wg : hpw;
         const dim3 grid((d.n_heads + ng * a.heads_per_wg - 1) / (ng * a.heads_per_wg), sl.n_seq);
         if (ng == 2) {
