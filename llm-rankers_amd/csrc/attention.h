@@ -41,6 +41,16 @@ struct AttnEncArgs {
 #define ATT_LOG2E 1.4426950408889634f
 // CHUNKED: the table reads are fenced into groups of four registers (8 values in flight instead of 32) for kernels that
 // run close to their register budget; the arithmetic and the order of every sum are the same.
+// VALU economy (the DMA kernel is bound by its VALU slots: ~8 instructions per score): the FMA and the subtraction run as
+// packed fp32 pairs (v_pk_fma_f32 / v_pk_add_f32: the same IEEE operations, two per slot) and the running maximum as
+// v_max3_f32 through inline asm - fmaxf() makes the compiler canonicalise both inputs first (v_max x, x, x: three
+// instructions per pair of scores instead of one); no NaN can reach here, and max is exact in any order.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float attn_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 template <bool MASK, bool FIRST, class BiasFn, bool CHUNKED = false>
 __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m_run, float& l_run,
                                                   int key_base, int L, BiasFn bias) {
@@ -52,24 +62,28 @@ __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16
   const int tile0 = MASK ? (__builtin_amdgcn_readfirstlane(key_base) & ~63) : 0;
   // CHUNKED: the table entries of register group q + 1 are requested before group q is used (LDS reads return in order, so
   // the counted wait in front of group q leaves them in flight): 16 values in flight, one exposed LDS round trip per tile
-  float bq[2][4][2];
-  if (CHUNKED) {
+  const f32x2 l2e = {ATT_LOG2E, ATT_LOG2E};
+  f32x2 bq[2][2][2];                                  // [buffer][register pair of the group][s0 / s1]
+  auto fetch_group = [&](int buf, int r0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { bq[0][j][0] = bias(j, 0); bq[0][j][1] = bias(j, 1); }
-  }
+    for (int jp = 0; jp < 2; ++jp)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+      for (int sub = 0; sub < 2; ++sub) bq[buf][jp][sub] = f32x2{bias(r0 + 2 * jp, sub), bias(r0 + 2 * jp + 1, sub)};
+  };
+  if (CHUNKED) fetch_group(0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
     if (CHUNKED && (r & 3) == 0) {
       __builtin_amdgcn_sched_barrier(0);
-      if (r < 12) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { bq[((r >> 2) + 1) & 1][j][0] = bias(r + 4 + j, 0); bq[((r >> 2) + 1) & 1][j][1] = bias(r + 4 + j, 1); }
-      }
+      if (r < 12) fetch_group(((r >> 2) + 1) & 1, r + 4);
       __builtin_amdgcn_sched_barrier(0);
     }
-    s0[r] = fmaf(s0[r], ATT_LOG2E, CHUNKED ? bq[(r >> 2) & 1][r & 3][0] : bias(r, 0));
-    s1[r] = fmaf(s1[r], ATT_LOG2E, CHUNKED ? bq[(r >> 2) & 1][r & 3][1] : bias(r, 1));
-    if (MASK && (r & 3) == 3) {
+    const f32x2 b0 = CHUNKED ? bq[(r >> 2) & 1][(r >> 1) & 1][0] : f32x2{bias(r, 0), bias(r + 1, 0)};
+    const f32x2 b1 = CHUNKED ? bq[(r >> 2) & 1][(r >> 1) & 1][1] : f32x2{bias(r, 1), bias(r + 1, 1)};
+    const f32x2 t0 = __builtin_elementwise_fma(f32x2{s0[r], s0[r + 1]}, l2e, b0);
+    const f32x2 t1 = __builtin_elementwise_fma(f32x2{s1[r], s1[r + 1]}, l2e, b1);
+    s0[r] = t0[0]; s0[r + 1] = t0[1]; s1[r] = t1[0]; s1[r + 1] = t1[1];
+    if (MASK && (r & 3) == 2) {
       const int g = r >> 2;
       if (tile0 + 8 * g + 8 > L) {
         asm volatile("");
@@ -82,19 +96,22 @@ __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16
         for (int j = 4 * g; j < 4 * g + 4; ++j) s1[j] = key_base + (j & 3) + 8 * g + 32 < L ? s1[j] : -1e30f;
       }
 #pragma unroll
-      for (int j = 4 * g; j < 4 * g + 4; ++j) tmax = fmaxf(tmax, fmaxf(s0[j], s1[j]));
+      for (int j = 4 * g; j < 4 * g + 4; ++j) tmax = attn_max3(tmax, s0[j], s1[j]);
     }
-    if (!MASK) tmax = fmaxf(tmax, fmaxf(s0[r], s1[r]));
+    if (!MASK) { tmax = attn_max3(tmax, s0[r], s1[r]); tmax = attn_max3(tmax, s0[r + 1], s1[r + 1]); }
   }
   if (CHUNKED) __builtin_amdgcn_sched_barrier(0);
-  tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-  const float m_new = FIRST ? tmax : fmaxf(m_run, tmax);
+  tmax = attn_max3(tmax, __shfl_xor(tmax, 32), tmax);
+  const float m_new = FIRST ? tmax : attn_max3(m_run, tmax, tmax);
+  const f32x2 m2 = {m_new, m_new};
   float psum = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-    s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 d0 = f32x2{s0[r], s0[r + 1]} - m2, d1 = f32x2{s1[r], s1[r + 1]} - m2;
+    s0[r] = __builtin_amdgcn_exp2f(d0[0]); s0[r + 1] = __builtin_amdgcn_exp2f(d0[1]);
+    s1[r] = __builtin_amdgcn_exp2f(d1[0]); s1[r + 1] = __builtin_amdgcn_exp2f(d1[1]);
     psum += s0[r] + s1[r];
+    psum += s0[r + 1] + s1[r + 1];
   }
   psum += __shfl_xor(psum, 32);
   if (FIRST) {
@@ -808,7 +825,11 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
   };
   auto sm_tile = [&](const LaneCtx& c, const float* lut, int kt, f32x16& s0, f32x16& s1) {
     const int key_base = kt * 64 + 4 * c.hh;
-    const float* lq = lut + c.lut_q + kt * 64;
+    // one opaque index per tile: all 32 table reads take their immediate offsets against ONE address register (left to the
+    // loop optimiser, the middle-tile loop carried 16 separate address registers, re-derived with 16 adds per tile)
+    int lqi = c.lut_q + kt * 64;
+    asm volatile("" : "+v"(lqi));
+    const float* lq = lut + lqi;
     auto bias = [&](int r, int sub) { return lq[(r & 3) + 8 * (r >> 2) + 32 * sub]; };
     const bool last = kt == nkt - 1;
     using BF = decltype(bias);

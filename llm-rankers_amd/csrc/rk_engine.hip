@@ -220,6 +220,12 @@ void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   // persistent: one workgroup per CU walks the tiles (max_wgs = CUs rounded down to a multiple of 8 keeps the tile -> XCD
   // association); max_wgs <= 0: one workgroup per tile
+  // (measured, r03: trimming the grid to the fewest workgroups with the same number of rounds - 232 instead of 256 for the
+  // 920 tiles of O / FFN-out, to leave 24 CUs to the decoder stream for the whole GEMM - changes nothing: 7350-7370 against
+  // 7367-7376 passages/s; the decoder kernels are not waiting for CUs, they share the memory system.  Likewise starting the
+  // workgroups that walk one tile less 12 / 20 / 28 us late, so that their read-modify-write epilogues fall into the others'
+  // MFMA phases at no cost to the critical path: o 0.496 -> 0.484 ms per step in the serial profile, 7302-7340 against
+  // 7338-7376 passages/s in the pipeline - the epilogue's cost is not a shared-HBM burst that de-phasing would spread)
   const int grid = max_wgs > 0 && tiles > max_wgs ? max_wgs : tiles;
   hipLaunchKernelGGL((gemm_pp2_kernel<EPI, KO, RS>), dim3(grid), dim3(512), smem, st, a);
 }
