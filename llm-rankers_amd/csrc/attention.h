@@ -51,10 +51,27 @@ __device__ __forceinline__ float attn_max3(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
-template <bool MASK, bool FIRST, class BiasFn, bool CHUNKED = false>
-__device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m_run, float& l_run,
-                                                  int key_base, int L, BiasFn bias) {
-  float tmax = -1e30f;
+// First half of a tile's softmax: t = s * log2(e) + bias (keys >= L: -1e30) in place, and the running maximum of this lane's
+// scores (tmax is read and updated: several tiles may share one maximum).
+// A lane and its partner (lane ^ 32) hold the two halves of a query row's scores: v_permlane32_swap hands each the other's
+// value without LDS (a and b are {own, partner} in one half-wave and {partner, own} in the other - max and + do not care).
+// (inline asm: the builtin form with a float on both sides came back with ONE register for both results - clang 19, gfx950 -
+// and the hazard recogniser does not look inside asm, hence the explicit wait states in front of the swap)
+__device__ __forceinline__ void attn_swap32(float& a, float& b) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float attn_row_max(float x) {
+  float a = x, b = x;
+  attn_swap32(a, b);
+  return attn_max3(a, b, b);
+}
+__device__ __forceinline__ float attn_row_sum(float x) {
+  float a = x, b = x;
+  attn_swap32(a, b);
+  return a + b;
+}
+template <bool MASK, class BiasFn, bool CHUNKED = false>
+__device__ __forceinline__ void attn_tile_bias_max(f32x16& s0, f32x16& s1, float& tmax, int key_base, int L, BiasFn bias) {
   // registers 4g .. 4g+3 of s0 / s1 hold keys tile0 + 8g (+32) .. +8 (both half-waves): a group that lies wholly inside the
   // sequence needs no select - decided per group on wave-uniform values, as a real scalar branch (the empty asm keeps the
   // compiler from turning it back into selects).  At L = 184 one group of eight is cut: 8 compare / select pairs instead
@@ -101,10 +118,11 @@ __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16
     if (!MASK) { tmax = attn_max3(tmax, s0[r], s1[r]); tmax = attn_max3(tmax, s0[r + 1], s1[r + 1]); }
   }
   if (CHUNKED) __builtin_amdgcn_sched_barrier(0);
-  tmax = attn_max3(tmax, __shfl_xor(tmax, 32), tmax);
-  const float m_new = FIRST ? tmax : attn_max3(m_run, tmax, tmax);
-  const f32x2 m2 = {m_new, m_new};
-  float psum = 0.f;
+}
+
+// Second half: p = exp2(t - m) in place; psum += this lane's 32 probabilities, pairwise (s0[r] + s1[r]) in register order.
+__device__ __forceinline__ void attn_tile_exp(f32x16& s0, f32x16& s1, float m, float& psum) {
+  const f32x2 m2 = {m, m};
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
     const f32x2 d0 = f32x2{s0[r], s0[r + 1]} - m2, d1 = f32x2{s1[r], s1[r + 1]} - m2;
@@ -113,7 +131,19 @@ __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16
     psum += s0[r] + s1[r];
     psum += s0[r + 1] + s1[r + 1];
   }
-  psum += __shfl_xor(psum, 32);
+}
+
+// Online-softmax step of one 64-key tile (sequences longer than ATT_ROW_MAXL keys; shorter ones take the whole-row form below).
+template <bool MASK, bool FIRST, class BiasFn, bool CHUNKED = false>
+__device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16& o0, f32x16& o1, float& m_run, float& l_run,
+                                                  int key_base, int L, BiasFn bias) {
+  float tmax = -1e30f;
+  attn_tile_bias_max<MASK, BiasFn, CHUNKED>(s0, s1, tmax, key_base, L, bias);
+  tmax = attn_row_max(tmax);
+  const float m_new = FIRST ? tmax : attn_max3(m_run, tmax, tmax);
+  float psum = 0.f;
+  attn_tile_exp(s0, s1, m_new, psum);
+  psum = attn_row_sum(psum);
   if (FIRST) {
     l_run = psum;
   } else {
@@ -124,6 +154,16 @@ __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16
   }
   m_run = m_new;
 }
+
+// WHOLE-ROW softmax (sequences of at most ATT_ROW_MAXL = 192 keys, i.e. three key tiles - the pointwise prompts): all score
+// tiles of a query row are formed first, ONE maximum and ONE sum are taken over the row (attn_tile_bias_max over the tiles in
+// order, one exchange with the partner lane; attn_tile_exp over the tiles in order, one exchange), and the unnormalised
+// probabilities go through P V without any rescaling.  Against the online form this drops two of three cross-lane
+// exchanges per row, the alpha exponentials and the rescale of the output accumulators, and lets a wave issue the MFMAs
+// of all its score tiles back to back.  Which form a sequence takes depends on ITS length only, so its bits never depend on
+// the batch: the DMA kernel holds the three tiles in registers; the tiled kernel (batches that also hold a longer sequence)
+// walks the key tiles of such a sequence twice - maximum first, then probabilities - and reproduces the same operations.
+#define ATT_ROW_MAXL 192
 
 // MINW: minimum waves per SIMD the register allocation must allow (1: up to 512 registers, one workgroup per CU;
 // 2: 256 registers, two workgroups per CU overlap each other's load / softmax / MFMA phases)
@@ -187,16 +227,25 @@ __global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p)
       *(half2v*)(sVt[buf] + (scc * 8 + j) * ATT_VSTR + 2 * srow) = pr;
     }
   };
+  // Whole-row softmax (ATT_ROW_MAXL above) for a short sequence that shares its batch with a longer one: the key tiles are
+  // walked TWICE - first pass: scores, bias and the row maximum only; second pass: the same scores again (same MFMA inputs,
+  // same bits), probabilities against that maximum, P V without rescaling - which reproduces the DMA kernel's operations
+  // and their order exactly.  (Never split: ATT_ROW_MAXL < ATT_SPLIT_MIN_L, so group 1 idles through the same barriers.)
+  const bool row_form = L <= ATT_ROW_MAXL;
+  const int n_total = row_form ? 2 * nkt : n_iter;
+  auto tile_of = [&](int it) { return row_form ? (it >= nkt ? it - nkt : it) : kt_begin + it; };
+  float row_tmax = -1e30f, row_m = 0.f, row_psum = 0.f;
   if (kt_begin < kt_end) {
     load_tile(kt_begin);
     store_tile(0);
   }
   __syncthreads();
-  for (int it = 0; it < n_iter; ++it) {
-    const int kt = kt_begin + it;
+  for (int it = 0; it < n_total; ++it) {
+    const int kt = tile_of(it);
     const int cur = it & 1;
-    if (kt + 1 < kt_end) load_tile(kt + 1);       // in flight while this tile is computed
-    if (wave_active && kt < kt_end) {
+    const bool more = kt_begin < kt_end && it + 1 < (row_form ? n_total : kt_end - kt_begin);
+    if (more) load_tile(tile_of(it + 1));       // in flight while this tile is computed
+    if (wave_active && kt_begin < kt_end && kt < kt_end) {
       const half_t* kbuf = sK[cur];
       const half_t* vbuf = sVt[cur];
       f32x16 s0, s1;
@@ -216,31 +265,35 @@ __global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p)
         // all 32 queries of this wave adds the same table value to every score - no table reads, no index math (17 of the
         // 23 tiles of a 1.4k-token prompt).  Same fmaf inputs as the table path: bit-identical.
         const bool far_l = kt * 64 + 63 - q0 <= -RK_LUT_R, far_r = kt * 64 - (q0 + 31) >= RK_LUT_R;
-        if (far_l || far_r) {
-          const float cb = far_l ? sLut[0] : sLut[RK_LUT_N - 1];
-          auto bias = [&](int, int) { return cb; };
-          if (kt == kt_begin) {
+        auto soft = [&](auto bias) {
+          using BF = decltype(bias);
+          if (row_form) {
+            float tm = -1e30f;                      // second pass: the maximum is already known
+            float& tmax = it < nkt ? row_tmax : tm;
+            if (last) attn_tile_bias_max<true, BF>(s0, s1, tmax, key_base, L, bias);
+            else attn_tile_bias_max<false, BF>(s0, s1, tmax, key_base, L, bias);
+            if (it == nkt - 1) row_m = attn_row_max(row_tmax);
+            if (it >= nkt) attn_tile_exp(s0, s1, row_m, row_psum);
+          } else if (kt == kt_begin) {
             if (last) attn_tile_softmax<true, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
             else attn_tile_softmax<false, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
           } else {
             if (last) attn_tile_softmax<true, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
             else attn_tile_softmax<false, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
           }
+        };
+        if (far_l || far_r) {
+          const float cb = far_l ? sLut[0] : sLut[RK_LUT_N - 1];
+          soft([&](int, int) { return cb; });
         } else {
-          auto bias = [&](int r, int sub) {
+          soft([&](int r, int sub) {
             int rel = key_base + (r & 3) + 8 * (r >> 2) + 32 * sub - qpos;
             rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
             return sLut[rel + RK_LUT_R];
-          };
-          if (kt == kt_begin) {
-            if (last) attn_tile_softmax<true, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-            else attn_tile_softmax<false, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-          } else {
-            if (last) attn_tile_softmax<true, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-            else attn_tile_softmax<false, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-          }
+          });
         }
       }
+      if (!row_form || it >= nkt) {                  // (first pass of the whole-row form: no P V)
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
@@ -263,10 +316,12 @@ __global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p)
           }
         }
       }
+      }
     }
-    if (kt + 1 < kt_end) store_tile(cur ^ 1);     // buffer cur^1 was last read before the previous barrier
+    if (more) store_tile(cur ^ 1);                // buffer cur^1 was last read before the previous barrier
     __syncthreads();
   }
+  if (row_form) l_run = attn_row_sum(row_psum);
   if (KS == 2) {
     // merge the two halves of a split sequence: group 1 hands (m, l, O) of its keys to the wave of group 0 that holds
     // the same queries - through its own, now idle, LDS stages ([value][lane]: conflict-free)
@@ -322,366 +377,26 @@ __global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p)
   }
 }
 
-// Short-sequence variant (L <= 192: the pointwise prompts).  The K rows and the TRANSPOSED V of one (sequence, head)
-// fit in LDS at once (27.6 + 25.1 KB), so they are loaded exactly once behind a single exposed memory latency and a
-// single barrier (the tiled kernel above pays a global-load round trip and two barriers per 64-key tile), V^T is
-// written as key PAIRS (ds_write_b32), 6 waves x 32 queries cover the whole sequence, and the output goes through LDS
-// so that stores are whole 128-byte context rows.  grid = (H, B), 384 threads, 3 workgroups per CU.
-#define ATTS_MAXL 192
-#define ATTS_VSTR 196   // sVt row stride in halfs (392 B: 8-B aligned; 98 dwords -> conflict-free b64 reads)
-template <int NW>   // waves per workgroup: 6 (one workgroup covers 192 queries) or 4 (128 queries, blockIdx.z picks the half)
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_enc_short_kernel(AttnEncArgs p) {
-  __shared__ __attribute__((aligned(16))) half_t sK[ATTS_MAXL * ATT_KSTR];
-  __shared__ __attribute__((aligned(16))) half_t sVt[64 * ATTS_VSTR];
-  __shared__ float sLutX[2 * ATTS_MAXL];   // table over every (key - query) in (-192, 192): no clamp in the loop
-  const int b = blockIdx.y;
-  const int tok0 = p.seq_off[b];
-  const int L = p.seq_off[b + 1] - tok0;
-  if ((int)blockIdx.z * NW * 32 >= L) return;   // uniform for the whole block
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int hh = lane >> 5, l31 = lane & 31;
-  const int h_end = min(p.I >> 6, ((int)blockIdx.x + 1) * p.heads_per_wg);
-  for (int h = blockIdx.x * p.heads_per_wg; h < h_end; ++h) {
-  if (h != (int)blockIdx.x * p.heads_per_wg) __syncthreads();   // the previous head's tables and staging rows are done with
-  for (int i = tid; i < 2 * ATTS_MAXL - 1; i += NW * 64) {
-    int rel = i - (ATTS_MAXL - 1);
-    rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
-    sLutX[i] = p.bias_lut[h * RK_LUT_N + rel + RK_LUT_R] * ATT_LOG2E;
-  }
-  const int nkt = (L + 63) >> 6;
-  const int nrows = nkt * 64;
-  // K rows: 16-B chunks, row-major (clamped rows are masked later)
-  for (int c = tid; c < ((p.ko & 2) ? 0 : nrows * 8); c += NW * 64) {
-    const int row = c >> 3, cc = c & 7;
-    const int key = row < L ? row : L - 1;
-    *(half8*)(sK + row * ATT_KSTR + cc * 8) = *(const half8*)(p.qkv + (size_t)(tok0 + key) * p.ld + p.I + h * 64 + cc * 8);
-  }
-  // V^T: one thread takes 2 adjacent keys x 8 d and writes 8 key-pairs (32-bit) into the transposed image
-  for (int c = tid; c < ((p.ko & 2) ? 0 : (nrows >> 1) * 8); c += NW * 64) {
-    const int kp = c >> 3, cc = c & 7;
-    const int k0 = 2 * kp < L ? 2 * kp : L - 1, k1 = 2 * kp + 1 < L ? 2 * kp + 1 : L - 1;
-    const half8 v0 = *(const half8*)(p.qkv + (size_t)(tok0 + k0) * p.ld + 2 * p.I + h * 64 + cc * 8);
-    const half8 v1 = *(const half8*)(p.qkv + (size_t)(tok0 + k1) * p.ld + 2 * p.I + h * 64 + cc * 8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const half2v pr = {v0[j], v1[j]};
-      *(half2v*)(sVt + (cc * 8 + j) * ATTS_VSTR + 2 * kp) = pr;
-    }
-  }
-  const int q0 = (blockIdx.z * NW + wave) * 32;
-  const bool wave_active = q0 < L;
-  const int qpos = q0 + l31;
-  const int qrow = qpos < L ? qpos : L - 1;
-  half8 qf[4];
-  {
-    const half_t* qptr = p.qkv + (size_t)(tok0 + qrow) * p.ld + h * 64 + 8 * hh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *(const half8*)(qptr + 16 * s);
-  }
-  f32x16 o0, o1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-  float m_run = -1e30f, l_run = 0.f;
-  const float* lut_q = sLutX + (ATTS_MAXL - 1) - qpos + 4 * hh;   // lut_q[key - 4hh] = bias(key - qpos) * log2(e)
-  __syncthreads();
-  if (wave_active) {
-    for (int kt = 0; kt < ((p.ko & 1) ? 0 : nkt); ++kt) {
-      const half_t* kb_ = sK + kt * 64 * ATT_KSTR;
-      f32x16 s0, s1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const half8 k0 = *(const half8*)(kb_ + l31 * ATT_KSTR + 16 * s + 8 * hh);
-        const half8 k1 = *(const half8*)(kb_ + (32 + l31) * ATT_KSTR + 16 * s + 8 * hh);
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
-      }
-      {
-        const int key_base = kt * 64 + 4 * hh;
-        const float* lq = lut_q + kt * 64;               // this query's table row, shifted to the tile's first key
-        auto bias = [&](int r, int sub) { return lq[(r & 3) + 8 * (r >> 2) + 32 * sub]; };
-        const bool last = kt == nkt - 1;
-        if (kt == 0) {
-          if (last) attn_tile_softmax<true, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-          else attn_tile_softmax<false, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-        } else {
-          if (last) attn_tile_softmax<true, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-          else attn_tile_softmax<false, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-        }
-      }
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp) {
-          half8 pf;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) pf[i] = (half_t)(sub == 0 ? s0[8 * sp + i] : s1[8 * sp + i]);
-          const int kb = kt * 64 + sub * 32 + 16 * sp + 4 * hh;
-          {
-            const half_t* vr = sVt + l31 * ATTS_VSTR + kb;
-            const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
-            const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o0, 0, 0, 0);
-          }
-          {
-            const half_t* vr = sVt + (32 + l31) * ATTS_VSTR + kb;
-            const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
-            const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o1, 0, 0, 0);
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();   // all waves are done with sK: reuse it to turn the per-lane 8-byte pieces into whole context rows
-  if (wave_active) {
-    const float inv = 1.0f / l_run;
-    half_t* st = sK + wave * (32 * ATT_KSTR);            // 32 query rows x 64 d (row stride 72 halfs)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int d = 8 * q + 4 * hh;
-      half4 a, c;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { a[j] = f2h_sat(o0[4 * q + j] * inv); c[j] = f2h_sat(o1[4 * q + j] * inv); }
-      *(half4*)(st + l31 * ATT_KSTR + d) = a;
-      *(half4*)(st + l31 * ATT_KSTR + 32 + d) = c;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r0 = 0; r0 < 32; r0 += 8) {
-      const int row = r0 + (lane >> 3), ch = lane & 7;
-      if (q0 + row < L)
-        *(half8*)(p.ctx + (size_t)(tok0 + q0 + row) * p.ldctx + h * 64 + ch * 8) = *(const half8*)(st + row * ATT_KSTR + ch * 8);
-    }
-  }
-  }   // heads
-}
-
-// Pair form of the short-sequence kernel: the production path for L <= 192.
-// Why: the 6-wave workgroup above puts 2+2+1+1 waves on the four SIMDs, runs at one workgroup per CU (163 VGPRs) and
-// exposes its whole load phase; PMC (profiles/r01e_attn_pmc.json) shows the waves waiting 61 % of their life, the VALU
-// (softmax: ~1200 instructions per wave) busy 31 %, MFMA 9 %, and the time per (sequence, head) is the same 11 us whether
-// a workgroup handles 1 or 16 heads.  Here a 768-thread workgroup runs TWO heads of one sequence side by side (waves
-// 0-5 / 6-11: three waves on every SIMD), walks `heads_per_wg` head pairs in turn, and fetches the next pair's K, V, Q
-// rows and bias table entries into registers while the current pair is computed, so the only exposed memory latency is
-// the first pair's.  (Also tried and slower: a warp-specialised form - 6 compute waves + 2 waves that fill a second LDS
-// buffer with the next head, one barrier per head - 0.61 vs 0.42 ms/step, bit-identical; not kept.)  Per-(sequence, head) arithmetic is the short kernel's, bit for bit (shared attn_tile_softmax).
-// grid = (ceil(ceil(H/2) / heads_per_wg), B), dynamic LDS = 2 x 54272 B.
-#define ATTP_GROUP_LDS (ATTS_MAXL * ATT_KSTR * 2 + 64 * ATTS_VSTR * 2 + 2 * ATTS_MAXL * 4)
-template <int NG>   // heads side by side in one workgroup: 1 (384 threads) or 2 (768 threads)
-__global__ __launch_bounds__(NG * 384, NG == 1 ? 2 : 3) void attn_enc_pair_kernel(AttnEncArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char attp_smem[];
-  const int g = NG == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= 384));   // head of the group this wave works on
-  const int tid = threadIdx.x - g * 384;
-  unsigned char* gbase = attp_smem + g * ATTP_GROUP_LDS;
-  half_t* sK = (half_t*)gbase;
-  half_t* sVt = (half_t*)(gbase + ATTS_MAXL * ATT_KSTR * 2);
-  float* sLutX = (float*)(gbase + ATTS_MAXL * ATT_KSTR * 2 + 64 * ATTS_VSTR * 2);
-  const int b = blockIdx.y;
-  const int tok0 = p.seq_off[b];
-  const int L = p.seq_off[b + 1] - tok0;
-  const int H = p.I >> 6;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int hh = lane >> 5, l31 = lane & 31;
-  const int nkt = (L + 63) >> 6;
-  const int nrows = nkt * 64;
-  const int npairs = (H + NG - 1) / NG;
-  const int pr_end = min(npairs, ((int)blockIdx.x + 1) * p.heads_per_wg);
-
-  // loop-invariant element offsets of the rows this thread copies (the head's column offset is added per pair)
-  unsigned koff[4], voff[2][2];   // BYTE offsets from the head's column base (uniform pointer + 32-bit lane offset loads)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 384 * i, row = c >> 3, cc = c & 7;
-    const int key = row < L ? row : L - 1;
-    koff[i] = (unsigned)((tok0 + key) * p.ld + p.I + cc * 8) * 2u;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 384 * i, kp = c >> 3, cc = c & 7;
-    const int k0 = 2 * kp < L ? 2 * kp : L - 1, k1 = 2 * kp + 1 < L ? 2 * kp + 1 : L - 1;
-    voff[i][0] = (unsigned)((tok0 + k0) * p.ld + 2 * p.I + cc * 8) * 2u;
-    voff[i][1] = (unsigned)((tok0 + k1) * p.ld + 2 * p.I + cc * 8) * 2u;
-  }
-  const int q0 = wave * 32;
-  const bool wave_active = q0 < L;
-  const int qpos = q0 + l31;
-  const unsigned qoff = (unsigned)((tok0 + (qpos < L ? qpos : L - 1)) * p.ld + 8 * hh) * 2u;
-  int lut_idx = tid - (ATTS_MAXL - 1);
-  lut_idx = (lut_idx < -RK_LUT_R ? -RK_LUT_R : (lut_idx > RK_LUT_R ? RK_LUT_R : lut_idx)) + RK_LUT_R;
-  const float* lut_q = sLutX + (ATTS_MAXL - 1) - qpos + 4 * hh;   // lut_q[key - 4hh] = bias(key - qpos) * log2(e)
-
-  half8 kreg[4], vreg[2][2], qnext[4];
-  float lutreg = 0.f;
-  // The prefetch loads are issued through inline asm so that the compiler's waitcnt pass does not see them: tracked
-  // loads made it wait for most of the NEXT heads' rows at the first MFMA of the current ones (in-order vmcnt), which
-  // serialised the two again.  Rules that keep this safe: every load is unconditional (clamped rows - a conditional asm
-  // output becomes a phi, and the copy the compiler may insert for it would read the register before the data lands),
-  // issue and wait sit in the SAME loop iteration (no loop-carried copies), and the wait's "+v" operands order every
-  // use of the destinations after it.
-  auto prefetch = [&](int h) {
-    const char* hb = (const char*)(p.qkv + h * 64);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(kreg[i]) : "v"(koff[i]), "s"(hb));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(vreg[i][0]) : "v"(voff[i][0]), "s"(hb));
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(vreg[i][1]) : "v"(voff[i][1]), "s"(hb));
-    }
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(qnext[0]) : "v"(qoff), "s"(hb));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=&v"(qnext[1]) : "v"(qoff), "s"(hb));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=&v"(qnext[2]) : "v"(qoff), "s"(hb));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:96" : "=&v"(qnext[3]) : "v"(qoff), "s"(hb));
-    const float* lb = p.bias_lut + h * RK_LUT_N;
-    asm volatile("global_load_dword %0, %1, %2" : "=&v"(lutreg) : "v"(lut_idx * 4), "s"(lb));
-  };
-  auto prefetch_wait = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(kreg[0]), "+v"(kreg[1]), "+v"(kreg[2]), "+v"(kreg[3]), "+v"(vreg[0][0]), "+v"(vreg[0][1]), "+v"(vreg[1][0]),
-                   "+v"(vreg[1][1]), "+v"(qnext[0]), "+v"(qnext[1]), "+v"(qnext[2]), "+v"(qnext[3]), "+v"(lutreg)
-                 :: "memory");
-  };
-
-  const int pr_first = blockIdx.x * p.heads_per_wg;
-  half8 qf[4];
-#pragma unroll
-  for (int s_ = 0; s_ < 4; ++s_) qf[s_] = half8{};
-  // iteration pr: fetch the rows of step pr | compute + store step pr-1 | rows of step pr -> LDS.  One extra iteration
-  // drains the pipeline (its fetch re-reads the last head: harmless).
-  for (int pr = pr_first; pr <= pr_end; ++pr) {
-    {
-      const int hn = NG * (pr < pr_end ? pr : pr_end - 1) + g;
-      prefetch(hn < H ? hn : H - 1);
-    }
-    const int h = NG * (pr - 1) + g;                    // the head computed in this iteration
-    const bool head_active = pr > pr_first && h < H;
-    if (pr > pr_first) {
-      f32x16 o0, o1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-      float m_run = -1e30f, l_run = 0.f;
-      if (head_active && wave_active) {
-        for (int kt = 0; kt < ((p.ko & 1) ? 0 : nkt); ++kt) {
-          const half_t* kb_ = sK + kt * 64 * ATT_KSTR;
-          f32x16 s0, s1;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const half8 k0 = *(const half8*)(kb_ + l31 * ATT_KSTR + 16 * s + 8 * hh);
-            const half8 k1 = *(const half8*)(kb_ + (32 + l31) * ATT_KSTR + 16 * s + 8 * hh);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
-          }
-          {
-            const int key_base = kt * 64 + 4 * hh;
-            const float* lq = lut_q + kt * 64;
-            auto bias = [&](int r, int sub) { return lq[(r & 3) + 8 * (r >> 2) + 32 * sub]; };
-            const bool last = kt == nkt - 1;
-            if (kt == 0) {
-              if (last) attn_tile_softmax<true, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-              else attn_tile_softmax<false, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-            } else {
-              if (last) attn_tile_softmax<true, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-              else attn_tile_softmax<false, false>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-            }
-          }
-#pragma unroll
-          for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-              half8 pf;
-#pragma unroll
-              for (int i = 0; i < 8; ++i) pf[i] = (half_t)(sub == 0 ? s0[8 * sp + i] : s1[8 * sp + i]);
-              const int kb = kt * 64 + sub * 32 + 16 * sp + 4 * hh;
-              {
-                const half_t* vr = sVt + l31 * ATTS_VSTR + kb;
-                const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
-                const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o0, 0, 0, 0);
-              }
-              {
-                const half_t* vr = sVt + (32 + l31) * ATTS_VSTR + kb;
-                const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
-                const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o1, 0, 0, 0);
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();   // (2) everyone is done with sK: reuse it to turn the per-lane 8-byte pieces into whole context rows
-      if (head_active && wave_active) {
-        const float inv = 1.0f / l_run;
-        half_t* st = sK + wave * (32 * ATT_KSTR);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int d = 8 * q + 4 * hh;
-          half4 a, c;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { a[j] = f2h_sat(o0[4 * q + j] * inv); c[j] = f2h_sat(o1[4 * q + j] * inv); }
-          *(half4*)(st + l31 * ATT_KSTR + d) = a;
-          *(half4*)(st + l31 * ATT_KSTR + 32 + d) = c;
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r0 = 0; r0 < 32; r0 += 8) {
-          const int row = r0 + (lane >> 3), ch = lane & 7;
-          if (q0 + row < L)
-            *(half8*)(p.ctx + (size_t)(tok0 + q0 + row) * p.ldctx + h * 64 + ch * 8) = *(const half8*)(st + row * ATT_KSTR + ch * 8);
-        }
-      }
-    }
-    prefetch_wait();
-    __syncthreads();   // (3) the staging rows and tables of step pr-1 are read: LDS may be overwritten
-    if (pr < pr_end) {
-      // registers -> LDS: K rows, V^T as key pairs, the head's bias table (rows beyond the sequence are clamped copies)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = tid + 384 * i;
-        *(half8*)(sK + (c >> 3) * ATT_KSTR + (c & 7) * 8) = kreg[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int c = tid + 384 * i, kp = c >> 3, cc = c & 7;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const half2v pv = {vreg[i][0][j], vreg[i][1][j]};
-          *(half2v*)(sVt + (cc * 8 + j) * ATTS_VSTR + 2 * kp) = pv;
-        }
-      }
-      sLutX[tid] = lutreg * ATT_LOG2E;
-#pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) qf[s_] = qnext[s_];
-    }
-    __syncthreads();   // (1) the rows of step pr are in LDS
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// DMA form of the short-sequence kernel (round 3): the production path for L <= 192.
-// The pair kernel above moved K and V global -> VGPR -> LDS (V through a scalar 16-bit transpose: 16 two-byte LDS stores per
-// lane and head), ran ONE lock-step workgroup per CU with three workgroup barriers per head, and sized its grid so that
-// 320 sequences became 320 workgroups on 256 CUs.  rocprofv3 (profiles/r02d_*): 262 us per launch at 320 x 184 tokens,
-// 8 % MFMA busy, 41 % of the wave cycles waiting, 4.4 M LDS bank-conflict cycles - 29 % of the kernel's HBM floor.  Here
+// Short-sequence kernel (L <= ATT_ROW_MAXL = 192 for every sequence of the batch: the pointwise prompts) - the production path.
+// History: rounds 1-2 ran a register-staged kernel (K and V global -> VGPR -> LDS, V through a scalar 16-bit transpose, one
+// lock-step workgroup per CU, three workgroup barriers per head, online softmax per 64-key tile): 262 us per launch at
+// 320 x 184 tokens, 8 % MFMA busy, 29 % of the kernel's HBM floor (profiles/r02d_*).  This kernel replaced it in round 3
+// (the old ones are gone: two forms of the same arithmetic are two things to keep bit-identical):
 //   * K and V rows go global -> LDS by DMA (global_load_lds_dwordx4), row-major, no staging registers and no LDS stores;
-//     the bank-conflict swizzles are applied to the per-lane SOURCE address (the DMA image is lane-linear): K chunks by
-//     (row>>1)&7 for the ds_read_b128 A fragments (the GEMM's image), V chunk bit 2 by key bit 1 for the transposing reads;
+//     the bank-conflict swizzle is applied to the per-lane SOURCE address (the DMA image is lane-linear) and serves both
+//     the ds_read_b128 K fragments and the transposing V reads;
 //   * V^T fragments come straight out of the row-major image with ds_read_b64_tr_b16 (each 16-lane group reads a
 //     [4 keys][16 d] block and every lane receives one d column of it);
 //   * three row buffers rotate (K_h, V_h, K_h+1): the next head's K lands while this head is computed, V_h is fetched at
-//     the head boundary and awaited after the first key tile's QK^T + softmax with a COUNTED vmcnt - two barriers per
-//     head, neither behind an exposed memory round trip - and 75 KiB of LDS / <= 168 VGPRs put TWO such workgroups on a
-//     CU, whose phases interleave;
+//     the head boundary and awaited - a COUNTED vmcnt - only when the row's probabilities are ready: two barriers per
+//     head, neither behind an exposed memory round trip;
+//   * WHOLE-ROW softmax (ATT_ROW_MAXL above): the 96 score registers of a query row are formed by 24 back-to-back MFMAs,
+//     one maximum / one sum per row, P packed to fp16 as it is formed, P V without rescaling;
 //   * the context rows leave the registers directly: v_permlane32_swap pairs the 8-byte pieces of the two half-waves into
 //     16-byte stores (no LDS staging, no barrier);
-//   * the grid is (heads / heads_per_wg, sequences) with a few heads per workgroup, so 5120 (sequence, head) units
-//     spread evenly over 512 workgroup slots.
-// Per-(sequence, head) arithmetic is attn_tile_softmax's and the MFMA operand order of the kernels above: bit-identical.
-// grid = (ceil(H / heads_per_wg), B), 384 threads, dynamic LDS = ATTD_LDS_BYTES.
+//   * the grid is (heads / (groups x heads per group), sequences): 5120 (sequence, head) units in 1280 workgroups.
+// The tiled kernel above reproduces the same operations for such a sequence when its batch also holds a longer one.
 #define ATTD_ROWS 192
 #define ATTD_BUF_HALFS (ATTD_ROWS * 64)
 #define ATTD_LUT_N (2 * ATTD_ROWS)
@@ -788,11 +503,11 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
   float lutreg, qwarm;
   // The Q rows and the table entry of the NEXT head travel through inline asm (invisible to the waitcnt pass, which would
   // otherwise drain the DMA queue at their first use): unconditional, issued and awaited in the same loop iteration, and
-  // the wait's "+v" operands order every use behind it (the rules of the pair kernel above; tests/test_isa_guards.py).
-  // Sixteen more live registers do not fit beside the softmax at three waves per SIMD, so the Q fragments are loaded
-  // straight into qf once the head's last QK^T is done; what is issued a head ahead is one dword per row (qwarm) that
-  // pulls the row's 128-byte line into L2, so that the real loads are short.
-  auto issue_warm = [&](const LaneCtx& c, int h) {
+  // the wait's "+v" operands order every use behind it (tests/test_isa_guards.py).  Sixteen more live registers do not fit
+  // beside the 96 score registers of a row at three waves per SIMD, so the Q fragments of the next head are loaded straight
+  // into qf once the row's probabilities are packed (they have P V to arrive); what is issued a head ahead is one dword
+  // per row (qwarm) that pulls the row's 128-byte line into L2, so that the real loads are short.
+  auto issue_lut = [&](const LaneCtx& c, int h) {
     const char* hb = (const char*)(p.qkv + h * 64);
     asm volatile("global_load_dword %0, %1, %2" : "=&v"(qwarm) : "v"(c.qoff), "s"(hb) : "memory");
     const float* lb = p.bias_lut + h * RK_LUT_N;
@@ -809,8 +524,6 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(lutreg), "+v"(qwarm) :: "memory");
   };
 
-  f32x16 o0, o1;
-  float m_run, l_run;
   auto qk_tile = [&](const LaneCtx& c, const half_t* kbuf, int kt, f32x16& s0, f32x16& s1) {
     const half_t* kb_ = kbuf + kt * 64 * 64 + c.kfo0;
 #pragma unroll
@@ -823,30 +536,23 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
     }
   };
-  auto sm_tile = [&](const LaneCtx& c, const float* lut, int kt, f32x16& s0, f32x16& s1) {
+  // first half of the row softmax for key tile kt: bias, mask, running maximum (attn_tile_bias_max)
+  auto bm_tile = [&](auto maskc, const LaneCtx& c, const float* lut, int kt, f32x16& s0, f32x16& s1, float& tmax) {
     const int key_base = kt * 64 + 4 * c.hh;
-    // one opaque index per tile: all 32 table reads take their immediate offsets against ONE address register (left to the
-    // loop optimiser, the middle-tile loop carried 16 separate address registers, re-derived with 16 adds per tile)
+    // one opaque index per tile: all 32 table reads take their immediate offsets against ONE address register
     int lqi = c.lut_q + kt * 64;
     asm volatile("" : "+v"(lqi));
     const float* lq = lut + lqi;
     auto bias = [&](int r, int sub) { return lq[(r & 3) + 8 * (r >> 2) + 32 * sub]; };
-    const bool last = kt == nkt - 1;
     using BF = decltype(bias);
-    if (kt == 0) {
-      if (last) attn_tile_softmax<true, true, BF, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-      else attn_tile_softmax<false, true, BF, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-    } else {
-      if (last) attn_tile_softmax<true, false, BF, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-      else attn_tile_softmax<false, false, BF, true>(s0, s1, o0, o1, m_run, l_run, key_base, L, bias);
-    }
+    attn_tile_bias_max<decltype(maskc)::value, BF, true>(s0, s1, tmax, key_base, L, bias);
   };
   // P V of one key tile.  The V^T fragments are read with inline-asm ds_read_b64_tr_b16 (the builtin form makes the waitcnt
   // pass drain the whole DMA queue - vmcnt(0) - in front of the first read: it cannot tell the K rows still in flight for
   // the next head from the V rows being read).  Four reads (one k16 step: first / second key quad for o0 and o1) are
   // issued one step ahead of the MFMAs that consume them; LDS operations return in order, so lgkmcnt(4) retires the
   // older four.  The sched_barriers around the tile keep compiler-issued LDS reads out of the counted span.
-  auto pv_tile = [&](auto firstc, const LaneCtx& c, const half_t* vbuf, int kt, const f32x16& s0, const f32x16& s1) {
+  auto pv_tile = [&](auto firstc, const LaneCtx& c, const half_t* vbuf, int kt, const unsigned (&pp)[16], f32x16& o0, f32x16& o1) {   // pp: P as packed halfs, s0's 16 then s1's
     constexpr bool FIRST_TILE = decltype(firstc)::value;   // key tile 0: the accumulators start from zero (C = 0 in the first MFMAs)
     const unsigned vb0 = (unsigned)(size_t)(const __attribute__((address_space(3))) half_t*)(vbuf + kt * 64 * 64) ;
     unsigned va[4];                                        // byte addresses: o0 first / second key quad, o1 first / second
@@ -855,9 +561,8 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     half4 v[2][4];
     auto step = [&](auto gc, half4 (&d)[4]) {
       constexpr int g = decltype(gc)::value, sub = g >> 1, sp = g & 1;
-      half8 pf;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) pf[i] = (half_t)(sub == 0 ? s0[8 * sp + i] : s1[8 * sp + i]);
+      const attd_u32x4 pu = {pp[8 * sub + 4 * sp], pp[8 * sub + 4 * sp + 1], pp[8 * sub + 4 * sp + 2], pp[8 * sub + 4 * sp + 3]};
+      const half8 pf = __builtin_bit_cast(half8, pu);
       if constexpr (g < 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
       else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
       __builtin_amdgcn_sched_barrier(0);
@@ -884,9 +589,9 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     step(integral_constant<int, 2>{}, v[0]);
     step(integral_constant<int, 3>{}, v[1]);
   };
-  auto opaque_lane = [&]() {
-    int lane = threadIdx.x & 63;
-    asm volatile("" : "+v"(lane));
+  auto opaque_lane = [&]() {   // recomputed at every use (two instructions): no register holds the lane number across a phase
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
     return lane;
   };
 
@@ -896,7 +601,7 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     const LaneCtx c = lane_ctx(lane);
     if (dma_wave) issue_rows(lane, 1, 0, h_first);
     __builtin_amdgcn_sched_barrier(0);
-    issue_warm(c, h_first);
+    issue_lut(c, h_first);
     issue_q(c, h_first);
     wait_q();
     sLut[c.tid] = lutreg * ATT_LOG2E;
@@ -907,8 +612,14 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
   }
 
   int kb = 0, vb = 1, nb = 2;                             // buffers of K_h, V_h, K_h+1
-  auto head = [&](auto lastc, int n) {
+  // NKT: the sequence's key tiles (1 .. 3) as a compile-time constant - the head body is straight-line code, only its last
+  // tile carries the key mask
+  // ACTIVE: this wave has query rows (wave-uniform for the whole kernel, so the two forms are separate straight-line bodies:
+  // guarded by a run-time `if`, values defined in one guarded block and used in the next stayed allocated in between)
+  auto head = [&](auto lastc, auto nktc, auto activec, int n) {
     constexpr bool LAST = decltype(lastc)::value;
+    constexpr int NKT = decltype(nktc)::value;
+    constexpr bool ACTIVE = decltype(activec)::value;
     const int h = min(h_first + n, H - 1);
     const int h_next = min(h_first + n + 1, H - 1);
     const bool store_ok = n < nh_own;
@@ -922,41 +633,67 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     if constexpr (!LAST) {
       if (dma_wave) issue_rows(lane, 1, nb, h_next);
       __builtin_amdgcn_sched_barrier(0);
-      issue_warm(c, h_next);
+      issue_lut(c, h_next);
     }
     __builtin_amdgcn_sched_barrier(0);
-    f32x16 s0, s1;
-    if (wave_active) {
-      qk_tile(c, kbuf, 0, s0, s1);
-      __builtin_amdgcn_sched_barrier(0);
-      sm_tile(c, lut, 0, s0, s1);
+    // ---- scores of the whole row: up to three key tiles, MFMAs back to back ----
+    f32x16 s[NKT][2];
+    if constexpr (ACTIVE) {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) qk_tile(c, kbuf, kt, s[kt][0], s[kt][1]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- whole-row softmax (attention.h: ATT_ROW_MAXL): one maximum, one sum, P packed to fp16 as it is formed ----
+    // (every phase re-derives what it needs of the lane context from a fresh opaque lane number: nothing but the score
+    // registers lives across the phases)
+    unsigned pp[NKT][16];
+    float l_row = 1.f;
+    if constexpr (ACTIVE) {
+      const LaneCtx c1 = lane_ctx(opaque_lane());
+      float tmax = -1e30f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        if (kt == NKT - 1) bm_tile(std::integral_constant<bool, true>{}, c1, lut, kt, s[kt][0], s[kt][1], tmax);
+        else bm_tile(std::integral_constant<bool, false>{}, c1, lut, kt, s[kt][0], s[kt][1], tmax);
+      }
+      const float m_row = attn_row_max(tmax);
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+          attn_tile_exp(s[kt][0], s[kt][1], m_row, psum);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const half2v a = {(half_t)s[kt][0][2 * i], (half_t)s[kt][0][2 * i + 1]};
+            const half2v b2 = {(half_t)s[kt][1][2 * i], (half_t)s[kt][1][2 * i + 1]};
+            pp[kt][i] = __builtin_bit_cast(unsigned, a);
+            pp[kt][8 + i] = __builtin_bit_cast(unsigned, b2);
+          }
+        }
+      l_row = attn_row_sum(psum);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!LAST) issue_q(lane_ctx(opaque_lane()), h_next);   // qf has been dead since the score tiles (every wave, active or not: same vmcnt counts)
     __builtin_amdgcn_sched_barrier(0);
     // V_h: this wave's four DMA instructions are the oldest loads in flight (behind them: 4 K rows + the line touch + the
-    // table entry of the next head; the context stores of the previous head are older but at most 4, and can only make
-    // the wait stricter)
+    // table entry + the 4 Q loads of the next head; the context stores of the previous head are older but at most 4, and
+    // can only make the wait stricter)
     if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (wave_active) {
-      pv_tile(std::integral_constant<bool, true>{}, c, vbuf, 0, s0, s1);
+    f32x16 o0, o1;                                        // (local to the head: nothing of them lives across the softmax)
+    if constexpr (ACTIVE) {
+      const LaneCtx c3 = lane_ctx(opaque_lane());
+      pv_tile(std::integral_constant<bool, true>{}, c3, vbuf, 0, pp[0], o0, o1);
       __builtin_amdgcn_sched_barrier(0);
-      for (int kt = 1; kt < nkt; ++kt) {
-        qk_tile(c, kbuf, kt, s0, s1);
-        __builtin_amdgcn_sched_barrier(0);
-        sm_tile(c, lut, kt, s0, s1);
-        __builtin_amdgcn_sched_barrier(0);
-        pv_tile(std::integral_constant<bool, false>{}, c, vbuf, kt, s0, s1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      if constexpr (NKT > 1) pv_tile(std::integral_constant<bool, false>{}, c3, vbuf, 1, pp[1], o0, o1);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NKT > 2) pv_tile(std::integral_constant<bool, false>{}, c3, vbuf, 2, pp[2], o0, o1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!LAST) issue_q(c, h_next);              // the head's last QK^T is done: qf is free (every wave, active or not)
-    __builtin_amdgcn_sched_barrier(0);
     unsigned pk[2][8];                                    // the context row pieces of this lane as packed halfs
-    if (wave_active) {
-      const float inv = 1.0f / l_run;
+    if constexpr (ACTIVE) {
+      const float inv = 1.0f / l_row;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         half4 a, cc;
@@ -969,15 +706,16 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    const LaneCtx c4 = lane_ctx(opaque_lane());
     if constexpr (!LAST) {
       wait_q();                                           // K_h+1 (DMA) and the table entry landed long ago; Q_h+1 from L2
-      sLut[((n + 1) & 1) * ATTD_LUT_N + c.tid] = lutreg * ATT_LOG2E;
+      sLut[((n + 1) & 1) * ATTD_LUT_N + c4.tid] = lutreg * ATT_LOG2E;
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (wave_active) {
+    if constexpr (ACTIVE) {
       // piece q of o0 holds d = 8 q + 4 hh .. +4.  Swapping (piece 0 | hh=1) <-> (piece 2 | hh=0) and (1 | 1) <-> (3 | 0)
       // leaves d = 16 hh .. 16 hh + 16 contiguous in this lane: two 16-byte stores per 32-column half
-      half_t* dst = p.ctx + (size_t)(tok0 + (c.qpos < L ? c.qpos : L - 1)) * p.ldctx + h * 64 + 16 * c.hh;
+      half_t* dst = p.ctx + (size_t)(tok0 + (c4.qpos < L ? c4.qpos : L - 1)) * p.ldctx + h * 64 + 16 * c4.hh;
 #pragma unroll
       for (int o = 0; o < 2; ++o) {
         const auto x0 = __builtin_amdgcn_permlane32_swap(pk[o][0], pk[o][4], false, false);
@@ -986,7 +724,7 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
         const auto y1 = __builtin_amdgcn_permlane32_swap(pk[o][3], pk[o][7], false, false);
         const attd_u32x4 lo = {x0[0], x1[0], x0[1], x1[1]};
         const attd_u32x4 hi = {y0[0], y1[0], y0[1], y1[1]};
-        if (c.qpos < L && store_ok) {
+        if (c4.qpos < L && store_ok) {
           *(attd_u32x4*)(dst + 32 * o) = lo;
           *(attd_u32x4*)(dst + 32 * o + 8) = hi;
         }
@@ -1000,8 +738,15 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
       const int t = kb; kb = nb; nb = vb; vb = t;         // K_h+1 becomes K; V_h+1 goes where K_h was; K_h+2 where V_h was
     }
   };
-  for (int n = 0; n + 1 < nh; ++n) head(std::integral_constant<bool, false>{}, n);
-  head(std::integral_constant<bool, true>{}, nh - 1);
+  auto heads = [&](auto nktc, auto activec) {
+    for (int n = 0; n + 1 < nh; ++n) head(std::integral_constant<bool, false>{}, nktc, activec, n);
+    head(std::integral_constant<bool, true>{}, nktc, activec, nh - 1);
+  };
+  using Act = std::integral_constant<bool, true>;
+  if (!wave_active) heads(std::integral_constant<int, 1>{}, std::integral_constant<bool, false>{});
+  else if (nkt == 3) heads(std::integral_constant<int, 3>{}, Act{});
+  else if (nkt == 2) heads(std::integral_constant<int, 2>{}, Act{});
+  else heads(std::integral_constant<int, 1>{}, Act{});
 }
 
 // Decoder attention (self: causal + unidirectional bias; cross: zero bias, keys = encoder states of the same

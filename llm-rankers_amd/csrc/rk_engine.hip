@@ -487,25 +487,17 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
       gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xn, dm, w.qkv, dm, sl.qkv, 3 * I, T, 3 * I, dm);
     }
     {
-      // L <= 192: pair kernel - a workgroup runs two heads of a sequence side by side and walks `ppw` head pairs, sized so
-      // that the launch has at least one workgroup per CU; the per-(sequence, head) arithmetic does not depend on it.
-      // opt_attn_short: 5 = DMA-staged kernel (default); 1 = register-prefetch pair kernel (round 2's default); 2 / 4 = plain
-      // short kernels with 6 / 4 waves; 0 = tiled kernel.  All bit-identical.
-      const int NG = 1;   // (a two-heads-side-by-side form, 12 waves, measured slower: 168-VGPR cap -> spills; not instantiated)
-      const int npairs = (d.n_heads + NG - 1) / NG;
-      int ppw = 1;
-      while (ppw * 2 <= npairs && npairs % (ppw * 2) == 0 && (long)sl.n_seq * (npairs / (ppw * 2)) >= e->n_cu) ppw *= 2;
-      if (e->opt_attn_heads_per_wg > 0) ppw = e->opt_attn_heads_per_wg;
-      AttnEncArgs a{sl.qkv, sl.ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I, ppw, e->opt_attn_ko};
+      // Every sequence of the batch at most ATT_ROW_MAXL keys: the DMA kernel (attn_short = 5, the default: two six-wave groups
+      // per 768-thread workgroup; 6: one group per workgroup); otherwise, or with attn_short = 0, the tiled kernel.  The two
+      // compute a sequence bit-identically (attention.h: ATT_ROW_MAXL).
+      AttnEncArgs a{sl.qkv, sl.ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I, 1, e->opt_attn_ko};
       const double att_flops = 4.0 * (double)sl.maxL * T * I;   // exact for uniform lengths, upper bound if ragged
       Bracket br(e, st, PC_ENC_ATTN, att_flops, (double)T * 4 * I * 2.0);
-      if (sl.maxL <= ATTS_MAXL && (e->opt_attn_short == 5 || e->opt_attn_short == 6)) {
-        // 5: two six-wave groups per 768-thread workgroup (two head ranges side by side on a CU); 6: one group per workgroup.
-        // heads per group: 4 amortise a group's pipeline fill best; fewer when that would leave CUs without a workgroup
-        const int ng = e->opt_attn_short == 5 ? 2 : 1;
+      if (sl.maxL <= ATT_ROW_MAXL && e->opt_attn_short) {
+        const int ng = e->opt_attn_short == 6 ? 1 : 2;
         // heads per group: the value in {4, 2, 1} that needs the fewest head-times on the busiest CU (workgroups run one per CU:
         // rounds x heads per workgroup), the larger one on a tie (fewer pipeline fills).  320 sequences x 16 heads: 2
-        // (1280 workgroups = 5 rounds of 2 heads; 4 would be 3 rounds of 4: 145 against 155 us per launch)
+        // (1280 workgroups = 5 rounds of 2 heads; 4 would be 3 rounds of 4)
         int hpw = 4; long best = -1;
         for (int cand = 4; cand >= 1; cand >>= 1) {
           const long wgs = (long)sl.n_seq * ((d.n_heads + ng * cand - 1) / (ng * cand));
@@ -523,14 +515,6 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
           ensure_dynamic_lds((const void*)attn_enc_dma_kernel<1>, ATTD_LDS_BYTES, attr_done);
           hipLaunchKernelGGL(attn_enc_dma_kernel<1>, grid, dim3(384), ATTD_LDS_BYTES, st, a);
         }
-      } else if (sl.maxL <= ATTS_MAXL && e->opt_attn_short == 1) {
-        hipLaunchKernelGGL(attn_enc_pair_kernel<1>, dim3((npairs + ppw - 1) / ppw, sl.n_seq), dim3(384), ATTP_GROUP_LDS, st, a);
-      } else if (sl.maxL <= ATTS_MAXL && e->opt_attn_short == 2) {
-        a.heads_per_wg = 1;
-        hipLaunchKernelGGL(attn_enc_short_kernel<6>, dim3(d.n_heads, sl.n_seq), dim3(384), 0, st, a);
-      } else if (sl.maxL <= ATTS_MAXL && e->opt_attn_short) {
-        a.heads_per_wg = 1;
-        hipLaunchKernelGGL(attn_enc_short_kernel<4>, dim3(d.n_heads, sl.n_seq, (sl.maxL + 127) / 128), dim3(256), 0, st, a);
       }
       else if (e->opt_attn_tiled_occ >= 3)
         hipLaunchKernelGGL(attn_enc_kernel<3>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
@@ -1921,7 +1905,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "xattn_mfma")) { e->opt_xattn_mfma = value != 0; ++e->opt_epoch; return RK_OK; }   // query-side cross-attention: weighted sums on the matrix cores (1) or the VALU form (0)
   if (!strcmp(key, "attn_heads_per_wg")) { e->opt_attn_heads_per_wg = value; return RK_OK; }   // 0 auto
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
-  if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 5 DMA kernel (two groups per workgroup), 6 DMA kernel (one group), 1 pair kernel, 2 / 4 plain short kernels, 0 tiled
+  if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 5 (any non-zero value but 6) DMA kernel, two groups per workgroup; 6 one group; 0 tiled kernel
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
     if (set_device(e) || sync_all(e)) return RK_ERR_HIP;
@@ -1993,8 +1977,8 @@ int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_fl
   if (!strcmp(name, "occupancy")) {   // resident workgroups per CU the runtime computes for the main kernels
     if (max_floats < 6) return RK_ERR_INVALID;
     int n = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_short_kernel<4>, 256, 0); out[0] = (float)n;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_pair_kernel<1>, 384, ATTP_GROUP_LDS); out[1] = (float)n;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_kernel<2>, 256, 0); out[0] = (float)n;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (attn_enc_kernel<2, 2>), 512, 0); out[1] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f16_kernel<EPI_STORE_F16, true>, 256, GEMM_LDS_BYTES); out[2] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_pp2_kernel<EPI_STORE_F16, 0>, 512, 163840); out[3] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_kernel<1>, 256, 0); out[4] = (float)n;

@@ -265,9 +265,8 @@ def test_flan_t5_large_dims_vs_oracle_and_properties():
     np.testing.assert_array_equal(v6, full[:8])          # 64x64 small-M tiles: and again
     np.testing.assert_array_equal(v1_regs, v1_glds)      # DMA and register staging run the same arithmetic
     np.testing.assert_array_equal(v1_glds, full)         # ... and so do all tile shapes (same K order per output)
-    for mode in (0, 1, 2):                               # tiled / register-prefetch pair / plain short kernel instead of the DMA one
-        eng.set_option("attn_short", mode)
-        np.testing.assert_array_equal(eng.score(batch, [0], ids), full)
+    eng.set_option("attn_short", 0)                      # the tiled kernel instead of the DMA one
+    np.testing.assert_array_equal(eng.score(batch, [0], ids), full)
     for mode in (6, 5):                                  # DMA kernel with one / two head groups per workgroup,
         eng.set_option("attn_short", mode)
         for hpw in (1, 2, 16):                           # ... heads per group: same bits
@@ -286,9 +285,11 @@ def test_flan_t5_large_dims_vs_oracle_and_properties():
 
 
 def test_encoder_attention_kernels_bit_identical_on_ragged_batches():
-    """Every encoder attention kernel (DMA-staged default, register-prefetch pair, plain short, tiled) writes the same
-    context rows for ragged lengths around the tile edges (1, 64, 65, 128, 129, 191, 192 ...), whatever the number of heads a
-    workgroup of the DMA kernel walks - a sequence's bits must not depend on the kernel its batch selects."""
+    """The two encoder attention kernels (DMA-staged whole-row default; tiled, which walks the key tiles of a short sequence
+    twice) write the same context rows for ragged lengths around the tile edges (1, 64, 65, 128, 129, 191, 192 ...), whatever
+    the number of heads a workgroup of the DMA kernel walks, and a short sequence gets the same rows when a longer one in its
+    batch sends the whole batch to the tiled kernel (with and without the key split for sequences beyond 512 tokens) - a
+    sequence's bits must not depend on the kernel its batch selects."""
     from llmrankers import _synth
     for dims, lens in ((_synth.TOY_GATED_UNTIED, [109, 5, 64, 192, 130, 1, 65, 128, 184, 191, 2, 33, 129]),
                        (_synth.FLAN_T5_SMALL, [184, 20, 77, 192, 65, 129, 96, 1, 184, 127])):
@@ -298,15 +299,12 @@ def test_encoder_attention_kernels_bit_identical_on_ragged_batches():
         seqs = [rs.randint(2, dims.vocab, size=n).tolist() for n in lens]
         T, I = sum(lens), dims.n_heads * dims.d_kv
 
-        def ctx():
-            eng.score(seqs, [0], [3, 4])
-            return eng.debug_read("ctx", T * I).copy()
-        eng.set_option("attn_short", 2)
+        def ctx(batch=None, rows=T):
+            eng.score(batch or seqs, [0], [3, 4])
+            return eng.debug_read("ctx", rows * I).copy()
+        eng.set_option("attn_short", 0)
         ref = ctx()
         assert np.isfinite(ref).all()
-        for mode in (0, 1, 4):
-            eng.set_option("attn_short", mode)
-            np.testing.assert_array_equal(ctx(), ref, err_msg=f"attn_short={mode}")
         for mode in (5, 6):                              # two / one six-wave group(s) per workgroup
             eng.set_option("attn_short", mode)
             for hpw in (0, 1, 2, 3, 16):                 # (3 heads: a group short of heads repeats one without storing)
@@ -314,6 +312,9 @@ def test_encoder_attention_kernels_bit_identical_on_ragged_batches():
                 np.testing.assert_array_equal(ctx(), ref, err_msg=f"DMA kernel {mode}, heads_per_wg={hpw}")
         eng.set_option("attn_heads_per_wg", 0)
         eng.set_option("attn_short", 5)
+        for extra in (300, 700):                         # a longer sequence behind them: tiled kernel / tiled kernel with key split
+            longer = seqs + [rs.randint(2, dims.vocab, size=extra).tolist()]
+            np.testing.assert_array_equal(ctx(longer, T), ref, err_msg=f"short sequences beside one of {extra} tokens")
         eng.close()
 
 

@@ -1,8 +1,9 @@
 """Compile-time guards on the generated gfx950 ISA (no GPU needed: hipcc cross-compiles).
 
 Two kernels rely on properties the compiler does not promise:
-* attn_enc_pair_kernel prefetches the next head's rows with inline-asm loads that the waitcnt pass does not track; the
-  destination registers must not be read, copied or spilled before the explicit `s_waitcnt vmcnt(0)`;
+* attn_enc_dma_kernel keeps LDS-DMA loads in flight across barriers and fetches the next head's Q rows / table entry with
+  inline-asm loads that the waitcnt pass does not track; the destination registers must not be read, copied or spilled
+  before the explicit `s_waitcnt vmcnt(0)`, and no compiler-placed vmcnt wait (a tracked load, a spill) may drain the queue;
 * gemm_pp2_kernel keeps DMA loads in flight across barriers with counted vmcnt: its K loop must contain no
   `vmcnt(0)` drain and no scratch traffic.
 A compiler upgrade that breaks either would give timing-dependent garbage or a silent 2x slowdown; this test fails instead.
@@ -31,7 +32,7 @@ def isa(tmp_path_factory):
 
 def kernel_body(lines, mangled):
     start = next(i for i, l in enumerate(lines) if l.startswith(mangled + ":"))
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))   # (a kernel may hold several s_endpgm)
     return lines[start:end + 1]
 
 
@@ -41,28 +42,6 @@ def vregs(text):
         out.update(range(int(a), int(b) + 1))
     out.update(int(a) for a in re.findall(r"\bv(\d+)\b", text))
     return out
-
-
-def test_attention_prefetch_registers_untouched_until_the_wait(isa):
-    body = kernel_body(isa, "_Z20attn_enc_pair_kernelILi1EEv11AttnEncArgs")
-    dests, first, wait = set(), None, None
-    for i, l in enumerate(body):
-        in_asm = i > 0 and "ASMSTART" in body[i - 1]
-        m = re.match(r"\s*global_load_dword(?:x4)?\s+(v\[\d+:\d+\]|v\d+),", l)
-        if m and in_asm:
-            first = i if first is None else first
-            dests |= vregs(m.group(1))
-        if in_asm and "s_waitcnt vmcnt(0)" in l:
-            wait = i
-    assert first is not None and wait is not None and wait > first and len(dests) == 49, (first, wait, len(dests))
-    for i in range(first, wait):
-        code = body[i].split(";")[0]
-        if not code.strip() or code.strip().startswith(".") or "ASM" in body[i]:
-            continue
-        if i > 0 and "ASMSTART" in body[i - 1] and "global_load" in code:
-            continue
-        assert not (vregs(code) & dests), f"prefetch destination touched before the wait: {body[i].strip()}"
-    assert not any("scratch_" in l for l in body), "attention kernel spills"
 
 
 @pytest.mark.parametrize("ng", [1, 2])
@@ -75,8 +54,10 @@ def test_dma_attention_keeps_its_dma_queue_and_its_asm_destinations(isa, ng):
     assert not any("scratch_" in l for l in body), "DMA attention kernel spills"
     m = re.search(r"NumVgprs: (\d+)", "\n".join(isa[isa.index(body[-1]):isa.index(body[-1]) + 400]))
     assert m and int(m.group(1)) <= 168, "more than 168 VGPRs: three waves per SIMD (two groups per CU) no longer fit"
-    assert sum("global_load_lds_dwordx4" in l for l in body) == 16      # prologue K + {V, next K} + last head's V
-    assert sum("ds_read_b64_tr_b16" in l for l in body) == 64
+    # four head bodies (1 / 2 / 3 key tiles, and the waves without query rows), each as {V, next K} + last head's V; prologue K
+    assert sum("global_load_lds_dwordx4" in l for l in body) == 4 + 4 * 12
+    assert sum("ds_read_b64_tr_b16" in l for l in body) == 2 * 16 * (1 + 2 + 3)
+    assert sum("v_mfma_f32_32x32x16_f16" in l for l in body) == 2 * 16 * (1 + 2 + 3)
     pending, n_waits = set(), 0
     for i, l in enumerate(body):
         in_asm = i > 0 and "ASMSTART" in body[i - 1]
