@@ -15,8 +15,9 @@ struct AttnEncArgs {
   const int* seq_off;    // [B+1] token offsets of the packed batch
   const float* bias_lut; // [H][RK_LUT_N]
   int ld, ldctx, I;
-  int heads_per_wg;      // short kernel only: heads blockIdx.x * heads_per_wg .. are handled by one workgroup in turn
-  int ko;                // timing-only knock-outs (short kernel): 1 = skip the compute loop, 2 = skip the K/V/Q global loads
+  int heads_per_wg;      // DMA kernel only: (sequence, head) items per wave group, walked in turn
+  int ko;                // DMA kernel, measurement builds only: timing knock-outs (ATTD_KO)
+  int n_seq;             // DMA kernel only: sequences in the batch
 };
 
 // Flash-style encoder self-attention.  grid = (ceil(maxL/128), H, B), 256 threads = 4 waves x 32 queries.
@@ -398,6 +399,15 @@ __global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p)
 //   * the grid is (heads / (groups x heads per group), sequences): 5120 (sequence, head) units in 1280 workgroups.
 // The tiled kernel above reproduces the same operations for such a sequence when its batch also holds a longer one.
 #define ATTD_ROWS 192
+// timing-only knock-outs of this kernel (measurement builds: hipcc ... -DRK_MEASURE, loaded through RK_ENGINE_LIB; results are
+// garbage): AttnEncArgs::ko bit 0 no K / V DMA inside the head loop, 1 no score MFMAs, 2 no softmax, 4 no P V, 5 no context
+// stores.  tools/attn_dma_check.py --ko=<mask>.  Round 3, 320 x 184: all five off 58 of 140 us - what a launch costs before any
+// work: five rounds of workgroups with their prologues, the barriers and the Q / table loads of every head.
+#ifdef RK_MEASURE
+#define ATTD_KO(bit) ((p.ko >> (bit)) & 1)
+#else
+#define ATTD_KO(bit) 0
+#endif
 #define ATTD_BUF_HALFS (ATTD_ROWS * 64)
 #define ATTD_LUT_N (2 * ATTD_ROWS)
 #define ATTD_LDS_BYTES (3 * ATTD_BUF_HALFS * 2 + 2 * ATTD_LUT_N * 4)
@@ -425,6 +435,10 @@ __device__ __forceinline__ void attd_issue_vt(half4 (&d)[4], const unsigned (&va
 // it does not look for it - tools/probes/probe_resid.hip: 384-thread workgroups with >= 160 VGPRs run ONE per CU (the
 // kernel measured the same at 256 and at 512 workgroups).  Twelve waves of ONE workgroup always fit three per SIMD.  The
 // two groups share only the workgroup barriers (same sequence in both: same sequence length, same head count).
+// (Tried and dropped on the whole-row form, round 3, each bit-identical and within +-1 % or worse: three issue priorities
+// for the three waves of a SIMD (s_setprio), the next head's Q loads issued right after the score tiles instead of after
+// the softmax, the context stores deferred behind the next head's DMA issues so that the counted V wait does not also
+// wait for them: 138 against 132 us.)
 // (Tried and dropped, round 3: a full-prefetch form of the one-group kernel - four row buffers, K AND V of the next head
 // landing a whole head ahead, the next Q rows in registers of their own, context rows stored a head later, ONE barrier per
 // head, 178 VGPRs - bit-identical, 177 us per launch against 161 for the one-group and 145 for the two-group form: the
@@ -437,29 +451,50 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
   half_t* const sbuf = (half_t*)attd_smem;                                  // three [192][64] row images
   float* const sLut = (float*)(attd_smem + 3 * ATTD_BUF_HALFS * 2);         // two bias tables (this head's / the next one's)
   const int wave = __builtin_amdgcn_readfirstlane(((int)threadIdx.x - grp * 384) >> 6);
-  const int b = blockIdx.y;
-  const int tok0 = p.seq_off[b];
-  const int L = p.seq_off[b + 1] - tok0;
-  const int H = p.I >> 6;
-  // heads [h_first, h_first + nh_own) belong to this group; every group of the workgroup walks nh heads (group 0's count,
-  // the largest) so that all waves meet the same barriers - a group short of heads (H not a multiple of NG x heads_per_wg)
-  // repeats its last valid head, or head H-1, without storing
-  const int h_wg = blockIdx.x * NG * p.heads_per_wg;
-  const int nh = min(H - h_wg, p.heads_per_wg);
-  if (nh <= 0 || L <= 0) return;                                            // uniform for the whole block
-  const int h_first = min(h_wg + grp * p.heads_per_wg, H - 1);
-  const int nh_own = max(0, min(H - (h_wg + grp * p.heads_per_wg), p.heads_per_wg));
-  const int nkt = (L + 63) >> 6, nrows = nkt * 64;
-  const bool dma_wave = 32 * wave < nrows;                                  // this wave's 32 rows exist (wave-uniform)
+  // PERSISTENT: the launch is one workgroup per CU; the (sequence, head) items t = sequence x H + head are dealt out in
+  // contiguous runs of p.heads_per_wg per GROUP, and a group walks its run exactly as it used to walk the heads of one
+  // sequence - the next item's K rows, Q rows and table entry travel while the current one is computed - so a sequence
+  // boundary costs nothing and the workgroup prologue (first K / Q / table behind an exposed round trip, measured 3.4 us)
+  // is paid once per launch instead of once per five heads.  Every group of a workgroup walks as many items as group 0 (the
+  // same barriers for all waves); a group short of items repeats the last item of the batch without storing.
+  struct Item { int h, tok0, L; };                                          // wave-uniform
+  const int H = p.I >> 6, total = p.n_seq * H, per = p.heads_per_wg;
+  const int t_wg = blockIdx.x * NG * per;
+  const int n_walk = min(per, total - t_wg);
+  if (n_walk <= 0) return;                                                  // uniform for the whole block
+  const int t_first = t_wg + grp * per;
+  const int n_own = max(0, min(per, total - t_first));
+  // item n of this group = (sequence pb, head ph), stepped head by head from the group's first item (one division per
+  // launch; everything stays in scalar registers: a per-item division would run on the VALU, put the sequence index in a
+  // VGPR and turn the two offset loads into vector loads - whose wait drains the DMA queue)
+  int pb = __builtin_amdgcn_readfirstlane(min(t_first, total - 1) / H), ph = min(t_first, total - 1) - pb * H;
+  // The two token offsets of an item come by an explicit s_load_dwordx2 (inline asm, awaited with lgkmcnt(0) by item_done):
+  // behind the kernel's own global stores the compiler no longer trusts the scalar cache and would fetch them with a VECTOR
+  // load, whose vmcnt(0) drains the DMA queue in the middle of a head.  (seq_off is never written by this kernel.  An extra
+  // SMEM operation in flight can only make the compiler's counted lgkmcnt waits stricter.)
+  typedef int attd_i32x2 __attribute__((ext_vector_type(2)));
+  auto item_issue = [&](attd_i32x2& raw, int& h_out) {     // request the item at (pb, ph), then step (clamped to the batch's last item)
+    const int* src = p.seq_off + pb;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(raw) : "s"(src) : "memory");
+    h_out = ph;
+    if (ph + 1 < H) ++ph;
+    else if (pb + 1 < p.n_seq) { ++pb; ph = 0; }
+  };
+  auto item_done = [&](attd_i32x2& raw, int h) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(raw) :: "memory");
+    Item it;
+    it.h = h; it.tok0 = raw[0]; it.L = raw[1] - raw[0];
+    return it;
+  };
   const int q0 = wave * 32;
-  const bool wave_active = q0 < L;
+  // the item being computed (updated by the item loop; the lambdas below read them)
+  int tok0 = 0, L = 0;
 
   // Everything a lane derives from its lane number (fragment addresses, DMA source offsets ...) is ~25 registers.  Kept
   // across the head loop they would not fit beside the softmax at three waves per SIMD, so every head re-derives them from
   // an opaque copy of the lane number (a dozen integer instructions against ~1200 of softmax).
   struct LaneCtx {
     int hh, l31, tid, qpos;
-    unsigned qoff;       // BYTE offset of this lane's part of its query row from the head's column base
     int lut_idx;         // entry of the head's bias table this thread converts for the next head
     int lut_q;           // sLut[lut_q + key - 4hh] = bias(key - qpos) * log2(e)
     int kfo0, vfo0;      // fragment offsets (halfs), see below
@@ -467,7 +502,6 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
   auto lane_ctx = [&](int lane) {
     LaneCtx c;
     c.hh = lane >> 5; c.l31 = lane & 31; c.tid = wave * 64 + lane; c.qpos = q0 + c.l31;
-    c.qoff = ((unsigned)(tok0 + (c.qpos < L ? c.qpos : L - 1)) * (unsigned)p.ld + 8 * c.hh) * 2u;
     int li = c.tid - (ATTD_ROWS - 1);                                       // table entry tid <-> key - query = tid - 191
     c.lut_idx = (li < -RK_LUT_R ? -RK_LUT_R : (li > RK_LUT_R ? RK_LUT_R : li)) + RK_LUT_R;
     c.lut_q = (ATTD_ROWS - 1) - c.qpos + 4 * c.hh;
@@ -481,18 +515,25 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     c.vfo0 = (4 * c.hh + (i16 >> 2)) * 64 + (((2 * g1 + ((i16 & 3) >> 1)) ^ ((((i16 >> 3) & 1) << 2) | c.hh)) << 3) + 4 * (i16 & 1);
     return c;
   };
+  // BYTE offset of this lane's part of its query row of item `it` from the head's column base (rows beyond the sequence:
+  // its last row; an empty sequence: row 0 of whatever follows - loaded, never used)
+  auto q_off = [&](const LaneCtx& c, const Item& it) {
+    const int row = c.qpos < it.L ? c.qpos : max(it.L - 1, 0);
+    return ((unsigned)(it.tok0 + row) * (unsigned)p.ld + 8 * c.hh) * 2u;
+  };
   // DMA piece i of this wave fills LDS slots (4 wave + i) * 64 + lane: row r = slot >> 3, 16-B chunk c = slot & 7 (lane-
   // linear image); the global chunk it fetches is c ^ swizzle(r).
   // One swizzle serves both images: chunk ^= f(r), f = (r bit 1) << 2 | (r bit 3) << 1 | (r bit 2).  Over any 16
   // consecutive rows f takes each value twice (rows 2j, 2j+1, which sit in different halves of a 256-B bank row): the
   // ds_read_b128 K fragments are conflict-free like the GEMM's; and bit 2 follows key bit 1, so the four key rows of a
   // transposing V read occupy the four 64-B quarters of the bank row.
-  auto issue_rows = [&](int lane, int which, int buf, int h) {   // which: 1 = K columns, 2 = V columns of the fused qkv rows
-    const char* hb = (const char*)(p.qkv + which * p.I + h * 64);
+  // (every wave always issues its four pieces, whatever the sequence length: the counted vmcnt waits below rely on it)
+  auto issue_rows = [&](int lane, int which, int buf, const Item& it) {   // which: 1 = K columns, 2 = V columns of the fused qkv rows
+    const char* hb = (const char*)(p.qkv + which * p.I + it.h * 64);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int slot = (4 * wave + i) * 64 + lane, r = slot >> 3, c = slot & 7;
-      const unsigned off = ((unsigned)(tok0 + (r < L ? r : L - 1)) * (unsigned)p.ld + ((c ^ ATTD_SWZ(r)) << 3)) * 2u;
+      const unsigned off = ((unsigned)(it.tok0 + (r < it.L ? r : max(it.L - 1, 0))) * (unsigned)p.ld + ((c ^ ATTD_SWZ(r)) << 3)) * 2u;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hb + off),
                                        (__attribute__((address_space(3))) void*)(sbuf + buf * ATTD_BUF_HALFS + (4 * wave + i) * 512),
                                        16, 0, 0);
@@ -507,33 +548,53 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
   // beside the 96 score registers of a row at three waves per SIMD, so the Q fragments of the next head are loaded straight
   // into qf once the row's probabilities are packed (they have P V to arrive); what is issued a head ahead is one dword
   // per row (qwarm) that pulls the row's 128-byte line into L2, so that the real loads are short.
-  auto issue_lut = [&](const LaneCtx& c, int h) {
-    const char* hb = (const char*)(p.qkv + h * 64);
-    asm volatile("global_load_dword %0, %1, %2" : "=&v"(qwarm) : "v"(c.qoff), "s"(hb) : "memory");
-    const float* lb = p.bias_lut + h * RK_LUT_N;
+  auto issue_lut = [&](const LaneCtx& c, const Item& it) {
+    const char* hb = (const char*)(p.qkv + it.h * 64);
+    asm volatile("global_load_dword %0, %1, %2" : "=&v"(qwarm) : "v"(q_off(c, it)), "s"(hb) : "memory");
+    const float* lb = p.bias_lut + it.h * RK_LUT_N;
     asm volatile("global_load_dword %0, %1, %2" : "=&v"(lutreg) : "v"(c.lut_idx * 4), "s"(lb) : "memory");
   };
-  auto issue_q = [&](const LaneCtx& c, int h) {
-    const char* hb = (const char*)(p.qkv + h * 64);
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(qf[0]) : "v"(c.qoff), "s"(hb) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=&v"(qf[1]) : "v"(c.qoff), "s"(hb) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=&v"(qf[2]) : "v"(c.qoff), "s"(hb) : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:96" : "=&v"(qf[3]) : "v"(c.qoff), "s"(hb) : "memory");
+  auto issue_q = [&](const LaneCtx& c, const Item& it) {
+    const char* hb = (const char*)(p.qkv + it.h * 64);
+    const unsigned qo = q_off(c, it);
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(qf[0]) : "v"(qo), "s"(hb) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=&v"(qf[1]) : "v"(qo), "s"(hb) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=&v"(qf[2]) : "v"(qo), "s"(hb) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:96" : "=&v"(qf[3]) : "v"(qo), "s"(hb) : "memory");
   };
   auto wait_q = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]), "+v"(lutreg), "+v"(qwarm) :: "memory");
   };
 
-  auto qk_tile = [&](const LaneCtx& c, const half_t* kbuf, int kt, f32x16& s0, f32x16& s1) {
-    const half_t* kb_ = kbuf + kt * 64 * 64 + c.kfo0;
+  // Scores of a whole row: NKT key tiles x 4 k16 steps, two MFMAs each (keys 0-31 / 32-63 of the tile).  The K fragments of
+  // step i + 1 are requested before the MFMAs of step i (the sched_barriers pin that order; the compiler's own waitcnt pass
+  // then emits the counted waits).
+  auto qk_row = [&](auto nktc, const LaneCtx& c, const half_t* kbuf, f32x16 (&s)[decltype(nktc)::value][2]) {
+    constexpr int NKT = decltype(nktc)::value;
+    const half_t* kb_ = kbuf + c.kfo0;
+    half8 kf[2][2];
+    auto fetch = [&](int i, half8 (&d)[2]) {               // step i = 4 kt + k16 step
+      const half_t* a = kb_ + (i >> 2) * 64 * 64 + ((c.kfo0 ^ ((i & 3) << 4)) - c.kfo0);
+      d[0] = *(const half8*)a;
+      d[1] = *(const half8*)(a + 32 * 64);
+    };
+    fetch(0, kf[0]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    for (int i = 0; i < 4 * NKT; ++i) {
+      if (i + 1 < 4 * NKT) fetch(i + 1, kf[(i + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int kt = i >> 2, ks = i & 3;
+      if (ks == 0) {
+        f32x16 z;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const half8 k0 = *(const half8*)(kb_ + ((c.kfo0 ^ (s << 4)) - c.kfo0));
-      const half8 k1 = *(const half8*)(kb_ + 32 * 64 + ((c.kfo0 ^ (s << 4)) - c.kfo0));
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[s], s1, 0, 0, 0);
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        s[kt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i & 1][0], qf[ks], z, 0, 0, 0);
+        s[kt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i & 1][1], qf[ks], z, 0, 0, 0);
+      } else {
+        s[kt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i & 1][0], qf[ks], s[kt][0], 0, 0, 0);
+        s[kt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i & 1][1], qf[ks], s[kt][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // first half of the row softmax for key tile kt: bias, mask, running maximum (attn_tile_bias_max)
@@ -595,14 +656,19 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     return lane;
   };
 
-  // ---- prologue: K rows, Q rows and table of the first head -------------------------------------------------------
+  // ---- prologue: K rows, Q rows and table of the group's first item ---------------------------------------------------
+  attd_i32x2 raw0, raw1;
+  int ih0, ih1;
+  item_issue(raw0, ih0);
+  item_issue(raw1, ih1);
+  Item cur = item_done(raw0, ih0), nxt = item_done(raw1, ih1);
   {
     const int lane = opaque_lane();
     const LaneCtx c = lane_ctx(lane);
-    if (dma_wave) issue_rows(lane, 1, 0, h_first);
+    issue_rows(lane, 1, 0, cur);
     __builtin_amdgcn_sched_barrier(0);
-    issue_lut(c, h_first);
-    issue_q(c, h_first);
+    issue_lut(c, cur);
+    issue_q(c, cur);
     wait_q();
     sLut[c.tid] = lutreg * ATT_LOG2E;
     __builtin_amdgcn_sched_barrier(0);
@@ -620,27 +686,31 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     constexpr bool LAST = decltype(lastc)::value;
     constexpr int NKT = decltype(nktc)::value;
     constexpr bool ACTIVE = decltype(activec)::value;
-    const int h = min(h_first + n, H - 1);
-    const int h_next = min(h_first + n + 1, H - 1);
-    const bool store_ok = n < nh_own;
+    const int h = cur.h;
+    const bool store_ok = n < n_own;
     const int lane = opaque_lane();
     const LaneCtx c = lane_ctx(lane);
     const half_t* kbuf = sbuf + kb * ATTD_BUF_HALFS;
     const half_t* vbuf = sbuf + vb * ATTD_BUF_HALFS;
     const float* lut = sLut + (n & 1) * ATTD_LUT_N;
     // everyone is past the barrier that ended head h-1: its K and V buffers are free
-    if (dma_wave) issue_rows(lane, 2, vb, h);
+    if (!ATTD_KO(0)) issue_rows(lane, 2, vb, cur);
     if constexpr (!LAST) {
-      if (dma_wave) issue_rows(lane, 1, nb, h_next);
+      if (!ATTD_KO(0)) issue_rows(lane, 1, nb, nxt);
       __builtin_amdgcn_sched_barrier(0);
-      issue_lut(c, h_next);
+      issue_lut(c, nxt);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- scores of the whole row: up to three key tiles, MFMAs back to back ----
     f32x16 s[NKT][2];
     if constexpr (ACTIVE) {
+      if (!ATTD_KO(1)) qk_row(nktc, c, kbuf, s);
+      else {
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) qk_tile(c, kbuf, kt, s[kt][0], s[kt][1]);
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[kt][0][r] = 0.25f * r; s[kt][1][r] = 0.5f; }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- whole-row softmax (attention.h: ATT_ROW_MAXL): one maximum, one sum, P packed to fp16 as it is formed ----
@@ -651,16 +721,18 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     if constexpr (ACTIVE) {
       const LaneCtx c1 = lane_ctx(opaque_lane());
       float tmax = -1e30f;
+      if (!ATTD_KO(2)) {
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
-        if (kt == NKT - 1) bm_tile(std::integral_constant<bool, true>{}, c1, lut, kt, s[kt][0], s[kt][1], tmax);
-        else bm_tile(std::integral_constant<bool, false>{}, c1, lut, kt, s[kt][0], s[kt][1], tmax);
+        for (int kt = 0; kt < NKT; ++kt) {
+          if (kt == NKT - 1) bm_tile(std::integral_constant<bool, true>{}, c1, lut, kt, s[kt][0], s[kt][1], tmax);
+          else bm_tile(std::integral_constant<bool, false>{}, c1, lut, kt, s[kt][0], s[kt][1], tmax);
+        }
       }
       const float m_row = attn_row_max(tmax);
       float psum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
-          attn_tile_exp(s[kt][0], s[kt][1], m_row, psum);
+          if (!ATTD_KO(2)) attn_tile_exp(s[kt][0], s[kt][1], m_row, psum);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const half2v a = {(half_t)s[kt][0][2 * i], (half_t)s[kt][0][2 * i + 1]};
@@ -672,7 +744,7 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
       l_row = attn_row_sum(psum);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!LAST) issue_q(lane_ctx(opaque_lane()), h_next);   // qf has been dead since the score tiles (every wave, active or not: same vmcnt counts)
+    if constexpr (!LAST) issue_q(lane_ctx(opaque_lane()), nxt);   // qf has been dead since the score tiles (every wave, active or not: same vmcnt counts)
     __builtin_amdgcn_sched_barrier(0);
     // V_h: this wave's four DMA instructions are the oldest loads in flight (behind them: 4 K rows + the line touch + the
     // table entry + the 4 Q loads of the next head; the context stores of the previous head are older but at most 4, and
@@ -684,11 +756,16 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     f32x16 o0, o1;                                        // (local to the head: nothing of them lives across the softmax)
     if constexpr (ACTIVE) {
       const LaneCtx c3 = lane_ctx(opaque_lane());
-      pv_tile(std::integral_constant<bool, true>{}, c3, vbuf, 0, pp[0], o0, o1);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (NKT > 1) pv_tile(std::integral_constant<bool, false>{}, c3, vbuf, 1, pp[1], o0, o1);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (NKT > 2) pv_tile(std::integral_constant<bool, false>{}, c3, vbuf, 2, pp[2], o0, o1);
+      if (!ATTD_KO(4)) {
+        pv_tile(std::integral_constant<bool, true>{}, c3, vbuf, 0, pp[0], o0, o1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NKT > 1) pv_tile(std::integral_constant<bool, false>{}, c3, vbuf, 1, pp[1], o0, o1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NKT > 2) pv_tile(std::integral_constant<bool, false>{}, c3, vbuf, 2, pp[2], o0, o1);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = __builtin_bit_cast(float, pp[0][r]); o1[r] = __builtin_bit_cast(float, pp[NKT - 1][r]); }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     unsigned pk[2][8];                                    // the context row pieces of this lane as packed halfs
@@ -724,7 +801,7 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
         const auto y1 = __builtin_amdgcn_permlane32_swap(pk[o][3], pk[o][7], false, false);
         const attd_u32x4 lo = {x0[0], x1[0], x0[1], x1[1]};
         const attd_u32x4 hi = {y0[0], y1[0], y0[1], y1[1]};
-        if (c4.qpos < L && store_ok) {
+        if (c4.qpos < L && store_ok && !ATTD_KO(5)) {
           *(attd_u32x4*)(dst + 32 * o) = lo;
           *(attd_u32x4*)(dst + 32 * o + 8) = hi;
         }
@@ -738,15 +815,28 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
       const int t = kb; kb = nb; nb = vb; vb = t;         // K_h+1 becomes K; V_h+1 goes where K_h was; K_h+2 where V_h was
     }
   };
-  auto heads = [&](auto nktc, auto activec) {
-    for (int n = 0; n + 1 < nh; ++n) head(std::integral_constant<bool, false>{}, nktc, activec, n);
-    head(std::integral_constant<bool, true>{}, nktc, activec, nh - 1);
-  };
-  using Act = std::integral_constant<bool, true>;
-  if (!wave_active) heads(std::integral_constant<int, 1>{}, std::integral_constant<bool, false>{});
-  else if (nkt == 3) heads(std::integral_constant<int, 3>{}, Act{});
-  else if (nkt == 2) heads(std::integral_constant<int, 2>{}, Act{});
-  else heads(std::integral_constant<int, 1>{}, Act{});
+  // the item loop: every item picks its head body by its own sequence length (key tiles; waves without query rows idle
+  // through the same barriers)
+  using T = std::integral_constant<bool, true>; using F = std::integral_constant<bool, false>;
+  using N1 = std::integral_constant<int, 1>; using N2 = std::integral_constant<int, 2>; using N3 = std::integral_constant<int, 3>;
+  for (int n = 0; n < n_walk; ++n) {
+    tok0 = cur.tok0; L = cur.L;
+    item_issue(raw0, ih0);                                // item n + 2: its offsets have the whole item to arrive
+    const int nkt = (L + 63) >> 6;
+    const bool active = q0 < L;
+    if (n + 1 < n_walk) {
+      if (!active) head(F{}, N1{}, F{}, n);
+      else if (nkt == 3) head(F{}, N3{}, T{}, n);
+      else if (nkt == 2) head(F{}, N2{}, T{}, n);
+      else head(F{}, N1{}, T{}, n);
+    } else {
+      if (!active) head(T{}, N1{}, F{}, n);
+      else if (nkt == 3) head(T{}, N3{}, T{}, n);
+      else if (nkt == 2) head(T{}, N2{}, T{}, n);
+      else head(T{}, N1{}, T{}, n);
+    }
+    cur = nxt; nxt = item_done(raw0, ih0);
+  }
 }
 
 // Decoder attention (self: causal + unidirectional bias; cross: zero bias, keys = encoder states of the same

@@ -495,17 +495,13 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
       Bracket br(e, st, PC_ENC_ATTN, att_flops, (double)T * 4 * I * 2.0);
       if (sl.maxL <= ATT_ROW_MAXL && e->opt_attn_short) {
         const int ng = e->opt_attn_short == 6 ? 1 : 2;
-        // heads per group: the value in {4, 2, 1} that needs the fewest head-times on the busiest CU (workgroups run one per CU:
-        // rounds x heads per workgroup), the larger one on a tie (fewer pipeline fills).  320 sequences x 16 heads: 2
-        // (1280 workgroups = 5 rounds of 2 heads; 4 would be 3 rounds of 4)
-        int hpw = 4; long best = -1;
-        for (int cand = 4; cand >= 1; cand >>= 1) {
-          const long wgs = (long)sl.n_seq * ((d.n_heads + ng * cand - 1) / (ng * cand));
-          const long cost = ((wgs + e->n_cu - 1) / e->n_cu) * cand;
-          if (best < 0 || cost < best) { best = cost; hpw = cand; }
-        }
-        a.heads_per_wg = e->opt_attn_heads_per_wg > 0 ? e->opt_attn_heads_per_wg : hpw;
-        const dim3 grid((d.n_heads + ng * a.heads_per_wg - 1) / (ng * a.heads_per_wg), sl.n_seq);
+        // persistent launch: at most one workgroup per CU, the (sequence, head) items dealt out evenly in contiguous runs per
+        // wave group (320 sequences x 16 heads on 256 CUs x 2 groups: 10 items each)
+        const long total = (long)sl.n_seq * d.n_heads, groups = (long)e->n_cu * ng;
+        const int per = e->opt_attn_heads_per_wg > 0 ? e->opt_attn_heads_per_wg : (int)((total + groups - 1) / groups);
+        a.heads_per_wg = per;
+        a.n_seq = sl.n_seq;
+        const dim3 grid((unsigned)((total + (long)ng * per - 1) / ((long)ng * per)));
         if (ng == 2) {
           static std::atomic<uint64_t> attr_done{0};
           ensure_dynamic_lds((const void*)attn_enc_dma_kernel<2>, 2 * ATTD_LDS_BYTES, attr_done);

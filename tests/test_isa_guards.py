@@ -76,6 +76,22 @@ def test_dma_attention_keeps_its_dma_queue_and_its_asm_destinations(isa, ng):
             continue
         assert not (vregs(code) & pending), f"asm load destination touched before its wait: {l.strip()}"
     assert n_waits >= 4
+    # the token offsets of the next-but-one item: explicit s_load_dwordx2 (a compiler-issued vector load would put a vmcnt(0) in
+    # the middle of a head); its destination pair is not read or copied before the asm lgkmcnt(0) that follows it
+    n_sloads = 0
+    for i, l in enumerate(body):
+        m = re.match(r"\s*s_load_dwordx2 s\[(\d+):(\d+)\]", l)
+        if not (m and "ASMSTART" in body[i - 1]):
+            continue
+        n_sloads += 1
+        a, b = int(m.group(1)), int(m.group(2))
+        for j in range(i + 1, len(body)):
+            if "s_waitcnt lgkmcnt(0)" in body[j] and "ASMSTART" in body[j - 1]:
+                break
+            code = body[j].split(";")[0]
+            assert not re.search(rf"\bs{a}\b|\bs{b}\b|s\[{a}:{b}\]", code), f"offset pair touched before its wait: {code.strip()}"
+    assert n_sloads == 3                                  # two in the prologue, one per item in the loop
+    assert not any(re.match(r"\s*global_load_dwordx2", l) for l in body), "vector load of the token offsets"
 
 
 # (epilogue kind, folded-RMSNorm row factors): every product instantiation of the ping-pong kernel

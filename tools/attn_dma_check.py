@@ -57,6 +57,10 @@ def exactness():
     return ok
 
 
+# extra timing variants with the timing-only knock-outs of a measurement build (hipcc ... -DRK_MEASURE, RK_ENGINE_LIB=<that .so>)
+KO = [int(a[5:]) for a in sys.argv[1:] if a.startswith("--ko=")]
+
+
 def timing():
     import bench
     from llmrankers import _synth
@@ -70,8 +74,9 @@ def timing():
     slot_seqs = [[s for j in range(G) for s in _synth.synth_token_batch(B, L, L, dims.vocab, seed=929 + 8 * sl + j)]
                  for sl in range(eng.num_slots)]
     ref_scores = None
-    variants = [("tiled", 0, 0)] + [("dma1", 6, 4)] + [("dma2", 5, h) for h in (1, 2, 4)]
+    variants = [("tiled", 0, 0)] + [("dma1", 6, 0)] + [("dma2", 5, h) for h in (0, 2, 5, 20)] + [("dma2_ko%d" % k, 5, 2) for k in KO]
     for name, mode, hpw in variants:
+        eng.set_option("attn_ko", int(name.split("_ko")[1]) if "_ko" in name else 0) if KO else None
         eng.set_option("attn_short", mode)
         eng.set_option("attn_heads_per_wg", hpw)
         eng.stage(slot_seqs[0], slot=0)
@@ -92,8 +97,9 @@ def timing():
                           "launches": a["launches"], "scores_identical_to_tiled": bool(np.array_equal(sc, ref_scores)),
                           "total_ms_per_step": round(sum(v["ms"] for v in rep.values()) / (2 * G), 3)}), flush=True)
     # whole-pipeline passages/s, interleaved A/B (two rounds)
-    for rnd in range(2):
-        for name, mode, hpw in (("dma1", 6, 4), ("dma2", 5, 2), ("dma2", 5, 4)):
+    for rnd in range(0 if "--no-pipeline" in sys.argv else 2):
+        for name, mode, hpw in [("dma1", 6, 0), ("dma2", 5, 0), ("dma2", 5, 5)] + [("dma2_ko%d" % k, 5, 2) for k in KO]:
+            eng.set_option("attn_ko", int(name.split("_ko")[1]) if "_ko" in name else 0) if KO else None
             eng.set_option("attn_short", mode)
             eng.set_option("attn_heads_per_wg", hpw)
             pipe = bench.GroupPipeline(eng, slot_seqs, B, G, [0], [bench.YES_ID, bench.NO_ID])
@@ -107,8 +113,10 @@ def timing():
 if __name__ == "__main__":
     import torch  # noqa: F401  (its HIP runtime first)
     import __graft_entry__ as ge
-    ge.build()
-    ok = exactness()
-    print(json.dumps({"exactness_ok": ok}), flush=True)
+    if not os.environ.get("RK_ENGINE_LIB"):
+        ge.build()
+    if "--no-exact" not in sys.argv:
+        ok = exactness()
+        print(json.dumps({"exactness_ok": ok}), flush=True)
     if "--no-timing" not in sys.argv:
         timing()
