@@ -18,6 +18,7 @@ struct AttnEncArgs {
   int heads_per_wg;      // DMA kernel only: (sequence, head) items per wave group, walked in turn
   int ko;                // DMA kernel, measurement builds only: timing knock-outs (ATTD_KO)
   int n_seq;             // DMA kernel only: sequences in the batch
+  float* trace;          // DMA kernel, measurement builds only: phase time stamps of one workgroup (ATTD_STAMP), else nullptr
 };
 
 // Flash-style encoder self-attention.  grid = (ceil(maxL/128), H, B), 256 threads = 4 waves x 32 queries.
@@ -403,10 +404,15 @@ __global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p)
 // garbage): AttnEncArgs::ko bit 0 no K / V DMA inside the head loop, 1 no score MFMAs, 2 no softmax, 4 no P V, 5 no context
 // stores.  tools/attn_dma_check.py --ko=<mask>.  Round 3, 320 x 184: all five off 58 of 140 us - what a launch costs before any
 // work: five rounds of workgroups with their prologues, the barriers and the Q / table loads of every head.
+// ATTD_STAMP(k): wave `wave + 6 grp` of workgroup 7 records the 100 MHz wall clock (ticks since its start) at phase boundary k
+// of every item: p.trace[(wave12 * 16 + item) * 16 + k]  (engine option attn_trace, rk_debug_read("attn_trace"))
 #ifdef RK_MEASURE
 #define ATTD_KO(bit) ((p.ko >> (bit)) & 1)
+#define ATTD_STAMP(k) do { if (p.trace && blockIdx.x == 7 && n < 16) { const long long t_ = wall_clock64(); \
+    if ((threadIdx.x & 63) == 0) p.trace[((wave + 6 * grp) * 16 + n) * 16 + (k)] = (float)(int)(t_ - attd_t0); } } while (0)
 #else
 #define ATTD_KO(bit) 0
+#define ATTD_STAMP(k) do { } while (0)
 #endif
 #define ATTD_BUF_HALFS (ATTD_ROWS * 64)
 #define ATTD_LUT_N (2 * ATTD_ROWS)
@@ -487,6 +493,9 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     return it;
   };
   const int q0 = wave * 32;
+#ifdef RK_MEASURE
+  const long long attd_t0 = wall_clock64();
+#endif
   // the item being computed (updated by the item loop; the lambdas below read them)
   int tok0 = 0, L = 0;
 
@@ -694,13 +703,14 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     const half_t* vbuf = sbuf + vb * ATTD_BUF_HALFS;
     const float* lut = sLut + (n & 1) * ATTD_LUT_N;
     // everyone is past the barrier that ended head h-1: its K and V buffers are free
+    ATTD_STAMP(0);
     if (!ATTD_KO(0)) issue_rows(lane, 2, vb, cur);
     if constexpr (!LAST) {
-      if (!ATTD_KO(0)) issue_rows(lane, 1, nb, nxt);
       __builtin_amdgcn_sched_barrier(0);
       issue_lut(c, nxt);
     }
     __builtin_amdgcn_sched_barrier(0);
+    ATTD_STAMP(1);
     // ---- scores of the whole row: up to three key tiles, MFMAs back to back ----
     f32x16 s[NKT][2];
     if constexpr (ACTIVE) {
@@ -713,6 +723,7 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    ATTD_STAMP(2);
     // ---- whole-row softmax (attention.h: ATT_ROW_MAXL): one maximum, one sum, P packed to fp16 as it is formed ----
     // (every phase re-derives what it needs of the lane context from a fresh opaque lane number: nothing but the score
     // registers lives across the phases)
@@ -729,6 +740,7 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
         }
       }
       const float m_row = attn_row_max(tmax);
+      ATTD_STAMP(3);
       float psum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
@@ -744,15 +756,31 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
       l_row = attn_row_sum(psum);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!LAST) issue_q(lane_ctx(opaque_lane()), nxt);   // qf has been dead since the score tiles (every wave, active or not: same vmcnt counts)
+    ATTD_STAMP(4);
+    // The next item's K rows go out HERE, not at the top of the item beside V: the phase stamps of a measurement build
+    // (tools/attn_trace.py) showed the twelve waves of a CU spending 1.6 us (first group) / 3.6 us (second, queued behind the
+    // first) of a 12-us item just ISSUING their 96 DMA instructions - the address path takes ~30 KB/us per CU - and the first
+    // group then waiting for the second at the barrier.  V alone (needed first) is half of that; K_i+1 is not needed before the
+    // next item and queues behind the softmax instead: 117 -> 115 us per launch.  (The counted wait below is unchanged: V is
+    // still the oldest.  Letting the second group issue its V rows behind its score tiles as well, so that the two groups'
+    // bursts do not meet, changed nothing: the second group's waves are the younger ones and lose every arbitration, not
+    // just this one - the first group waits ~3 us of every item for them at the barriers.)
+    if constexpr (!LAST) {
+      const int lane4 = opaque_lane();
+      if (!ATTD_KO(0)) issue_rows(lane4, 1, nb, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      issue_q(lane_ctx(lane4), nxt);                      // qf has been dead since the score tiles (every wave, active or not: same vmcnt counts)
+    }
     __builtin_amdgcn_sched_barrier(0);
-    // V_h: this wave's four DMA instructions are the oldest loads in flight (behind them: 4 K rows + the line touch + the
-    // table entry + the 4 Q loads of the next head; the context stores of the previous head are older but at most 4, and
+    // V_h: this wave's four DMA instructions are the oldest loads in flight (behind them: the line touch + the table entry,
+    // 4 K rows and the 4 Q loads of the next item; the context stores of the previous head are older but at most 4, and
     // can only make the wait stricter)
     if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    ATTD_STAMP(5);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    ATTD_STAMP(6);
     f32x16 o0, o1;                                        // (local to the head: nothing of them lives across the softmax)
     if constexpr (ACTIVE) {
       const LaneCtx c3 = lane_ctx(opaque_lane());
@@ -768,6 +796,7 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    ATTD_STAMP(7);
     unsigned pk[2][8];                                    // the context row pieces of this lane as packed halfs
     if constexpr (ACTIVE) {
       const float inv = 1.0f / l_row;
@@ -784,11 +813,13 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     }
     __builtin_amdgcn_sched_barrier(0);
     const LaneCtx c4 = lane_ctx(opaque_lane());
+    ATTD_STAMP(8);
     if constexpr (!LAST) {
       wait_q();                                           // K_h+1 (DMA) and the table entry landed long ago; Q_h+1 from L2
       sLut[((n + 1) & 1) * ATTD_LUT_N + c4.tid] = lutreg * ATT_LOG2E;
     }
     __builtin_amdgcn_sched_barrier(0);
+    ATTD_STAMP(9);
     if constexpr (ACTIVE) {
       // piece q of o0 holds d = 8 q + 4 hh .. +4.  Swapping (piece 0 | hh=1) <-> (piece 2 | hh=0) and (1 | 1) <-> (3 | 0)
       // leaves d = 16 hh .. 16 hh + 16 contiguous in this lane: two 16-byte stores per 32-column half
@@ -807,11 +838,13 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
         }
       }
     }
+    ATTD_STAMP(10);
     if constexpr (!LAST) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): table written, every LDS read of this head retired
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      ATTD_STAMP(11);
       const int t = kb; kb = nb; nb = vb; vb = t;         // K_h+1 becomes K; V_h+1 goes where K_h was; K_h+2 where V_h was
     }
   };

@@ -107,6 +107,7 @@ struct rk_engine {
   Slot slots[RK_SLOTS];
   // options / measurement
   int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1;
+  float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
@@ -491,6 +492,9 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
       // per 768-thread workgroup; 6: one group per workgroup); otherwise, or with attn_short = 0, the tiled kernel.  The two
       // compute a sequence bit-identically (attention.h: ATT_ROW_MAXL).
       AttnEncArgs a{sl.qkv, sl.ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I, 1, e->opt_attn_ko};
+#ifdef RK_MEASURE
+      a.trace = e->attn_trace;
+#endif
       const double att_flops = 4.0 * (double)sl.maxL * T * I;   // exact for uniform lengths, upper bound if ragged
       Bracket br(e, st, PC_ENC_ATTN, att_flops, (double)T * 4 * I * 2.0);
       if (sl.maxL <= ATT_ROW_MAXL && e->opt_attn_short) {
@@ -1896,6 +1900,11 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "dec_fold_norm")) { e->opt_dec_fold_norm = value != 0; return RK_OK; }   // decoder RMSNorms folded into the weight-streaming GEMMs (1) or separate kernels (0)
   if (!strcmp(key, "fold_norm")) { e->opt_fold_norm = value != 0; return RK_OK; }           // encoder RMSNorm folded into the GEMMs (1) or separate kernels (0)
 #ifdef RK_MEASURE
+  if (!strcmp(key, "attn_trace")) {   // phase time stamps of one workgroup of the DMA attention kernel (attention.h: ATTD_STAMP)
+    if (value && !e->attn_trace) { if (hipMalloc(&e->attn_trace, 12 * 16 * 16 * sizeof(float)) != hipSuccess) return RK_ERR_HIP; hipMemset(e->attn_trace, 0, 12 * 16 * 16 * sizeof(float)); }
+    if (!value && e->attn_trace) { hipFree(e->attn_trace); e->attn_trace = nullptr; }
+    return RK_OK;
+  }
   if (!strcmp(key, "attn_ko")) { e->opt_attn_ko = value; return RK_OK; }   // timing-only knock-outs, see AttnEncArgs
 #endif
   if (!strcmp(key, "xattn_mfma")) { e->opt_xattn_mfma = value != 0; ++e->opt_epoch; return RK_OK; }   // query-side cross-attention: weighted sums on the matrix cores (1) or the VALU form (0)
@@ -1992,6 +2001,9 @@ int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_fl
   const int I = e->inner, dm = e->d.d_model;
   const void* src = nullptr; int64_t cnt = 0; bool is_half = true;
   if (n == "enc_hidden") { src = sl.hidden; cnt = (int64_t)sl.T * dm; is_half = false; }
+#ifdef RK_MEASURE
+  else if (n == "attn_trace" && e->attn_trace) { src = e->attn_trace; cnt = 12 * 16 * 16; is_half = false; }
+#endif
   else if (n == "enc_out") { src = sl.enc_out; cnt = (int64_t)sl.T * dm; }
   else if (n == "qkv") { src = sl.qkv; cnt = (int64_t)sl.T * 3 * I; }
   else if (n == "ctx") { src = sl.ctx; cnt = (int64_t)sl.T * I; }

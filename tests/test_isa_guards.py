@@ -54,7 +54,7 @@ def test_dma_attention_keeps_its_dma_queue_and_its_asm_destinations(isa, ng):
     assert not any("scratch_" in l for l in body), "DMA attention kernel spills"
     m = re.search(r"NumVgprs: (\d+)", "\n".join(isa[isa.index(body[-1]):isa.index(body[-1]) + 400]))
     assert m and int(m.group(1)) <= 168, "more than 168 VGPRs: three waves per SIMD (two groups per CU) no longer fit"
-    # four head bodies (1 / 2 / 3 key tiles, and the waves without query rows), each as {V, next K} + last head's V; prologue K
+    # four item bodies (1 / 2 / 3 key tiles, and the waves without query rows), each as {V, next K} + last item's V; prologue K
     assert sum("global_load_lds_dwordx4" in l for l in body) == 4 + 4 * 12
     assert sum("ds_read_b64_tr_b16" in l for l in body) == 2 * 16 * (1 + 2 + 3)
     assert sum("v_mfma_f32_32x32x16_f16" in l for l in body) == 2 * 16 * (1 + 2 + 3)
