@@ -318,6 +318,39 @@ def test_encoder_attention_kernels_bit_identical_on_ragged_batches():
         eng.close()
 
 
+def test_encoder_attention_persistent_walk_on_random_batches():
+    """The persistent DMA attention kernel deals (sequence, head) items out in contiguous runs per wave group and prefetches
+    across sequence boundaries: random batch shapes (1 .. 40 sequences of 1 .. 192 tokens, 3 and 6 heads, forced and automatic
+    run lengths - runs that end inside a sequence, groups without items, a last workgroup short of items) against the tiled
+    kernel, bit for bit."""
+    from llmrankers import _synth
+    rs = np.random.RandomState(7)
+    for dims in (_synth.TOY_GATED_UNTIED, _synth.FLAN_T5_SMALL):
+        state = _synth.synth_state_dict(dims, 5, gain=2.0)
+        eng = _engine(dims, state, max_tokens=8192, max_seqs=48, max_dec_len=4)
+        I = dims.n_heads * dims.d_kv
+        for trial in range(10):
+            n = int(rs.randint(1, 41))
+            lens = [int(x) for x in rs.choice([1, 2, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 150, 184, 191, 192], size=n)]
+            while sum(lens) > 8000:
+                lens.pop()
+            seqs = [rs.randint(2, dims.vocab, size=m).tolist() for m in lens]
+            T = sum(lens)
+
+            def ctx():
+                eng.score(seqs, [0], [3, 4])
+                return eng.debug_read("ctx", T * I).copy()
+            eng.set_option("attn_short", 0)
+            ref = ctx()
+            for mode, per in ((5, 0), (5, int(rs.randint(1, 8))), (6, 0), (6, int(rs.randint(1, 30)))):
+                eng.set_option("attn_short", mode)
+                eng.set_option("attn_heads_per_wg", per)
+                np.testing.assert_array_equal(ctx(), ref, err_msg=f"trial {trial}: lens={lens} mode={mode} items per group={per}")
+            eng.set_option("attn_heads_per_wg", 0)
+            eng.set_option("attn_short", 5)
+        eng.close()
+
+
 def test_capacity_and_argument_errors(toy):
     from llmrankers._engine import RkError
     dims, state, eng = toy["ckpt_gated_untied"]
