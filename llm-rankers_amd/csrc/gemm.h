@@ -262,6 +262,17 @@ __device__ __forceinline__ void gemm_epilogue_lse(const GemmArgs& p, f32x16 (&ac
   }
 }
 
+// Cache policy of the epilogue's memory traffic.  The outputs of the big GEMMs (120 - 360 MB per launch) and the old rows of the
+// fp32 stream are touched once per launch; written / read with the default policy they pass through the 4 MiB L2 of the XCD
+// and displace the A / W panels the co-resident tiles share.  Non-temporal hint (`nt`) on: bit 0 the read of the old fp32
+// rows, bit 1 the fp32 rows written back, bit 2 the fp16 tile stores (QKV, GEGLU / ReLU outputs), bit 3 the fp16 copy of the
+// stream.  Measured round 3 (separate libraries, one box, tools/ab_profile.py): bits 0-1 +0.4 %, bits 0-2 +1.6 % (7 485 ->
+// 7 600 passages/s; QKV 0.864 -> 0.818, FFN-in 1.56 -> 1.51 ms per step), bit 3 nothing.  The LOADS of the panels must stay
+// cacheable: `nt` on the A-panel DMA -4 %, on the W-panel DMA -8 % (GEMM_A_AUX / GEMM_W_AUX below); and the attention kernel's
+// context stores (16-byte pieces, not whole lines) got 20 % slower with it.
+#ifndef GEMM_EPI_NT
+#define GEMM_EPI_NT 7
+#endif
 template <int EPI, int NI, int MI, bool RESID_IN_ACC = false, int ROWS = 32, int DEPTH = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase,
                                                      int lane, unsigned char* stage, const float (&rsc)[MI]) {
@@ -303,7 +314,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
       int m = mbase + mi * 32 + hp * ROWS + row;
       m = m < p.M ? m : p.M - 1;                                 // clamped rows are never stored
       const int nn = n_ok ? n : 0;
-      oldv[RMW ? sl : 0][i] = *(const f32x4*)((const float*)p.C + cbase + (size_t)m * p.ldc + nn);
+      const f32x4* src_ = (const f32x4*)((const float*)p.C + cbase + (size_t)m * p.ldc + nn);
+      if constexpr (GEMM_EPI_NT != 0) oldv[RMW ? sl : 0][i] = __builtin_nontemporal_load(src_);
+      else oldv[RMW ? sl : 0][i] = *src_;
     }
   };
   if constexpr (RMW && DEPTH > 0) {
@@ -368,7 +381,11 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
       if (F32) {
         f32x4 v = *(const f32x4*)sp;
         if constexpr (RMW) { const f32x4 old = oldv[sl][i]; v = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]}; }
-        if (ok) *(f32x4*)((float*)p.C + cbase + (size_t)m * p.ldc + n) = v;
+        if (ok) {
+          f32x4* dst_ = (f32x4*)((float*)p.C + cbase + (size_t)m * p.ldc + n);
+          if constexpr (RMW && (GEMM_EPI_NT & 2) != 0) __builtin_nontemporal_store(v, dst_);
+          else *dst_ = v;
+        }
         if constexpr (EPI == EPI_RESID_F32 && CHUNKS == 16) {   // one wave = one 64-column block (the host never picks the 192-wide tile here)
           if (fold_out) {
             // explicit fma chain: left to the compiler, a*a + b*b contracts differently in different instantiations of
@@ -377,7 +394,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             ss = row16_sum_f(ss);                                // the 16 lanes of one row
             if (ok) {
               half4 xr = {f2h_sat(v[0] * p.xs), f2h_sat(v[1] * p.xs), f2h_sat(v[2] * p.xs), f2h_sat(v[3] * p.xs)};
-              *(half4*)(p.xraw + (size_t)m * p.ldx + n) = xr;
+              if constexpr ((GEMM_EPI_NT & 8) != 0) __builtin_nontemporal_store(xr, (half4*)(p.xraw + (size_t)m * p.ldx + n));
+              else *(half4*)(p.xraw + (size_t)m * p.ldx + n) = xr;
               if (ch == 0) p.ssq[(size_t)m * p.nb + (ncol0 >> 6)] = ss;
             }
           }
@@ -385,7 +403,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
       } else if (ok) {
         const half4 lo = *(const half4*)sp, hi = *(const half4*)(sp + 8);
         const half8 v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        *(half8*)((half_t*)p.C + cbase + (size_t)m * p.ldc + n) = v8;
+        if constexpr ((GEMM_EPI_NT & 4) != 0) __builtin_nontemporal_store(v8, (half8*)((half_t*)p.C + cbase + (size_t)m * p.ldc + n));
+        else *(half8*)((half_t*)p.C + cbase + (size_t)m * p.ldc + n) = v8;
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -912,6 +931,12 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // walks its tiles and overlaps each tile's epilogue with the next tile's first loads (qkv at M = 23552: 170 -> 149 us,
 // FFN-in 326 -> 308 us).  KO: timing-only knock-outs for bottleneck hunting (results are garbage): 1 = no DMA in
 // the loop, 2 = no fragment reads, 4 = no MFMA.  Product code instantiates KO = 0 only.
+#ifndef GEMM_A_AUX
+#define GEMM_A_AUX 0   // cache-policy bits of the ping-pong kernel's A-panel / W-panel DMA loads (bit 1 = nt)
+#endif
+#ifndef GEMM_W_AUX
+#define GEMM_W_AUX 0
+#endif
 #ifndef GEMM_PP2_ISSUE_Q
 #define GEMM_PP2_ISSUE_Q 1      // the DMA instruction of a k16 step goes out after its MFMA number ISSUE_Q (0..3)
 #endif
@@ -960,7 +985,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     const char* base = (const char*)((kind < 2 ? p.A : p.W) + tile * 64);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[kind][j]),
                                      (__attribute__((address_space(3))) void*)(smem + (kind * 2 + stage) * HALF + (wave * 2 + j) * 512),
-                                     16, 0, 0);
+                                     16, 0, kind < 2 ? GEMM_A_AUX : GEMM_W_AUX);
   };
   using std::integral_constant;
   using I0 = integral_constant<int, 0>; using I1 = integral_constant<int, 1>;

@@ -14,7 +14,8 @@ def main():
     import torch  # noqa: F401
     import bench
     import __graft_entry__ as ge
-    ge.build()
+    if not os.environ.get("RK_ENGINE_LIB"):
+        ge.build()
     from llmrankers import _synth
     from llmrankers._engine import RkEngine
     cfgs = []
