@@ -106,7 +106,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1;
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
@@ -323,7 +323,7 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
 // Folded RMSNorm hooks of one GEMM launch (GemmArgs): consumer side = rowscale, producer side = xraw + ssq.
 #define RK_XRAW_SCALE 0.0625f   // the fp16 copy of the fp32 residual stream is stored x 2^-4: head-room for the outlier
                                 // channels of real T5 checkpoints (fp16 max 65504 -> 1.0e6), exact (power of two)
-struct GemmFold { const float* rowscale = nullptr; half_t* xraw = nullptr; float* ssq = nullptr; const float* ssq_in = nullptr; };
+struct GemmFold { const float* rowscale = nullptr; half_t* xraw = nullptr; float* ssq = nullptr; const float* ssq_in = nullptr; int nb_in = 0; };
 
 void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int lda, const half_t* W, int ldw, void* C,
           int ldc, int M, int N, int K, int n_split = 0, long split_stride = 0, float scale = 1.f,
@@ -331,7 +331,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
   if (M <= 0) return;
   GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale, bsA, bsW, bsC};
   a.rowscale = fold.rowscale; a.xraw = fold.xraw; a.ssq = fold.ssq; a.ldx = N; a.nb = (N + 63) / 64; a.xs = RK_XRAW_SCALE;
-  a.ssq_in = fold.ssq_in; a.nb_in = (K + 63) / 64; a.eps_in = e->d.eps;       // (tiled producers: 64-column blocks)
+  a.ssq_in = fold.ssq_in; a.nb_in = fold.nb_in ? fold.nb_in : (K + 63) / 64; a.eps_in = e->d.eps;       // (tiled producers: 64-column blocks)
   const double flops = 2.0 * M * (double)N * K * batch;
   const double out_elems = EPI_IS_GATED(epi) ? (double)M * N / 2 : (double)M * N;
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
@@ -345,7 +345,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
     // kernel delaying some tile of the GEMM in flight, not its CU-time; so: many short workgroups)
     const dim3 b(SKINNY_THREADS);
     const unsigned gy = (unsigned)batch, gz = (unsigned)((M + 31) / 32);
-    a.nb = (N + 31) / 32; a.nb_in = (K + 31) / 32;             // this kernel's producer blocks are 32 columns wide
+    a.nb = (N + 31) / 32; a.nb_in = fold.nb_in ? fold.nb_in : (K + 31) / 32;   // this kernel's own producer blocks are 32 columns wide
     // (tried and dropped, round 3: a 1-D launch that runs all row slabs of a column block on ONE XCD, so that a weight row is
     // fetched into one L2 only - dec_gemm 0.337 vs 0.328 ms per step at 320 rows: the slabs are not bound by weight traffic)
     switch (epi) {
@@ -388,9 +388,9 @@ void embed(rk_engine* e, hipStream_t st, const int* ids, float* out, int rows, h
 }
 
 // folded RMSNorm: block sums of squares (left by the residual GEMM epilogue) -> row factors
-void rowscale(rk_engine* e, hipStream_t st, const float* ssq, float* out, int rows) {
+void rowscale(rk_engine* e, hipStream_t st, const float* ssq, float* out, int rows, int nb = 0) {   // nb: block sums per row (0: 64-column blocks)
   if (rows <= 0) return;
-  const int nb = (e->d.d_model + 63) / 64;
+  if (nb <= 0) nb = (e->d.d_model + 63) / 64;
   Bracket br(e, st, PC_NORM, 0, (double)rows * (nb + 1) * 4.0);
   hipLaunchKernelGGL(rowscale_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, ssq, out, rows, nb, e->d.d_model, e->d.eps, RK_XRAW_SCALE);
 }
@@ -577,7 +577,8 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
   // launches per layer less.  A producer never writes the buffer a workgroup of the same launch may still read: two of each.
   const bool dfold = ws && e->opt_dec_fold_norm && (e->opt_skinny & 0x3F) == 0x3F;
   int cur = 0; bool from_embed = true;
-  auto cons = [&]() { GemmFold f; if (from_embed) f.rowscale = sl.drowscale; else f.ssq_in = sl.dssq[cur]; return f; };
+  // (the producers of dssq are weight-streaming GEMMs: 32-column blocks, whichever kernel family consumes them)
+  auto cons = [&]() { GemmFold f; if (from_embed) f.rowscale = sl.drowscale; else { f.ssq_in = sl.dssq[cur]; f.nb_in = (dm + 31) / 32; } return f; };
   auto with_prod = [&](GemmFold f) { f.xraw = sl.dxraw[cur ^ 1]; f.ssq = sl.dssq[cur ^ 1]; return f; };
   auto flip = [&]() { cur ^= 1; from_embed = false; };
   embed(e, st, sl.d_dec_ids, sl.dhidden, M, dfold ? sl.dxraw[0] : nullptr, dfold ? sl.drowscale : nullptr);
@@ -652,9 +653,27 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
     if (dfold) {
       gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.co, I, sl.dhidden, dm, M, dm, I, 0, 0, 1.f, 1, 0, 0, 0, ws, with_prod(GemmFold()));
       flip();
-      gemm(e, st, PC_DEC_GEMM, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, sl.dxraw[cur], dm, w.ffn_in_f, dm, sl.dffh, F, M,
-           d.gated_gelu ? 2 * F : F, dm, 0, 0, 1.f, 1, 0, 0, 0, ws, cons());
+      {
+        // ONE decoder position (pointwise yes_no, MonoT5): FFN-in runs on the TILED kernels whatever the number of rows.  Its
+        // 5632 output columns are 176 column blocks x (rows / 32) workgroups for the weight-streaming kernel - 1760 at the
+        // bench's 320 rows, 29.9 us per layer - against 440 tiles of 64x64 on the matrix cores, 14.5 us (dec_gemm 0.32 ->
+        // 0.28 ms per step, +0.9 % passages/s).  The family follows from the call shape (L_d == 1), never from the batch, so a
+        // row's bits still do not depend on what shares its launch; the other projections of the layer (1024 columns: 80 tiles)
+        // measured the same on either family and stay where they were.
+        const bool tiled_in = e->opt_dec_ffn_tiled && Ld == 1;
+        const int epi_in = d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, n_in = d.gated_gelu ? 2 * F : F;
+        GemmFold cf = cons();
+        if (tiled_in && cf.ssq_in && consumer_uses_pp2(e, epi_in, M, n_in, dm)) {
+          // (many rows, or a forced tile shape: the persistent ping-pong kernel takes its row factors ready-made - same block
+          // sums, same rk_row_factor, same bits as the fill-in kernels form in their epilogue)
+          rowscale(e, st, cf.ssq_in, sl.drowscale, M, cf.nb_in);
+          cf = GemmFold(); cf.rowscale = sl.drowscale;
+        }
+        gemm(e, st, PC_DEC_GEMM, epi_in, sl.dxraw[cur], dm, w.ffn_in_f, dm, sl.dffh, F, M, n_in, dm, 0, 0, 1.f, 1, 0, 0, 0, tiled_in ? false : ws, cf);
+      }
       const bool last = l + 1 == d.n_dec_layers;   // the final norm (head kernels) reads the fp32 stream itself
+      // (the same switch for FFN-out - 80 tiles of 64x64 with 44 K steps each - took 9 us per layer off the serial profile and
+      // nothing measurable off the pipeline: left on the weight-streaming kernel)
       gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dffh, F, w.ffn_out, F, sl.dhidden, dm, M, dm, F, 0, 0, 1.f, 1, 0, 0, 0, ws, last ? GemmFold() : with_prod(GemmFold()));
       if (!last) flip();
       continue;
@@ -1891,6 +1910,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "dec_graph")) { e->opt_dec_graph = value != 0; return RK_OK; }             // decoder chains replayed as HIP graphs (1) or launched eagerly (0)
   if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
   if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x3F : value; return RK_OK; }   // bit per epilogue kind
+  if (!strcmp(key, "dec_ffn_tiled")) { e->opt_dec_ffn_tiled = value != 0; ++e->opt_epoch; return RK_OK; }   // one-position decoder: FFN-in on the tiled kernels (1) or the weight-streaming kernel (0)
   if (!strcmp(key, "gemm_persistent")) { e->opt_gemm_persistent = value; return RK_OK; }   // ping-pong GEMM: 1 = one workgroup per CU walks the tiles
   if (!strcmp(key, "attn_tiled_occ")) { e->opt_attn_tiled_occ = value; return RK_OK; }   // tiled encoder attention: register budget for 1 / 2 / 3 waves per SIMD
   if (!strcmp(key, "gemm_s64_stages")) { e->opt_s64_stages = value; return RK_OK; }   // LDS stages of the 64x64 GEMM: 0 = auto, 2..4
