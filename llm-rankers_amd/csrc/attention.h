@@ -397,7 +397,8 @@ __global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p)
 //     one maximum / one sum per row, P packed to fp16 as it is formed, P V without rescaling;
 //   * the context rows leave the registers directly: v_permlane32_swap pairs the 8-byte pieces of the two half-waves into
 //     16-byte stores (no LDS staging, no barrier);
-//   * the grid is (heads / (groups x heads per group), sequences): 5120 (sequence, head) units in 1280 workgroups.
+//   * the launch is PERSISTENT: one workgroup per CU, the (sequence, head) items dealt out in contiguous runs per wave group
+//     (5120 items at 320 sequences x 16 heads: 10 per group), prefetching across sequence boundaries (see the kernel).
 // The tiled kernel above reproduces the same operations for such a sequence when its batch also holds a longer one.
 #define ATTD_ROWS 192
 // timing-only knock-outs of this kernel (measurement builds: hipcc ... -DRK_MEASURE, loaded through RK_ENGINE_LIB; results are
@@ -434,13 +435,14 @@ __device__ __forceinline__ void attd_issue_vt(half4 (&d)[4], const unsigned (&va
 #ifndef ATTD_MINW
 #define ATTD_MINW 3
 #endif
-// NG = 2 (the production form): a 768-thread workgroup runs TWO such six-wave groups side by side, each on its own heads
-// and its own 75 KiB of LDS.  Why not two 384-thread workgroups per CU, which LDS (2 x 75 KiB) and registers (166 -> three
+// NG = 2 (the production form): a 768-thread workgroup runs TWO such six-wave groups side by side, each on its own items
+// and its own 75 KiB of LDS.  Why not two 384-thread workgroups per CU, which LDS (2 x 75 KiB) and registers (144 -> three
 // waves per SIMD) allow and the occupancy API promises: the dispatcher places the six waves of a workgroup 2,2,1,1 over
 // the four SIMDs from a start of its own choosing, a second workgroup then needs exactly the complementary 1,1,2,2, and
 // it does not look for it - tools/probes/probe_resid.hip: 384-thread workgroups with >= 160 VGPRs run ONE per CU (the
 // kernel measured the same at 256 and at 512 workgroups).  Twelve waves of ONE workgroup always fit three per SIMD.  The
-// two groups share only the workgroup barriers (same sequence in both: same sequence length, same head count).
+// two groups share only the workgroup barriers (two per item in every form of the item body, whatever the item's sequence
+// length - so groups on different sequences still meet the same barriers).
 // (Tried and dropped on the whole-row form, round 3, each bit-identical and within +-1 % or worse: three issue priorities
 // for the three waves of a SIMD (s_setprio), the next head's Q loads issued right after the score tiles instead of after
 // the softmax, the context stores deferred behind the next head's DMA issues so that the counted V wait does not also
