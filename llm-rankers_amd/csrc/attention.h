@@ -447,6 +447,11 @@ __device__ __forceinline__ void attd_issue_vt(half4 (&d)[4], const unsigned (&va
 // for the three waves of a SIMD (s_setprio), the next head's Q loads issued right after the score tiles instead of after
 // the softmax, the context stores deferred behind the next head's DMA issues so that the counted V wait does not also
 // wait for them: 138 against 132 us.)
+// (Tried and dropped, end of round 3: running the second group HALF AN ITEM behind the first - it passes one workgroup
+// barrier before its first item, the first group one after its last, so that one group's softmax meets the other's P V
+// instead of its softmax; correct by construction and bit-identical, 114 -> 121 us per launch: the extra half item is paid
+// and nothing comes back - the two groups' phases are not what limits an item; its ~190 KB of loads, DMA and stores per CU
+// at the ~30 KB/us a CU gets while all 256 pull are more than half of its 11.7 us.)
 // (Tried and dropped, round 3: a full-prefetch form of the one-group kernel - four row buffers, K AND V of the next head
 // landing a whole head ahead, the next Q rows in registers of their own, context rows stored a head later, ONE barrier per
 // head, 178 VGPRs - bit-identical, 177 us per launch against 161 for the one-group and 145 for the two-group form: the
