@@ -1,0 +1,82 @@
+// How many bytes per microsecond does ONE CU pull out of L2 when all CUs pull - by LDS-DMA (global_load_lds_dwordx4) and by
+// ordinary 16-byte loads into registers?  512-thread workgroups, one per CU (160 KiB of LDS requested), every wave streams a
+// 64-KiB region of its workgroup (L2-resident: 32 workgroups x 64 KiB = 2 MiB per XCD) again and again, eight 1-KiB
+// instructions in flight per wave.  Also with half / a quarter of the CUs active, and with a busy MFMA loop in four of the
+// eight waves (the clock the matrix cores allow).  Prints KB/us per CU and the aggregate.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE, int MFMA>   // MODE 0: LDS-DMA, 1: register loads
+__global__ __launch_bounds__(512) void pull(const char* src, int iters, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const char* base = src + (size_t)blockIdx.x * 65536;
+  f32x16 acc = {};
+  half8 a = {}, b = {};
+  for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.37f + 0.01f * lane); b[i] = (_Float16)(0.11f * (i + 1)); }
+  if (MFMA && wave >= 4) {                                    // four waves keep the matrix cores busy for the same number of rounds
+    for (int it = 0; it < iters * 8; ++it) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+    }
+    if (acc[0] == 123.f) sink[0] = acc[1];
+    return;
+  }
+  const int nload = MFMA ? 4 : 8;                             // loader waves
+  if (wave >= nload) return;
+  u32x4 r[8];
+  unsigned keep = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned off = (unsigned)(((it * 8 + u) * nload + wave) & 63) * 1024u + lane * 16u;   // walks the 64-KiB region
+      if (MODE == 0) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                         (__attribute__((address_space(3))) void*)(lds + (wave * 8 + u) * 1024), 16, 0, 0);
+      } else {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r[u]) : "v"(off), "s"(base) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { asm volatile("" : "+v"(r[u])); keep ^= r[u][0]; }
+    }
+  }
+  if (MODE == 0) keep = ((unsigned*)lds)[threadIdx.x];
+  if (keep == 0x12345678u) sink[1] = 1.f;
+}
+
+template <int MODE, int MFMA>
+void run(const char* name, const char* src, float* sink, int grid) {
+  const int iters = 4000;
+  hipFuncSetAttribute((const void*)pull<MODE, MFMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((pull<MODE, MFMA>), dim3(grid), dim3(512), 163840, 0, src, iters, sink);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  const int nload = MFMA ? 4 : 8;
+  const double kb_per_wg = (double)iters * 8 * nload;       // 1 KiB per instruction
+  printf("%-28s grid %3d: %7.1f us, %6.1f KB/us per CU, %5.2f TB/s aggregate\n", name, grid, ms * 1e3, kb_per_wg / (ms * 1e3),
+         kb_per_wg * 1024 * grid / (ms * 1e-3) / 1e12);
+}
+
+int main() {
+  char* src; float* sink;
+  hipMalloc(&src, 256 * 65536); hipMemset(src, 1, 256 * 65536); hipMalloc(&sink, 16);
+  for (int grid : {256, 128, 64}) {
+    run<0, 0>("LDS-DMA, 8 loader waves", src, sink, grid);
+    run<1, 0>("register loads, 8 waves", src, sink, grid);
+    run<0, 1>("LDS-DMA 4 waves + MFMA 4", src, sink, grid);
+    run<1, 1>("register loads 4 + MFMA 4", src, sink, grid);
+  }
+  printf("%s\n", hipGetErrorString(hipDeviceSynchronize()));
+  return 0;
+}
