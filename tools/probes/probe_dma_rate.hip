@@ -2,7 +2,8 @@
 // ordinary 16-byte loads into registers?  512-thread workgroups, one per CU (160 KiB of LDS requested), every wave streams a
 // 64-KiB region of its workgroup (L2-resident: 32 workgroups x 64 KiB = 2 MiB per XCD) again and again, eight 1-KiB
 // instructions in flight per wave.  Also with half / a quarter of the CUs active, and with a busy MFMA loop in four of the
-// eight waves (the clock the matrix cores allow).  Prints KB/us per CU and the aggregate.
+// eight waves (the clock the matrix cores allow).  Every wave records how long IT ran: prints the loader waves' rate and the
+// MFMA waves' time separately.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -14,6 +15,7 @@ __global__ __launch_bounds__(512) void pull(const char* src, int iters, float* s
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const char* base = src + (size_t)blockIdx.x * 65536;
+  const long long t_begin = wall_clock64();
   f32x16 acc = {};
   half8 a = {}, b = {};
   for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.37f + 0.01f * lane); b[i] = (_Float16)(0.11f * (i + 1)); }
@@ -23,6 +25,7 @@ __global__ __launch_bounds__(512) void pull(const char* src, int iters, float* s
       for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
     }
     if (acc[0] == 123.f) sink[0] = acc[1];
+    if (lane == 0) sink[16 + blockIdx.x * 8 + wave] = (float)(wall_clock64() - t_begin) * 0.01f;   // microseconds (100 MHz)
     return;
   }
   const int nload = MFMA ? 4 : 8;                             // loader waves
@@ -48,6 +51,7 @@ __global__ __launch_bounds__(512) void pull(const char* src, int iters, float* s
   }
   if (MODE == 0) keep = ((unsigned*)lds)[threadIdx.x];
   if (keep == 0x12345678u) sink[1] = 1.f;
+  if (lane == 0) sink[16 + blockIdx.x * 8 + wave] = (float)(wall_clock64() - t_begin) * 0.01f;
 }
 
 template <int MODE, int MFMA>
@@ -64,13 +68,20 @@ void run(const char* name, const char* src, float* sink, int grid) {
   }
   const int nload = MFMA ? 4 : 8;
   const double kb_per_wg = (double)iters * 8 * nload;       // 1 KiB per instruction
-  printf("%-28s grid %3d: %7.1f us, %6.1f KB/us per CU, %5.2f TB/s aggregate\n", name, grid, ms * 1e3, kb_per_wg / (ms * 1e3),
-         kb_per_wg * 1024 * grid / (ms * 1e-3) / 1e12);
+  static float host[16 + 256 * 8];
+  hipMemcpy(host, sink, sizeof(host), hipMemcpyDeviceToHost);
+  double tl = 0, tm = 0;
+  for (int b = 0; b < grid; ++b) for (int w = 0; w < 8; ++w) (w < nload ? tl : tm) += host[16 + b * 8 + w];
+  tl /= (double)grid * nload; if (MFMA) tm /= (double)grid * 4;
+  printf("%-28s grid %3d: kernel %7.1f us; loader waves %7.1f us = %6.1f KB/us per CU (%5.2f TB/s aggregate)", name, grid, ms * 1e3, tl,
+         kb_per_wg / tl, kb_per_wg * 1024 * grid / (tl * 1e-6) / 1e12);
+  if (MFMA) printf("; MFMA waves %7.1f us", tm);
+  printf("\n");
 }
 
 int main() {
   char* src; float* sink;
-  hipMalloc(&src, 256 * 65536); hipMemset(src, 1, 256 * 65536); hipMalloc(&sink, 16);
+  hipMalloc(&src, 256 * 65536); hipMemset(src, 1, 256 * 65536); hipMalloc(&sink, (16 + 256 * 8) * 4);
   for (int grid : {256, 128, 64}) {
     run<0, 0>("LDS-DMA, 8 loader waves", src, sink, grid);
     run<1, 0>("register loads, 8 waves", src, sink, grid);
