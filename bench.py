@@ -88,6 +88,9 @@ def parse_args():
     ap.add_argument("--regions", type=int, default=3, help="timed regions of exactly --steps steps each; the median is reported")
     ap.add_argument("--no_extras", action="store_true", help="skip the ragged (S2) and setwise (S3) legs after the timed region")
     ap.add_argument("--cpu_batch", type=int, default=32, help="batch size of the cpu_baseline leg (BASELINE.md section 3: 32)")
+    ap.add_argument("--dry_ranks", action="store_true",
+                    help="no GPU: N gloo ranks over tools/dry_engine.py walk the multi-rank control flow (communicator bring-up, "
+                         "sharding, one gather per launch sequence, gather checks, the JSON line); timings are meaningless")
     return ap.parse_args()
 
 
@@ -338,25 +341,34 @@ def main():
     import numpy as np
     import torch                        # first: its bundled HIP runtime must be the one in the process
     import torch.distributed as dist
-    if not torch.cuda.is_available():
+    dry = args.dry_ranks
+    if dry:
+        args.no_profile = args.no_per_query = args.no_cpu_baseline = args.no_extras = True
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    if local_rank >= torch.cuda.device_count():
+    elif local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
-    torch.cuda.set_device(local_rank)
+    else:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group(backend="gloo")                # host-side control plane only; scores travel over RCCL
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    import __graft_entry__ as ge
-    ge.build()
     from llmrankers import _synth
-    from llmrankers._engine import RkEngine
+    from llmrankers._runtime import T5Runtime
+    if dry:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        from dry_engine import DryEngine as RkEngine
+    else:
+        import __graft_entry__ as ge
+        ge.build()
+        from llmrankers._engine import RkEngine
 
     dims = _synth.NAMED_DIMS[args.model]
     B, L, G = args.batch_size, args.seq_len, max(1, args.group)
     t0 = time.time()
-    state = _synth.synth_state_dict(dims, seed=929, threads=min(32, os.cpu_count() or 8))
+    state = {} if dry else _synth.synth_state_dict(dims, seed=929, threads=min(32, os.cpu_count() or 8))
     eng = RkEngine(dims, device=local_rank, max_tokens=max(8192, G * B * L, 100 * (L + 72)), max_seqs=max(128, G * B), max_dec_len=4)
     eng.load_state(state.items())
     eng.set_option("gemm_glds", args.glds)
@@ -364,12 +376,19 @@ def main():
     for kv in args.opt:                                    # engine A/B switches for experiments, e.g. --opt gemm_variant=2
         k, v = kv.split("=")
         eng.set_option(k, int(v))
-    if world > 1:                                          # engine-owned RCCL communicator (K9); id travels over gloo
-        ids = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        eng.comm_init(ids[0], rank, world, G * B * 2)
+    rccl = None
+    if world > 1:
+        # engine-owned RCCL communicator (K9), built exactly as the rankers build theirs on their first sharded query
+        # (T5Runtime.ensure_comm -> comm_init_from_process_group: rank 0's id travels over the gloo group, nothing else does)
+        rt = T5Runtime.from_engine(eng, dims)
+        rt.comm_init_from_process_group(max(G * B * 2, args.hits * 2))
+        assert rt.comm_ready() and rt.comm_capacity >= G * B * 2
+    try:
+        rccl = eng.comm_library_info()                     # which librccl this process binds (path | ncclGetVersion code)
+    except Exception as exc:                               # never take a 1-GPU number down: RCCL is only needed for N > 1
+        rccl = f"unavailable: {exc}"
     if rank == 0:
-        print(f"[bench] weights generated + engine finalized in {time.time() - t0:.1f}s; group = {G} batches", file=sys.stderr)
+        print(f"[bench] weights generated + engine finalized in {time.time() - t0:.1f}s; group = {G} batches; rccl = {rccl}", file=sys.stderr)
 
     def group_batch(n_batches, seed):
         return [s for j in range(n_batches) for s in _synth.synth_token_batch(B, L, L, dims.vocab, seed=seed + j)]
@@ -391,10 +410,12 @@ def main():
 
     def fence():
         eng.sync()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not dry:
+                torch.cuda.synchronize()
 
     regions, ev_regions = [], []
     for r in range(max(1, args.regions)):
@@ -477,7 +498,8 @@ def main():
             "metric": "passages/sec (pointwise yes_no reranking, flan-t5-large shape)", "value": round(value, 1),
             "unit": "passages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if shard else "weak",
-            "vs_baseline": None, "dtype": "f16 (MFMA inputs), f32 accumulate + residual stream", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f16 (MFMA inputs), f32 accumulate + residual stream",
+            "data": "synthetic" if not dry else "DRY RUN (no GPU: tools/dry_engine.py, gloo) - control flow only, timings meaningless",
             "config": {"engine_group": (f"one query's share ({hi - lo} of {args.hits} candidates) per engine launch sequence" if shard
                                         else f"{G} batches ({G * B} passages) per engine launch sequence"),
                        "workload": (f"{args.model} pointwise yes_no, ONE query of hits={args.hits} candidates per step, cut over {world} rank(s) "
@@ -487,7 +509,7 @@ def main():
                        "mode": args.mode, "global_batch": args.hits if shard else B * world, "seq_len": L,
                        "parallelism": (f"dp{world}, candidates of each query sharded; one engine-issued RCCL all_gather per query" if shard else
                                        f"dp{world} (every rank scores its own batches; one engine-issued RCCL all_gather per launch sequence)"),
-                       "gather_check": gather_check,
+                       "gather_check": gather_check, "rccl": rccl,
                        "timed_regions_ms": [round(x * 1e3, 2) for x in regions], "region_reported": "median",
                        "weights": "synthetic N(0, HF-init std), seed 929", "engine_stream_ms_per_step": round(ev_ms / args.steps, 3),
                        "algorithmic_gflop_per_passage": round(gfl, 2),

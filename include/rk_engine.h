@@ -142,6 +142,11 @@ int rk_llama_last_logits(rk_engine* e, const int32_t* tokens, const int32_t* seq
 int rk_comm_unique_id(uint8_t* out_id, int n_bytes);
 int rk_comm_init(rk_engine* e, const uint8_t* id_bytes, int n_bytes, int rank, int world, int max_floats_per_rank);
 int rk_comm_world(const rk_engine* e, int* out_rank, int* out_world);
+/* max_floats_per_rank of the live communicator (0 without one): the bound every rank checks BEFORE it enters a gather */
+int rk_comm_capacity(const rk_engine* e);
+/* which RCCL the process bound (dlopen'ed on first use): "<path of the mapped library>|<ncclGetVersion code>" into buf,
+ * NUL-terminated; returns the length written or a negative status.  For logs: the torch wheel bundles its own librccl. */
+int rk_comm_library_info(char* buf, int n_bytes);
 /* ONE ncclAllGather of the slot's device score buffer (the first n_floats fp32 of what rk_t5_score_slot / rk_t5_qlm
  * left there; every rank passes the same n_floats, ranks with fewer scores are read up to their own count by the
  * caller), enqueued on the stream that produces the scores, followed by an async copy to pinned host memory.
@@ -155,6 +160,10 @@ int rk_comm_read_gathered_slot(rk_engine* e, int slot, float* out, int n_floats_
  * share; capacity = rk_comm_init's max_floats_per_rank); rk_comm_read_appended waits and copies out[world][n_floats].
  * Every rank issues exactly one collective per query, whatever its number of engine calls. */
 int rk_comm_append_scores_slot(rk_engine* e, int slot, int n_floats, int dst_offset);
+/* the same for n_floats HOST values (small per-passage side data that has to reach every rank with the scores, e.g. the
+ * token counts behind the reference's prompt-token counter, ref: llmrankers/pointwise.py:105-114): staged through pinned
+ * memory, copied to the send buffer on the stream the gather will run on; the caller's buffer is free on return */
+int rk_comm_append_host(rk_engine* e, const float* values, int n_floats, int dst_offset);
 int rk_comm_all_gather_appended(rk_engine* e, int n_floats);
 int rk_comm_read_appended(rk_engine* e, float* out, int n_floats_total);
 int rk_comm_destroy(rk_engine* e);

@@ -696,8 +696,12 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
   int kb = 0, vb = 1, nb = 2;                             // buffers of K_h, V_h, K_h+1
   // NKT: the sequence's key tiles (1 .. 3) as a compile-time constant - the head body is straight-line code, only its last
   // tile carries the key mask
-  // ACTIVE: this wave has query rows (wave-uniform for the whole kernel, so the two forms are separate straight-line bodies:
-  // guarded by a run-time `if`, values defined in one guarded block and used in the next stayed allocated in between)
+  // ACTIVE: this wave has query rows in THIS item (wave-uniform per item - items span sequences of different lengths in the
+  // persistent launch, so `q0 < L` is re-evaluated per item; the two forms are separate straight-line bodies: guarded by a
+  // run-time `if`, values defined in one guarded block and used in the next stayed allocated in between).  INVARIANT the
+  // counted vmcnt(10) below relies on: the ACTIVE and the !ACTIVE body issue the SAME number of loads behind V_h - the line
+  // touch + table entry (2), four K rows of the next item, four Q loads of the next item - in any mix of lengths
+  // (tests/test_isa_guards.py counts them per body; the ragged GPU test mixes L <= 32, 64 < L <= 128 and L = 192 in one launch)
   auto head = [&](auto lastc, auto nktc, auto activec, int n) {
     constexpr bool LAST = decltype(lastc)::value;
     constexpr int NKT = decltype(nktc)::value;
@@ -782,6 +786,7 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     // V_h: this wave's four DMA instructions are the oldest loads in flight (behind them: the line touch + the table entry,
     // 4 K rows and the 4 Q loads of the next item; the context stores of the previous head are older but at most 4, and
     // can only make the wait stricter)
+    // (10 = 2 + 4 + 4 loads issued behind V_h by EVERY wave, active or not: see the ACTIVE note at the top of `head`)
     if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     ATTD_STAMP(5);

@@ -50,6 +50,8 @@ struct GemmArgs {
   // EPI_LSE_F32 (qlm head): C = float2 [M, ldc] (block max, sum of exp(x - block max)) per 32-column block (ldc = blocks);
   // row m scores label lse_labels[m % lse_npos], whose logit goes to lse_xlab[m].  The logits never reach memory.
   const int* lse_labels; int lse_npos; float* lse_xlab;
+  // ping-pong kernel: width (in tiles) of the column panels of the grouped tile order (gemm_tile_coords); host default GEMM_GROUP_N
+  int group_n;
 };
 
 #define GEMM_BM 128
@@ -115,16 +117,16 @@ __device__ __forceinline__ half8 gemm_frag(const half_t* s_tile, int r, int cc) 
 // (32/GROUP_N rows x GROUP_N cols) block of the output and share A / W panels through that XCD's private L2.
 // Bijective for any grid size.
 #define GEMM_GROUP_N 8
-__device__ __forceinline__ void gemm_tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+__device__ __forceinline__ void gemm_tile_coords(int bid, int tiles_m, int tiles_n, int& tm, int& tn, int group_n = GEMM_GROUP_N) {
   const int nwg = tiles_m * tiles_n;
   const int xcd = bid & 7, loc = bid >> 3;
   const int q = nwg >> 3, r = nwg & 7;
   const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  const int per_panel = tiles_m * GEMM_GROUP_N;
+  const int per_panel = tiles_m * group_n;
   const int pn = lin / per_panel, rem = lin - pn * per_panel;
-  const int w = min(GEMM_GROUP_N, tiles_n - pn * GEMM_GROUP_N);
+  const int w = min(group_n, tiles_n - pn * group_n);
   tm = rem / w;
-  tn = pn * GEMM_GROUP_N + rem - tm * w;
+  tn = pn * group_n + rem - tm * w;
 }
 
 // Epilogue shared by the tiled and the skinny kernel.  acc[ni][mi] are 32x32 MFMA C fragments of a 64(n) x 64(m)
@@ -930,7 +932,8 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // Needs K >= 128 (two K tiles).  The kernel is PERSISTENT (see set_tile below): launched with one workgroup per CU it
 // walks its tiles and overlaps each tile's epilogue with the next tile's first loads (qkv at M = 23552: 170 -> 149 us,
 // FFN-in 326 -> 308 us).  KO: timing-only knock-outs for bottleneck hunting (results are garbage): 1 = no DMA in
-// the loop, 2 = no fragment reads, 4 = no MFMA.  Product code instantiates KO = 0 only.
+// the loop, 2 = no fragment reads, 4 = no MFMA, 8 = no W-panel DMA, 16 = no A-panel DMA (round 4: what a register-staged
+// feed of one operand could buy at most).  Product code instantiates KO = 0 only.
 #ifndef GEMM_A_AUX
 #define GEMM_A_AUX 0   // cache-policy bits of the ping-pong kernel's A-panel / W-panel DMA loads (bit 1 = nt)
 #endif
@@ -962,7 +965,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   // runs the epilogue of the current one: pipeline fill and workgroup launch no longer sit between two tiles.
   auto set_tile = [&](int tile) {
     int tm, tn;
-    gemm_tile_coords(tile, tiles_m, tiles_n, tm, tn);
+    gemm_tile_coords(tile, tiles_m, tiles_n, tm, tn, p.group_n);
     m0 = tm * 256; n0 = tn * 256;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1033,7 +1036,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
         for (int ks = 0; ks < 4; ++ks) { aF[0][ks] = *(const half8*)(sa + koff[ks]); aF[1][ks] = *(const half8*)(sa + 2048 + koff[ks]); }
       }
     }
-    if constexpr (WAIT >= 0 && !(KO & 1)) gemm_wait_vmcnt<WAIT >= 0 ? WAIT : 0>();
+    // (knock-outs 8 / 16 drop the W / A half of the DMA: the counted waits follow the number of instructions still issued)
+    constexpr int NA = (KO & 16) ? 0 : 2, NW = (KO & 8) ? 0 : 2;
+    constexpr int WAITK = WAIT == 4 ? NA + NW : (WAIT == 2 ? NA : WAIT);
+    if constexpr (WAIT >= 0 && !(KO & 1)) gemm_wait_vmcnt<WAITK >= 0 ? WAITK : 0>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -1054,15 +1060,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             // SP0 of tile t prefetches W1(t+1), A1(t+1); SP1 prefetches A0(t+2), W0(t+2)  (stage of tile t+1 = st^1, t+2 = st)
             if constexpr (SP == 0) {
-              if (ks == 0) issue1(I3{}, st ^ 1, t + 1, I0{});
-              if (ks == 1) issue1(I3{}, st ^ 1, t + 1, I1{});
-              if (ks == 2) issue1(I1{}, st ^ 1, t + 1, I0{});
-              if (ks == 3) issue1(I1{}, st ^ 1, t + 1, I1{});
+              if constexpr (!(KO & 8)) { if (ks == 0) issue1(I3{}, st ^ 1, t + 1, I0{}); if (ks == 1) issue1(I3{}, st ^ 1, t + 1, I1{}); }
+              if constexpr (!(KO & 16)) { if (ks == 2) issue1(I1{}, st ^ 1, t + 1, I0{}); if (ks == 3) issue1(I1{}, st ^ 1, t + 1, I1{}); }
             } else {
-              if (ks == 0) issue1(I0{}, st, t + 2, I0{});
-              if (ks == 1) issue1(I0{}, st, t + 2, I1{});
-              if (ks == 2) issue1(I2{}, st, t + 2, I0{});
-              if (ks == 3) issue1(I2{}, st, t + 2, I1{});
+              if constexpr (!(KO & 16)) { if (ks == 0) issue1(I0{}, st, t + 2, I0{}); if (ks == 1) issue1(I0{}, st, t + 2, I1{}); }
+              if constexpr (!(KO & 8)) { if (ks == 2) issue1(I2{}, st, t + 2, I0{}); if (ks == 3) issue1(I2{}, st, t + 2, I1{}); }
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -1076,12 +1078,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
 
   // ---- prologue of a tile: half-tiles 0..5 = K tile 0 complete, A0 and W0 of K tile 1 ----
   auto issue_prologue = [&]() {
-    issue1(I0{}, 0, 0, I0{}); issue1(I0{}, 0, 0, I1{});
-    issue1(I2{}, 0, 0, I0{}); issue1(I2{}, 0, 0, I1{});
-    issue1(I3{}, 0, 0, I0{}); issue1(I3{}, 0, 0, I1{});
-    issue1(I1{}, 0, 0, I0{}); issue1(I1{}, 0, 0, I1{});
-    issue1(I0{}, 1, 1, I0{}); issue1(I0{}, 1, 1, I1{});
-    issue1(I2{}, 1, 1, I0{}); issue1(I2{}, 1, 1, I1{});
+    if constexpr (!(KO & 16)) { issue1(I0{}, 0, 0, I0{}); issue1(I0{}, 0, 0, I1{}); }
+    if constexpr (!(KO & 8)) { issue1(I2{}, 0, 0, I0{}); issue1(I2{}, 0, 0, I1{}); }
+    if constexpr (!(KO & 8)) { issue1(I3{}, 0, 0, I0{}); issue1(I3{}, 0, 0, I1{}); }
+    if constexpr (!(KO & 16)) { issue1(I1{}, 0, 0, I0{}); issue1(I1{}, 0, 0, I1{}); }
+    if constexpr (!(KO & 16)) { issue1(I0{}, 1, 1, I0{}); issue1(I0{}, 1, 1, I1{}); }
+    if constexpr (!(KO & 8)) { issue1(I2{}, 1, 1, I0{}); issue1(I2{}, 1, 1, I1{}); }
   };
   using Yes = integral_constant<bool, true>; using No = integral_constant<bool, false>;
   using W4 = integral_constant<int, 4>; using W2 = integral_constant<int, 2>; using W0c = integral_constant<int, 0>;
@@ -1099,7 +1101,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // at most 6 operations outstanding: the six oldest of the 12 prologue loads (A0, W0, W1 of K tile 0, this wave's
   // share) have landed - epilogue stores of the previous tile are younger and only make the wait stricter
-  gemm_wait_vmcnt<6>();
+  gemm_wait_vmcnt<((KO & 16) ? 0 : 4) + ((KO & 8) ? 0 : 2)>();
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);

@@ -106,7 +106,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1;
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
@@ -126,7 +126,7 @@ struct rk_engine {
   float* d_gather[RK_SLOTS] = {nullptr}; float* h_gather[RK_SLOTS] = {nullptr}; size_t gather_cap = 0;
   hipEvent_t ev_gather[RK_SLOTS] = {nullptr}; bool gather_pending[RK_SLOTS] = {false}; int gather_n[RK_SLOTS] = {0};
   // appended form (a rank's share scored in several engine calls): send buffer [gather_cap], result [world][gather_cap]
-  float *d_gsend = nullptr, *d_gall = nullptr, *h_gall = nullptr;
+  float *d_gsend = nullptr, *d_gall = nullptr, *h_gall = nullptr, *h_gstage = nullptr;
   hipEvent_t ev_gall = nullptr, ev_append = nullptr; bool gall_pending = false, append_foreign = false; int gall_n = 0;
 };
 
@@ -236,14 +236,15 @@ void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
 // time ~ rounds over the resident slots x the variant's time for one round of K = 1024 (us, MI355X, tools/gemm_bench.py
 // at M = 736 .. 23552, profiles/r01c_gemm_bench.txt, r01e_gemm_pingpong.txt).  All variants sum K in the same order, so
 // the choice never changes a result bit.  GEGLU pairs gate/up inside 64-row wave tiles: no 192-wide tile for it.
-int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_producer = false) {
+int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_producer = false, double* cost_out = nullptr) {
+  if (cost_out) *cost_out = 0;
   if (e->opt_gemm_variant) return (e->opt_gemm_variant == 3 && (EPI_IS_GATED(epi) || fold_producer)) ? 2 : e->opt_gemm_variant;
   struct V { int id, bm, bn, slots; double round_us; };
   static const V vs[5] = {{5, 256, 256, 256, 25.5}, {2, 256, 256, 256, 29.8}, {3, 256, 192, 256, 24.7}, {4, 256, 128, 256, 19.0}, {1, 128, 128, 512, 17.3}};
   // 64x64 tiles (variant 6) win only while the larger tiles leave most of the chip idle (tools/gemm_bench.py, r02: O / FFN-out
   // of one or two setwise prompts, M = 1450 / 2900: 12.7 / 15.0 us against 15.7 / 17.4 us on 128x128 tiles; from M = 5888 on,
   // or for the wide QKV / FFN-in outputs, they lose): at most 192 tiles of 128x128
-  if ((long)((M + 127) / 128) * ((N + 127) / 128) <= 192 && K >= 64) return 6;
+  if ((long)((M + 127) / 128) * ((N + 127) / 128) <= 192 && K >= 64) { if (cost_out) *cost_out = 15.0; return 6; }
   double best = 1e30; int bv = 1;
   for (const V& v : vs) {
     if (v.id == 3 && (EPI_IS_GATED(epi) || fold_producer)) continue;   // (the folded-norm producer needs 64-column wave tiles)
@@ -252,23 +253,72 @@ int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_p
     const double cost = (double)((tiles + v.slots - 1) / v.slots) * v.round_us;
     if (cost < best - 1e-9) { best = cost; bv = v.id; }
   }
+  if (cost_out) *cost_out = best;
   return bv;
+}
+
+// Launch plan of one tiled GEMM: rows [0, m_pp2) on the persistent ping-pong kernel in WHOLE rounds over the CUs, the rest
+// (m_pp2 = 0: everything) on `variant`.  The ping-pong kernel pays a full round for a partial one: the 100 passages of one
+// query (M = 18 400: 72 row panels) are 288 tiles of the O / FFN-out projections = 1.1 rounds paid as 2, 864 of QKV = 3.4 as
+// 4.  All tile variants produce the same bits (K order, epilogue statistics: tests), so the rows beyond the last whole round
+// go to the cheapest fill-in variant as a second launch - same model as choose_variant.  The grouped bench launches (M = 58 880)
+// keep one launch: their last round is 60-98 % full and the model says so.
+struct GemmPlan { int m_pp2; int variant; };
+GemmPlan choose_plan(const rk_engine* e, int epi, int M, int N, int K, bool fold_producer) {
+  double whole = 0;
+  GemmPlan plan{0, choose_variant(e, epi, M, N, K, fold_producer, &whole)};
+  if (!e->opt_gemm_split || e->opt_gemm_variant || K < 128 || e->opt_gemm_persistent != 1) return plan;
+  if (!(epi == EPI_STORE_F16 || epi == EPI_RESID_F32 || EPI_IS_GATED(epi) || epi == EPI_RELU_F16)) return plan;   // (the heads index rows from 0)
+  const int wgs = e->n_cu & ~7, tiles_n = (N + 255) / 256, tiles_m = (M + 255) / 256;
+  const long rounds = (long)tiles_m * tiles_n / wgs;
+  if (rounds < 1 || (long)tiles_m * tiles_n % wgs == 0) return plan;
+  const int panels = (int)(rounds * wgs / tiles_n);          // whole row panels inside the whole rounds
+  if (panels < 1 || panels >= tiles_m) return plan;
+  const long used = (long)panels * tiles_n;
+  double rest = 0;
+  const int v_rest = choose_variant(e, epi, M - panels * 256, N, K, fold_producer, &rest);
+  const double split = (double)((used + wgs - 1) / wgs) * 25.5 + rest + 1.5;   // + a kernel boundary
+  if (split < whole - 1e-9) { plan.m_pp2 = panels * 256; plan.variant = v_rest; }
+  return plan;
 }
 
 // does a folded-norm consumer GEMM of this shape run the persistent ping-pong kernel (row factors from rowscale_kernel)?
 bool consumer_uses_pp2(const rk_engine* e, int epi, int M, int N, int K) {
-  int v = choose_variant(e, epi, M, N, K, false);
+  const GemmPlan pl = choose_plan(e, epi, M, N, K, false);
+  int v = pl.variant;
   if (v > 6) v = 5;
-  return v == 5 && K >= 128;
+  return pl.m_pp2 > 0 || (v == 5 && K >= 128);
 }
 
 template <int EPI>
-void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a) {
-  int variant = choose_variant(e, EPI, a.M, a.N, a.K, a.xraw != nullptr);
+void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a_in, int force_variant = 0) {
+  GemmArgs a = a_in;
+  int variant = force_variant;
+  if (!variant) {
+    const GemmPlan pl = choose_plan(e, EPI, a.M, a.N, a.K, a.xraw != nullptr);
+    variant = pl.variant;
+    if (pl.m_pp2 > 0) {
+      // whole rounds on the ping-pong kernel, then the remaining rows on the fill-in variant (row-offset arguments)
+      GemmArgs head = a;
+      head.M = pl.m_pp2;
+      launch_gemm_epi<EPI>(e, st, head, 5);
+      const size_t r = (size_t)pl.m_pp2;
+      constexpr size_t celt = (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) ? 4 : 2;
+      a.A += r * a.lda;
+      a.C = (char*)a.C + r * (size_t)a.ldc * celt;
+      if (a.rowscale) a.rowscale += r;
+      if (a.xraw) a.xraw += r * a.ldx;
+      if (a.ssq) a.ssq += r * a.nb;
+      if (a.ssq_in) a.ssq_in += r * a.nb_in;
+      a.M -= pl.m_pp2;
+    }
+  }
 #ifdef RK_MEASURE
   if constexpr (EPI == EPI_STORE_F16) {                              // timing-only knock-outs (gemm_variant 80 + mask)
-    if (variant > 80 && variant < 88 && a.K >= 128) {
+    if (variant > 80 && variant <= 96 && a.K >= 128) {
       switch (variant - 80) {
+        case 8: launch_pp2<EPI, 8>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;    // no W-panel DMA
+        case 16: launch_pp2<EPI, 16>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;  // no A-panel DMA
         case 1: launch_pp2<EPI, 1>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
         case 2: launch_pp2<EPI, 2>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
         case 3: launch_pp2<EPI, 3>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
@@ -332,6 +382,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
   GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale, bsA, bsW, bsC};
   a.rowscale = fold.rowscale; a.xraw = fold.xraw; a.ssq = fold.ssq; a.ldx = N; a.nb = (N + 63) / 64; a.xs = RK_XRAW_SCALE;
   a.ssq_in = fold.ssq_in; a.nb_in = fold.nb_in ? fold.nb_in : (K + 63) / 64; a.eps_in = e->d.eps;       // (tiled producers: 64-column blocks)
+  a.group_n = e->opt_gemm_group_n > 0 ? e->opt_gemm_group_n : GEMM_GROUP_N;
   const double flops = 2.0 * M * (double)N * K * batch;
   const double out_elems = EPI_IS_GATED(epi) ? (double)M * N / 2 : (double)M * N;
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
@@ -872,6 +923,7 @@ struct RcclApi {
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;   // optional
 };
 RcclApi g_rccl;
 
@@ -889,6 +941,7 @@ const RcclApi* rccl_api() {
   RK_SYM(GetUniqueId, "ncclGetUniqueId") RK_SYM(CommInitRank, "ncclCommInitRank") RK_SYM(CommDestroy, "ncclCommDestroy")
   RK_SYM(AllGather, "ncclAllGather") RK_SYM(GetErrorString, "ncclGetErrorString")
 #undef RK_SYM
+  g_rccl.GetVersion = (decltype(g_rccl.GetVersion))dlsym(g_rccl.h, "ncclGetVersion");
   return &g_rccl;
 }
 
@@ -903,6 +956,7 @@ void comm_release(rk_engine* e) {
   if (e->d_gsend) { hipFree(e->d_gsend); e->d_gsend = nullptr; }
   if (e->d_gall) { hipFree(e->d_gall); e->d_gall = nullptr; }
   if (e->h_gall) { hipHostFree(e->h_gall); e->h_gall = nullptr; }
+  if (e->h_gstage) { hipHostFree(e->h_gstage); e->h_gstage = nullptr; }
   if (e->ev_gall) { hipEventDestroy(e->ev_gall); e->ev_gall = nullptr; }
   if (e->ev_append) { hipEventDestroy(e->ev_append); e->ev_append = nullptr; }
   e->gall_pending = false; e->append_foreign = false; e->gall_n = 0;
@@ -1752,6 +1806,7 @@ int rk_comm_init(rk_engine* e, const uint8_t* id_bytes, int n_bytes, int rank, i
   HIPCHK(e, hipMemset(e->d_gsend, 0, e->gather_cap * sizeof(float)));
   HIPCHK(e, hipMalloc((void**)&e->d_gall, e->gather_cap * world * sizeof(float)));
   HIPCHK(e, hipHostMalloc((void**)&e->h_gall, e->gather_cap * world * sizeof(float), hipHostMallocDefault));
+  HIPCHK(e, hipHostMalloc((void**)&e->h_gstage, e->gather_cap * sizeof(float), hipHostMallocDefault));
   HIPCHK(e, hipEventCreateWithFlags(&e->ev_gall, hipEventDisableTiming));
   HIPCHK(e, hipEventCreateWithFlags(&e->ev_append, hipEventDisableTiming));
   return RK_OK;
@@ -1762,6 +1817,20 @@ int rk_comm_world(const rk_engine* e, int* out_rank, int* out_world) {
   if (out_rank) *out_rank = e->comm ? e->comm_rank : 0;
   if (out_world) *out_world = e->comm ? e->comm_world : 1;
   return RK_OK;
+}
+
+int rk_comm_capacity(const rk_engine* e) { return (e && e->comm) ? (int)e->gather_cap : 0; }
+
+int rk_comm_library_info(char* buf, int n_bytes) {
+  if (!buf || n_bytes <= 1) return RK_ERR_INVALID;
+  const RcclApi* r = rccl_api();
+  if (!r) return fail(nullptr, RK_ERR_HIP, "%s", g_rccl.err.c_str());
+  Dl_info info{};
+  const char* path = (dladdr((void*)r->AllGather, &info) && info.dli_fname) ? info.dli_fname : "?";
+  int ver = 0;
+  if (r->GetVersion) r->GetVersion(&ver);
+  const int n = snprintf(buf, (size_t)n_bytes, "%s|%d", path, ver);
+  return n < n_bytes ? n : n_bytes - 1;
 }
 
 int rk_comm_all_gather_slot(rk_engine* e, int slot, int n_floats) {
@@ -1808,6 +1877,23 @@ int rk_comm_append_scores_slot(rk_engine* e, int slot, int n_floats, int dst_off
   HIPCHK(e, hipMemcpyAsync(e->d_gsend + dst_offset, sl.d_scores, (size_t)n_floats * sizeof(float), hipMemcpyDeviceToDevice, sd));
   if (sd != dec_stream(e, e->slots[0])) { HIPCHK(e, hipEventRecord(e->ev_append, sd)); e->append_foreign = true; }
   return mark_decoder_done(e, sl);      // the slot's score buffer stays busy until the copy has read it
+}
+
+int rk_comm_append_host(rk_engine* e, const float* values, int n_floats, int dst_offset) {
+  if (!e || (!values && n_floats > 0)) return RK_ERR_INVALID;
+  if (!e->comm) return fail(e, RK_ERR_STATE, "rk_comm_init has not been called");
+  if (n_floats < 0 || dst_offset < 0 || (size_t)n_floats + (size_t)dst_offset > e->gather_cap)
+    return fail(e, RK_ERR_CAPACITY, "append of %d host floats at %d exceeds the send buffer (%zu)", n_floats, dst_offset, e->gather_cap);
+  int rc = set_device(e);
+  if (rc) return rc;
+  if (n_floats == 0) return RK_OK;
+  // the previous gather still reads the send buffer (and its staging copy may be in flight) until its event has passed
+  if (e->gall_pending) { HIPCHK(e, hipEventSynchronize(e->ev_gall)); e->gall_pending = false; }
+  hipStream_t s0 = dec_stream(e, e->slots[0]);     // the stream rk_comm_all_gather_appended runs on: the copy precedes it in order
+  // one staging region per destination range: regions of one query do not overlap, the next query starts behind the gather's event
+  memcpy(e->h_gstage + dst_offset, values, (size_t)n_floats * sizeof(float));
+  HIPCHK(e, hipMemcpyAsync(e->d_gsend + dst_offset, e->h_gstage + dst_offset, (size_t)n_floats * sizeof(float), hipMemcpyHostToDevice, s0));
+  return RK_OK;
 }
 
 int rk_comm_all_gather_appended(rk_engine* e, int n_floats) {
@@ -1932,6 +2018,8 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
   if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 5 (any non-zero value but 6) DMA kernel, two groups per workgroup; 6 one group; 0 tiled kernel
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
+  if (!strcmp(key, "gemm_split")) { e->opt_gemm_split = value != 0; return RK_OK; }   // rows beyond the ping-pong kernel's last whole round on a fill-in tile variant (1) or one launch (0)
+  if (!strcmp(key, "gemm_group_n")) { e->opt_gemm_group_n = value; return RK_OK; }   // ping-pong GEMM: column-panel width of the tile order in tiles (0 = default 8)
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
     if (set_device(e) || sync_all(e)) return RK_ERR_HIP;
     for (Slot& sl : e->slots) sl.dec_pending = false;

@@ -65,6 +65,9 @@ ABI = {
     "rk_comm_unique_id": (C.c_int, [_P(C.c_uint8), C.c_int]),
     "rk_comm_init": (C.c_int, [C.c_void_p, _P(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int]),
     "rk_comm_world": (C.c_int, [C.c_void_p, _i32p, _i32p]),
+    "rk_comm_capacity": (C.c_int, [C.c_void_p]),
+    "rk_comm_library_info": (C.c_int, [C.c_char_p, C.c_int]),
+    "rk_comm_append_host": (C.c_int, [C.c_void_p, _f32p, C.c_int, C.c_int]),
     "rk_comm_all_gather_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rk_comm_read_gathered_slot": (C.c_int, [C.c_void_p, C.c_int, _f32p, C.c_int]),
     "rk_comm_append_scores_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
@@ -271,6 +274,21 @@ class RkEngine:
         buf = (C.c_uint8 * self.COMM_ID_BYTES).from_buffer_copy(unique_id)
         self._chk(self.lib.rk_comm_init(self.h, buf, self.COMM_ID_BYTES, rank, world, max_floats_per_rank))
         self.comm_rank, self.comm_world = rank, world
+        self.comm_capacity = int(self.lib.rk_comm_capacity(self.h))   # what every rank checks before it enters a gather
+
+    def comm_library_info(self) -> str:
+        """'<path of the RCCL library this process bound>|<ncclGetVersion code>' (the torch wheel bundles its own librccl;
+        which one served the run belongs in the logs)."""
+        buf = C.create_string_buffer(1024)
+        n = self.lib.rk_comm_library_info(buf, 1024)
+        if n < 0:
+            raise RkError(n, (self.lib.rk_last_error(None) or b"").decode())
+        return buf.value.decode()
+
+    def comm_append_host(self, values, offset: int):
+        """Put host floats at `offset` of the engine's send buffer (side data that travels with the scores in the one gather)."""
+        v = np.ascontiguousarray(values, dtype=np.float32).reshape(-1)
+        self._chk(self.lib.rk_comm_append_host(self.h, v.ctypes.data_as(_f32p), v.size, offset))
 
     def comm_all_gather(self, n_floats: int, slot: int = 0):
         """Enqueue ONE RCCL all_gather of the slot's device score buffer behind the work that fills it (no sync)."""

@@ -164,7 +164,12 @@ class T5Runtime:
         ids = [self.engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         self.engine.comm_init(ids[0], rank, world, max_floats_per_rank or self.COMM_FLOATS_PER_RANK)
-        self.comm_capacity = max_floats_per_rank or self.COMM_FLOATS_PER_RANK
+
+    @property
+    def comm_capacity(self) -> int:
+        """Floats per rank the live communicator can ship - the ENGINE's figure, whoever built the communicator (this
+        runtime, bench.py or a tool through engine.comm_init): one value for the check and the message on every rank."""
+        return int(getattr(self.engine, "comm_capacity", 0) or 0)
 
     def ensure_comm(self) -> bool:
         """Called by a candidate-sharding ranker before its first sharded query: under an initialised process group of
@@ -181,15 +186,20 @@ class T5Runtime:
         self.comm_init_from_process_group()
         return self.comm_ready()
 
-    def sharded_scores(self, kind: str, seqs, arg, out_ids, width_floats: int):
+    def sharded_scores(self, kind: str, seqs, arg, out_ids, width_floats: int, tail=None, tail_offset: int = 0):
         """This rank's share of one query -> (local raw outputs, allv [world, width_floats]) with ONE RCCL all_gather.
         The share may take several engine calls (more than max_seqs sequences / max_tokens tokens): each call's scores are
         appended to the engine's send buffer on the device (rk_comm_append_scores_slot), then the whole share is shipped.
-        Every rank issues exactly one collective per query whatever its chunk count (also with an empty share)."""
-        if width_floats > getattr(self, "comm_capacity", self.COMM_FLOATS_PER_RANK):
+        Every rank issues exactly one collective per query whatever its chunk count (also with an empty share).
+        `tail`: host floats that travel in the same gather at `tail_offset` of this rank's row (the per-passage token counts
+        behind the reference's counters).  width_floats is the same on every rank (it follows from the candidate count and
+        the world size alone), so the capacity check below fails on ALL ranks or none - never inside the collective."""
+        if width_floats > self.comm_capacity:
             raise ValueError(f"{width_floats} floats per rank exceed the communicator's send buffer ({self.comm_capacity}); "
                              "build it with comm_init_from_process_group(max_floats_per_rank=...)")
         k = len(out_ids) if kind == "score" else 1
+        if tail is not None and len(tail):
+            self.engine.comm_append_host(np.asarray(tail, dtype=np.float32), tail_offset)
         parts, off = [], 0
         for chunk in self._chunks(seqs):
             part = self.engine.qlm(chunk, arg) if kind == "qlm" else self.engine.score(chunk, arg, out_ids)

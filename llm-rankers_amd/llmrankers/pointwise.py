@@ -63,8 +63,8 @@ class PointwiseLlmRanker(LlmRanker):
         self.method = method
         self.batch_size = batch_size
         # opt-in data parallelism (one process per GPU under torchrun): each rank scores a contiguous chunk of the
-        # candidate list, one all_gather collects the scores (llmrankers/_dist.py).  Counters then describe the
-        # local chunk; scores and rank order are identical to a single-GPU run.
+        # candidate list, one all_gather collects the scores AND the prompts' token counts (llmrankers/_dist.py), so
+        # scores, rank order and the three counters are those of a single-GPU run on every rank.
         self.shard_candidates = shard_candidates
         self.total_compare = 0
         self.total_completion_tokens = 0
@@ -105,6 +105,13 @@ class PointwiseLlmRanker(LlmRanker):
             out.append(chunk)
         return out
 
+    def _count_from_lengths(self, lengths, dec_len: int):
+        """The same counters from the prompts' token counts alone (sharded runs: every rank tokenises only its share and
+        learns the other lengths from the gather): one compare per reference batch, batch-longest padding (ref :105-114)."""
+        for s, e in batches(len(lengths), self.batch_size):
+            self.total_compare += 1
+            self.total_prompt_tokens += (e - s) * int(max(lengths[s:e])) + (e - s) * dec_len
+
     def _raw(self, chunks, kind, arg, out_ids):
         """Raw engine output for all batches of one query, concatenated in passage order."""
         if not chunks:
@@ -134,18 +141,26 @@ class PointwiseLlmRanker(LlmRanker):
         if spec is None:
             return sorted(ranking, key=lambda x: x.score, reverse=True)
         prompts, kind, arg, out_ids, dec_len, finish = spec
-        chunks = self._counted_batches(prompts, dec_len)
+        flat = tokenize_prompts(self.tokenizer, prompts)
         k = len(out_ids) if kind == "score" else 1
+        # a rank's row of the gather: its scores [width * k], then its prompts' token counts [width] (exact in fp32) - the
+        # counters of the whole query (ref: pointwise.py:105-114) need every passage's length, and every rank reports them
+        lens = np.asarray([len(q) for q in flat], dtype=np.float32)
+        row = width * (k + 1)
         # the engine builds its RCCL communicator on the first sharded query (collective: every rank is here)
         if getattr(self.llm, "ensure_comm", lambda: False)():
-            flat = [q for c in chunks for q in c]
-            local, allv = self.llm.sharded_scores(kind, flat, arg, out_ids, width * k)
+            local, allv = self.llm.sharded_scores(kind, flat, arg, out_ids, row, tail=lens, tail_offset=width * k)
             assert len(local) == (e - s) * k
-            allv = np.asarray(allv, dtype=np.float32).reshape(ws, width * k)
+            allv = np.asarray(allv, dtype=np.float32).reshape(ws, row)
         else:
-            local = self._raw(chunks, kind, arg, out_ids).reshape(-1)
-            allv = _dist.all_gather_flat(local, width * k)
+            chunks = [flat[i:j] for i, j in batches(len(flat), self.batch_size)]
+            local = np.zeros(row, np.float32)
+            local[:(e - s) * k] = self._raw(chunks, kind, arg, out_ids).reshape(-1)
+            local[width * k:width * k + (e - s)] = lens
+            allv = _dist.all_gather_flat(local, row)
         raw = np.concatenate([allv[r, :(b - a) * k] for r, (a, b) in enumerate(bounds)])
+        all_lens = np.concatenate([allv[r, width * k:width * k + (b - a)] for r, (a, b) in enumerate(bounds)])
+        self._count_from_lengths(np.rint(all_lens).astype(np.int64), dec_len)
         scores = finish(raw.reshape(-1, k) if kind == "score" else raw)
         for doc, sc in zip(ranking, scores):
             doc.score = float(sc)

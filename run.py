@@ -81,6 +81,26 @@ def read_run_qids(path):
     return seen
 
 
+def read_run_lines(path):
+    """{qid: [raw lines]} of a (partial) run file, qids in file order."""
+    out = {}
+    try:
+        with open(path) as f:
+            for line in f:
+                parts = line.split()
+                if parts:
+                    out.setdefault(parts[0], []).append(line if line.endswith("\n") else line + "\n")
+    except FileNotFoundError:
+        pass
+    return out
+
+
+def part_files(save_path):
+    """Per-rank part files of a --resume run in query-replica mode (`<save_path>.rank<N>`), any world size."""
+    import glob
+    return sorted(glob.glob(glob.escape(save_path) + ".rank*"))
+
+
 def split_into_shards(data, num_shards):
     """Contiguous shards whose sizes differ by at most one (ref: Rank-R1/run_setwise.py:90-92)."""
     base, extra = divmod(len(data), num_shards)
@@ -267,11 +287,20 @@ def main(args):
     shard_cands = candidates_sharded(args, world)
     replicas = world > 1 and not shard_cands                         # ranks take whole queries; rank 0 collects the rankings
     all_qids = [qid for qid, _, _ in first_stage]
+    all_shards = None
     if replicas:
-        first_stage = split_into_shards(first_stage, world)[rank]
+        all_shards = split_into_shards(first_stage, world)
+        first_stage = all_shards[rank]
     writer = rank == 0                                               # candidate sharding: every rank holds every ranking
     resume = bool(getattr(args.run, "resume", False))
     done = set(read_run_qids(args.run.save_path)) if resume else set()
+    # query replicas under --resume: every rank appends ITS finished queries to <save_path>.rank<N> after every call (durable
+    # like the single-process form, ref: Rank-R1/run_setwise.py:79-87); a restart - with any number of ranks - skips what any
+    # part file holds, and rank 0 merges the parts into --save_path at the end
+    my_part = f"{args.run.save_path}.rank{rank}" if (resume and replicas) else None
+    if resume and replicas:
+        for pf in part_files(args.run.save_path):
+            done.update(read_run_qids(pf))
     if done:
         print(f"{args.run.save_path} exists. Continue ranking ({len(done)} queries done)")
     first_stage_order = {qid: [d.docid for d in ranking] for qid, _, ranking in first_stage}
@@ -304,18 +333,33 @@ def main(args):
             n_cmp += c
             n_prompt += p
             n_compl += t
-        if resume and writer and not replicas:                       # durable after every call (ref: Rank-R1/run_setwise.py:79-87)
+        if resume and my_part:                                       # durable after every call, one part file per rank
+            write_run_file(my_part, results[-len(pending):], "LLMRankers", mode="a")
+        elif resume and writer:                                      # (ref: Rank-R1/run_setwise.py:79-87)
             write_run_file(args.run.save_path, results[-len(pending):], "LLMRankers", mode="a")
         pending.clear()
 
+    # --shuffle_ranking random draws from ONE global sequence (random.seed(929), ref: run.py:16,187): under query replicas every
+    # rank walks ALL queries in first-stage order and shuffles each of them, so that its own queries see exactly the draws a
+    # single process would have made for them.  (Rankers that draw random numbers themselves - setwise permutation voting -
+    # cannot be advanced past the queries of other ranks: their multi-rank runs differ from a single process, and say so.)
+    mine = {qid for qid, _, _ in first_stage}
+    walk = first_stage
+    if replicas and args.run.shuffle_ranking == "random":
+        walk = [item for shard in all_shards for item in shard]
+        if getattr(ranker, "num_permutation", 1) > 1 and rank == 0:
+            print("[run] note: permutation voting draws from the global RNG inside rerank(); with --num_gpus > 1 the draws of a "
+                  "query differ from a single-process run", file=sys.stderr)
     tic = time.time()
-    for qid, query, ranking in first_stage:
+    for qid, query, ranking in walk:
         if qid in done:
             continue
         if args.run.shuffle_ranking == "random":
             random.shuffle(ranking)
         elif args.run.shuffle_ranking == "inverse":
             ranking = ranking[::-1]
+        if qid not in mine:
+            continue
         pending.append((qid, query, ranking))
         if len(pending) >= per_call:
             flush()
@@ -346,7 +390,20 @@ def main(args):
     print(f"Avg completion tokens: {n_compl / n}")
     print(f"Avg time per query: {(toc - tic) / n}")
     if replicas and resume:
-        write_run_file(args.run.save_path, results, "LLMRankers", mode="a")
+        # merge: what --save_path already held, then every rank's part file (all flushed: the barrier above), in first-stage order
+        merged = read_run_lines(args.run.save_path)
+        parts_now = part_files(args.run.save_path)
+        for pf in parts_now:
+            for qid, lines in read_run_lines(pf).items():
+                merged.setdefault(qid, lines)
+        order = [q for q in merged if q not in set(all_qids)] + [q for q in all_qids if q in merged]
+        tmp = args.run.save_path + ".merge"
+        with open(tmp, "w") as f:
+            for q in order:
+                f.writelines(merged[q])
+        os.replace(tmp, args.run.save_path)
+        for pf in parts_now:
+            os.remove(pf)
     elif not resume:
         write_run_file(args.run.save_path, results, "LLMRankers")
     if getattr(args.run, "qrels", None):

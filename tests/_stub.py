@@ -95,7 +95,14 @@ class FakeCommEngine:
         assert uid == bytes(range(128)), "the id did not travel from rank 0"
         self.calls["init"] += 1
         self.comm_rank, self.comm_world = rank, world
+        self.comm_capacity = cap
         self._send = np.full(cap, np.nan, np.float32)
+
+    def comm_append_host(self, values, offset):
+        v = np.asarray(values, dtype=np.float32).reshape(-1)
+        assert offset + len(v) <= len(self._send)
+        self.calls["append_host"] = self.calls.get("append_host", 0) + 1
+        self._send[offset:offset + len(v)] = v
 
     def comm_append(self, n, offset, slot=0):
         assert slot == 0 and n <= len(self._last)

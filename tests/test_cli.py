@@ -305,6 +305,12 @@ def test_two_rank_run_py_matches_single_process(runmod, tmp_path, ckpt_dirs, sha
         assert p.returncode == 0, err[-2000:]
         outs.append(out)
     assert "Avg comparisons" in outs[0] and "Avg comparisons" not in outs[1]       # rank 0 reports
+
+    def avgs(text):
+        return [l for l in text.splitlines() if l.startswith("Avg") and "time" not in l]
+    # ... the single-process (= the reference's) statistics: under candidate sharding every rank learns all token counts from
+    # the gather, under query replicas rank 0 sums the ranks' counters
+    assert avgs(outs[0]) == avgs(single.stdout) and len(avgs(single.stdout)) == 3
     a = [l.split("\t") for l in (tmp_path / "single.trec").read_text().splitlines()]
     b = [l.split("\t") for l in (tmp_path / "multi.trec").read_text().splitlines()]
     assert [x[:4] + x[5:] for x in a] == [x[:4] + x[5:] for x in b] and len(a) == 21
@@ -314,3 +320,52 @@ def test_two_rank_run_py_matches_single_process(runmod, tmp_path, ckpt_dirs, sha
         assert all(c["init"] == 1 and c["gather"] == 3 and c["append"] == 6 for c in calls), calls
     else:                       # replicas: no communicator, no gather
         assert all(c["init"] == 0 and c["gather"] == 0 for c in calls), calls
+
+
+def test_two_rank_replicas_resume_is_durable(runmod, tmp_path, ckpt_dirs):
+    """--resume under query replicas (--shard_candidates 0, 2 ranks): every rank appends its finished queries to
+    <save_path>.rank<N> as it goes; a restart skips what ANY part file (or --save_path) already holds - here q3 sits in a part
+    file a 'crashed' run left behind - and rank 0 merges everything into --save_path in first-stage order and removes the parts."""
+    import json
+    import socket
+    import subprocess
+    ck = ckpt_dirs["ckpt_gated_untied"]
+    (tmp_path / "q.tsv").write_text("q1\tneural ranking model\nq2\twater river mountain\nq3\tmusic art film\n")
+    (tmp_path / "d.tsv").write_text("\n".join(f"d{i}\t{w}" for i, w in enumerate(
+        ["search engine index", "river water city", "music art film", "vaccine covid virus", "bank money trade",
+         "neural model answer", "mountain river water", "film music topic"])) + "\n")
+    lines = [f"{q} Q0 d{i} {r + 1} {10 - r} bm25" for q in ("q1", "q2", "q3") for r, i in enumerate([0, 1, 2, 3, 4, 5, 6])]
+    (tmp_path / "in.trec").write_text("\n".join(lines) + "\n")
+    (tmp_path / "worker.py").write_text(RUN_WORKER)
+
+    def argv(save, extra=()):
+        return ["run", "--model_name_or_path", ck, "--run_path", str(tmp_path / "in.trec"), "--save_path", str(save),
+                "--query_file", str(tmp_path / "q.tsv"), "--doc_file", str(tmp_path / "d.tsv"), "--hits", "7",
+                "--shard_candidates", "0", *extra, "pointwise", "--method", "yes_no", "--batch_size", "3"]
+
+    base_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    single = subprocess.run([sys.executable, str(tmp_path / "worker.py"), REPO, ck, json.dumps(argv(tmp_path / "single.trec"))],
+                            capture_output=True, text=True, env=dict(base_env, OMP_NUM_THREADS="2"), timeout=600)
+    assert single.returncode == 0, single.stderr[-2000:]
+    want = (tmp_path / "single.trec").read_text()
+    # what a killed earlier run left: q3 finished by (then) rank 1, nothing merged yet
+    (tmp_path / "multi.trec.rank1").write_text("".join(l + "\n" for l in want.splitlines() if l.startswith("q3\t")))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, str(tmp_path / "worker.py"), REPO, ck, json.dumps(argv(tmp_path / "multi.trec", ["--resume"]))],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(base_env, OMP_NUM_THREADS="2", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))) for r in range(2)]
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        outs.append(out)
+    a = [l.split("\t") for l in want.splitlines()]
+    b = [l.split("\t") for l in (tmp_path / "multi.trec").read_text().splitlines()]
+    assert [x[:4] + x[5:] for x in a] == [x[:4] + x[5:] for x in b] and len(b) == 21
+    assert not list(tmp_path.glob("multi.trec.rank*"))                           # merged and removed
+    calls = [json.loads(next(l for l in o.splitlines() if l.startswith("CALLS "))[6:]) for o in outs]
+    # shards: rank 0 = (q1, q2), rank 1 = (q3,): q3 was done, so rank 1 scored nothing; rank 0 scored 2 queries x 4 engine calls
+    assert calls[1]["score"] == 0 and calls[0]["score"] == 8, calls
