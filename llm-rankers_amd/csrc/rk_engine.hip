@@ -927,12 +927,37 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 
+// Which librccl: ONE per process.  When PyTorch is in the process its wheel's own copy (torch/lib/librccl.so, 2.26.6 in this
+// image against 2.27.7 under /opt/rocm) is usually mapped already - a second, different RCCL beside it would bring its own
+// HSA / IPC state.  So: (1) the copy already mapped into this process (first "librccl" entry of /proc/self/maps), by its
+// exact path; (2) the SONAME through the loader's search path; (3) the ROCm install.  rk_comm_library_info reports the
+// path and version actually bound, and bench.py / run.py log it.
+std::string mapped_rccl_path() {
+  FILE* f = fopen("/proc/self/maps", "r");
+  if (!f) return "";
+  char line[4096];
+  std::string found;
+  while (fgets(line, sizeof line, f)) {
+    const char* p = strstr(line, "librccl");
+    if (!p) continue;
+    const char* path = strchr(line, '/');
+    if (!path) continue;
+    found.assign(path);
+    while (!found.empty() && (found.back() == '\n' || found.back() == ' ')) found.pop_back();
+    break;
+  }
+  fclose(f);
+  return found;
+}
+
 const RcclApi* rccl_api() {
   if (g_rccl.tried) return g_rccl.h ? &g_rccl : nullptr;
   g_rccl.tried = true;
+  const std::string mapped = mapped_rccl_path();
+  if (!mapped.empty()) g_rccl.h = dlopen(mapped.c_str(), RTLD_NOW | RTLD_GLOBAL);
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (g_rccl.h) break;
+    g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
   }
   if (!g_rccl.h) { g_rccl.err = std::string("dlopen(librccl.so.1) failed: ") + (dlerror() ? dlerror() : "?"); return nullptr; }
 #define RK_SYM(field, sym)                                                              \

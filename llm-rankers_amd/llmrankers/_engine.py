@@ -92,12 +92,14 @@ ABI = {
 _lib = None
 
 
-def load_library(path: Optional[str] = None):
-    """dlopen librk_engine.so and attach prototypes. Raises if the in-tree build is missing (no fallback)."""
+def load_library(path: Optional[str] = None, make_default: bool = False):
+    """dlopen librk_engine.so and attach prototypes. Raises if the in-tree build is missing (no fallback).
+    The product always loads the in-tree library (LIB_PATH).  `path` + make_default=True is for tools/ only: separately compiled
+    A/B or measurement builds (tools/_lib.py); no environment variable redirects the product's library."""
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or os.environ.get("RK_ENGINE_LIB", LIB_PATH)
+    p = path or LIB_PATH
     # PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  If torch gets imported AFTER this library (e.g. via
     # transformers' tokenizer), the process would hold two HIP runtimes; importing torch first lets the loader
     # resolve our DT_NEEDED libamdhip64.so.7 to the copy already mapped.  Plumbing only — nothing here uses torch.
@@ -117,7 +119,7 @@ def load_library(path: Optional[str] = None):
         fn = getattr(lib, name)     # AttributeError here = the .so does not export what the header declares
         fn.restype = res
         fn.argtypes = args
-    if path is None:
+    if path is None or make_default:
         _lib = lib
     return lib
 

@@ -112,6 +112,7 @@ def timing():
 
 if __name__ == "__main__":
     import torch  # noqa: F401  (its HIP runtime first)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lib; _lib.use_env_library()   # RK_ENGINE_LIB: A/B or measurement build (tools only)
     import __graft_entry__ as ge
     if not os.environ.get("RK_ENGINE_LIB"):
         ge.build()

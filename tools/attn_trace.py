@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Phase timeline of the DMA attention kernel from a measurement build (hipcc ... -DRK_MEASURE -o build/librk_engine_measure.so;
-RK_ENGINE_LIB=build/librk_engine_measure.so python tools/attn_trace.py): the twelve waves of one workgroup stamp the 100 MHz wall
+"""Phase timeline of the DMA attention kernel from a measurement build (hipcc ... -DRK_MEASURE -o exp/librk_engine_measure.so;
+RK_ENGINE_LIB=exp/librk_engine_measure.so python tools/attn_trace.py): the twelve waves of one workgroup stamp the 100 MHz wall
 clock at the phase boundaries of every item (attention.h: ATTD_STAMP); prints the mean duration of every phase in microseconds
 per wave group, for the bench shape (flan-t5-large dims, 320 x 184 tokens)."""
 import json
@@ -17,6 +17,7 @@ PHASES = ["dma_issue", "scores(QK)", "bias+max", "exp+pack", "issue_q+wait_V", "
 
 def main():
     import torch  # noqa: F401
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lib; _lib.use_env_library()   # RK_ENGINE_LIB: A/B or measurement build (tools only)
     import bench
     from llmrankers import _synth
     from llmrankers._engine import RkEngine

@@ -17,6 +17,8 @@ SHAPES = [  # name, M, N, K, epi
 
 
 def main():
+    import torch  # noqa: F401  (its HIP runtime first)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lib; _lib.use_env_library()   # RK_ENGINE_LIB: A/B or measurement build (tools only)
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     m_override = int(os.environ.get("RK_BENCH_M", "0"))
     if m_override:

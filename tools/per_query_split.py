@@ -14,6 +14,7 @@ sys.path[:0] = [os.path.join(REPO, "llm-rankers_amd"), REPO]
 def main():
     import numpy as np
     import torch  # noqa: F401
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lib; _lib.use_env_library()   # RK_ENGINE_LIB: A/B or measurement build (tools only)
     import bench
     import __graft_entry__ as ge
     ge.build()

@@ -16,6 +16,7 @@ sys.path[:0] = [os.path.join(REPO, "llm-rankers_amd"), REPO]
 
 def main():
     import torch  # noqa: F401  (its HIP runtime first)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lib; _lib.use_env_library()   # RK_ENGINE_LIB: A/B or measurement build (tools only)
     import bench
     import __graft_entry__ as ge
     ge.build()
