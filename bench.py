@@ -312,9 +312,11 @@ def per_query_numbers(eng, dims, B, L):
                              "tokens_per_prompt": round(ranker.total_prompt_tokens / 100.0, 1),
                              "note": "PointwiseLlmRanker.rerank incl. prompt building, host tokenisation (fixture tokenizer), sort"}
         try:
-            # (c) the same through PointwiseLlmRanker.rerank_many (run.py --queries_per_call 3): three queries per engine launch
-            # sequence - identical rankings, the engine's grouped throughput instead of its one-query-at-a-time one
-            queries = [" ".join(rs.choice(words, 30)) for _ in range(3)]
+            # (c) the same through PointwiseLlmRanker.rerank_many with run.py's DEFAULT queries per call (--queries_per_call 0 =
+            # auto: enough queries for >= 256 passages, 3 at hits=100) - identical rankings and counters, the engine's grouped
+            # throughput instead of its one-query-at-a-time one: this is what `python run.py run ... pointwise` delivers
+            from llmrankers._batching import default_queries_per_call
+            queries = [" ".join(rs.choice(words, 30)) for _ in range(default_queries_per_call("pointwise", 100))]
             ts = []
             for _ in range(5):
                 items = [(q, [SearchResult(docid=str(i), score=float(100 - i), text=d) for i, d in enumerate(docs)]) for q in queries]
@@ -322,7 +324,8 @@ def per_query_numbers(eng, dims, B, L):
                 ranker.rerank_many(items)
                 ts.append(time.perf_counter() - t)
             ms = float(np.median(ts[2:])) * 1e3 / len(queries)
-            out["rerank_many_api"] = {"queries_per_call": len(queries), "ms_per_query": round(ms, 2), "passages_per_s": round(100 / ms * 1e3, 1)}
+            out["rerank_many_api"] = {"queries_per_call": len(queries), "ms_per_query": round(ms, 2), "passages_per_s": round(100 / ms * 1e3, 1),
+                                      "note": "run.py's default (--queries_per_call 0 = auto): PointwiseLlmRanker.rerank_many"}
         except Exception as exc:
             out["rerank_many_api"] = {"error": repr(exc)}
     except Exception as exc:                                   # never take the headline number down

@@ -147,3 +147,16 @@ def batches(n_items: int, batch_size: int) -> Iterator[Tuple[int, int]]:
 def padded_token_count(seqs: Sequence[Sequence[int]]) -> int:
     """B x L_longest: what `input_ids.shape[0] * input_ids.shape[1]` is after the reference's collator."""
     return len(seqs) * max(len(s) for s in seqs) if seqs else 0
+
+
+def default_queries_per_call(kind: str, hits: int) -> int:
+    """How many queries run.py hands to a ranker's rerank_many at once when --queries_per_call is left at 0 (auto).
+    Results, caller lists and counters are those of one query at a time (tests); what changes is what one engine launch
+    sequence holds.  pointwise: enough queries for >= 256 passages (the encoder GEMMs then run at M >= 47k tokens and one
+    decoder chain serves them all: 6.4k against 5.6k passages/s through the API, bench line `per_query`); setwise: four
+    heapsorts in lockstep (49 against 106 ms per query); anything else one query at a time."""
+    if kind == "pointwise":
+        return max(1, min(8, -(-256 // max(1, int(hits)))))
+    if kind == "setwise":
+        return 4
+    return 1

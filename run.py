@@ -309,7 +309,10 @@ def main(args):
     # --queries_per_call N: N queries go to the engine together (PointwiseLlmRanker.rerank_many: all their batches in one launch
     # sequence; SetwiseLlmRanker.rerank_many: their heapsorts advance in lockstep, one engine call per step of all the chains) -
     # same rankings and counters as one query at a time, the engine's batched throughput instead of its per-query one
-    per_call = max(1, int(getattr(args.run, "queries_per_call", 1) or 1))
+    per_call = int(getattr(args.run, "queries_per_call", 0) or 0)
+    if per_call <= 0:                                                # auto: the engine's grouped throughput by default
+        from llmrankers._batching import default_queries_per_call
+        per_call = default_queries_per_call("pointwise" if args.pointwise else ("setwise" if args.setwise else "other"), args.run.hits)
     if per_call > 1 and not hasattr(ranker, "rerank_many"):
         per_call = 1
     if per_call > 1 and args.run.shuffle_ranking == "random" and getattr(ranker, "num_permutation", 1) > 1:
@@ -446,8 +449,10 @@ def build_parser():
     rp.add_argument("--shard_candidates", type=int, default=None, choices=[0, 1],
                     help="pointwise under several ranks: 1 (default) shards every query's candidates and gathers the scores over "
                          "RCCL, 0 deals whole queries to the ranks")
-    rp.add_argument("--queries_per_call", type=int, default=1,
-                    help="pointwise / setwise: queries handed to the engine together (same rankings and counters as one at a time)")
+    rp.add_argument("--queries_per_call", type=int, default=0,
+                    help="pointwise / setwise: queries handed to the engine together (same rankings and counters as one at a time); "
+                         "0 = auto: pointwise enough queries for >= 256 passages per engine launch sequence (3 at hits=100), setwise 4; "
+                         "1 = the reference's one query at a time")
     pw = commands.add_parser("pointwise")
     pw.add_argument("--method", type=str, default="yes_no", choices=["qlm", "yes_no"])
     pw.add_argument("--batch_size", type=int, default=2)

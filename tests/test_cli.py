@@ -114,6 +114,7 @@ def test_resume_appends_and_skips_done_queries(runmod, tmp_path, ckpt_dirs, monk
         args = runmod.parse_args(parser, commands, ["run", "--model_name_or_path", ck, "--run_path", str(tmp_path / "in.trec"),
                                                     "--save_path", str(save), "--query_file", str(tmp_path / "q.tsv"),
                                                     "--doc_file", str(tmp_path / "d.tsv"), "--hits", "4", "--qrels", str(tmp_path / "qrels"),
+                                                    "--queries_per_call", "1",   # (this test counts rerank() calls: one query at a time)
                                                     *extra, "pointwise", "--method", "yes_no", "--batch_size", "2"])
         runmod.validate(args)
         runmod.main(args)
@@ -210,8 +211,12 @@ def test_queries_per_call_gives_the_same_run_and_statistics(runmod, tmp_path, ck
         runmod.main(args)
         return [l for l in capsys.readouterr().out.splitlines() if l.startswith("Avg") and "time" not in l]
 
-    stats1 = run(tmp_path / "one.trec")
+    stats1 = run(tmp_path / "one.trec", ["--queries_per_call", "1"])               # the reference's loop: one query at a time
     n1 = len(engine_calls)
+    del engine_calls[:]
+    stats_auto = run(tmp_path / "auto.trec")                                       # default = auto: 256 / hits -> capped at 8 queries per call
+    assert (tmp_path / "auto.trec").read_text() == (tmp_path / "one.trec").read_text() and stats_auto == stats1
+    assert engine_calls == [20]                                                    # all 5 queries x 4 passages in ONE engine call
     del engine_calls[:]
     stats3 = run(tmp_path / "three.trec", ["--queries_per_call", "3"])             # groups of 3 + 2
     assert (tmp_path / "three.trec").read_text() == (tmp_path / "one.trec").read_text()
@@ -341,7 +346,7 @@ def test_two_rank_replicas_resume_is_durable(runmod, tmp_path, ckpt_dirs):
     def argv(save, extra=()):
         return ["run", "--model_name_or_path", ck, "--run_path", str(tmp_path / "in.trec"), "--save_path", str(save),
                 "--query_file", str(tmp_path / "q.tsv"), "--doc_file", str(tmp_path / "d.tsv"), "--hits", "7",
-                "--shard_candidates", "0", *extra, "pointwise", "--method", "yes_no", "--batch_size", "3"]
+                "--shard_candidates", "0", "--queries_per_call", "1", *extra, "pointwise", "--method", "yes_no", "--batch_size", "3"]
 
     base_env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     single = subprocess.run([sys.executable, str(tmp_path / "worker.py"), REPO, ck, json.dumps(argv(tmp_path / "single.trec"))],

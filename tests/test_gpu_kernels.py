@@ -658,13 +658,20 @@ def test_comm_single_rank_appended_gather_of_a_multi_chunk_share(toy):
     eng = _engine(dims, state, max_tokens=2048, max_seqs=4, max_dec_len=8)
     rt = T5Runtime.from_engine(eng, dims)
     eng.comm_init(eng.comm_unique_id(), 0, 1, 256)
-    rt.comm_capacity = 256
+    assert rt.comm_capacity == 256                       # the ENGINE's figure, whoever built the communicator
+    info = eng.comm_library_info()
+    assert "librccl" in info and int(info.rsplit("|", 1)[1]) > 0, info
     try:
         seqs = _synth.synth_token_batch(11, 4, 60, dims.vocab, seed=5)
         want = np.concatenate([eng.score(seqs[i:i + 4], [0], [21, 22]) for i in range(0, 11, 4)])
-        local, allv = rt.sharded_scores("score", seqs, [0], [21, 22], 13 * 2)
+        # scores [13 x 2] then host side data [13] (the prompts' token counts of a sharded query) in ONE gather
+        lens = np.asarray([len(q) for q in seqs], dtype=np.float32)
+        local, allv = rt.sharded_scores("score", seqs, [0], [21, 22], 13 * 3, tail=lens, tail_offset=13 * 2)
         np.testing.assert_array_equal(local.reshape(11, 2), want)
         np.testing.assert_array_equal(np.asarray(allv).reshape(-1)[:22].reshape(11, 2), want)
+        np.testing.assert_array_equal(np.asarray(allv).reshape(-1)[26:37], lens)
+        with pytest.raises(ValueError):                   # beyond the send buffer: refused on the host, before any collective
+            rt.sharded_scores("score", seqs, [0], [21, 22], 257)
         labels = [0, 5, 9, 17]
         want_q = np.concatenate([eng.qlm(seqs[i:i + 4], labels) for i in range(0, 11, 4)])
         local_q, allv_q = rt.sharded_scores("qlm", seqs, labels, None, 13)
