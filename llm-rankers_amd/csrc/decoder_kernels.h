@@ -1,0 +1,257 @@
+// Fused projections around the query-side cross-attention of the few-row decoder (round 4).
+//
+// hf: T5LayerCrossAttention (modeling_t5.py:404-432) as restated in attention.h (XAttnArgs): per decoder layer
+//     q = W_q norm(x);  qk_h = W_k,h^T q_h;  [scores / softmax / sum_t p e_t over 64-key chunks];  combine;  ctx_h = W_v,h (.)
+// was FIVE launches: two per-head weight-streaming GEMMs of 64-wide K or N (5120 workgroups each at 320 rows), the chunk
+// kernel, the combine kernel (H x rows workgroups) and the q projection before them.  The two pairs around the chunk kernel
+// are row- AND head-local, so each pair is one kernel here, one workgroup per (head, slab of decoder rows), on the matrix cores:
+//   dec_cross_qk_kernel:  q_h = rowfactor * (W_q,h x)  (K = d, split over the four waves, fixed-order LDS tree) -> fp16 in LDS
+//                         -> qk_h = W_k,h^T q_h (K = 64) -> qk [rows, H, d] fp16          (replaces the cq + ckT GEMMs)
+//   dec_cross_cv_kernel:  merge the chunks' partial sums of a (row, head) in chunk order and normalise (the arithmetic of
+//                         xattn_combine_kernel) -> fp16 in LDS -> ctx_h = W_v,h (.) (K = d) -> ctx [rows, H*64] fp16
+//                                                                                         (replaces combine + the wv GEMM)
+// A decoder layer at one position is 7 launches instead of 9 (9 instead of 11 beyond), the 5120-workgroup launches are gone.
+// A row's result does not depend on which rows share its slab (MFMA columns are independent), so neither on the batch nor
+// on the rows-per-workgroup the host picks.  Rounding points are the unfused path's (q, qk, the merged sums and ctx are fp16
+// there too); only the fp32 summation order over K differs (contiguous quarters here, interleaved 16-steps there).
+#pragma once
+#include "common.h"
+
+struct DecQKArgs {
+  const half_t* x; int ldx;      // [M, ldx] decoder stream: fp16(x * xs) with the norm folded (row factor below) or the normalised rows
+  const half_t* wq;              // [H*64, d] cross-attention q projection (norm weight folded in when x is the raw stream)
+  const half_t* wkT;             // [H][d][64]  W_k regrouped per head and transposed (finalize)
+  half_t* qk;                    // [M, H, d]
+  int M, d, H;
+  const float* rowscale;         // row factors, or
+  const float* ssq_in; int nb_in; float eps, xs;   // block sums of squares -> rk_row_factor; both null: factor 1
+};
+
+__device__ __forceinline__ void dec_tree_reduce2(f32x16& a0, f32x16& a1, float* red, int wave, int lane) {
+  // (w0 + w2) + (w1 + w3), fixed order; red: 2 x 2 x 16 x 64 floats
+  if (wave >= 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[((wave - 2) * 2 + 0) * 1024 + r * 64 + lane] = a0[r]; red[((wave - 2) * 2 + 1) * 1024 + r * 64 + lane] = a1[r]; }
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] += red[(wave * 2 + 0) * 1024 + r * 64 + lane]; a1[r] += red[(wave * 2 + 1) * 1024 + r * 64 + lane]; }
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[r * 64 + lane] = a0[r]; red[1024 + r * 64 + lane] = a1[r]; }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] += red[r * 64 + lane]; a1[r] += red[1024 + r * 64 + lane]; }
+  }
+}
+
+// out[n][m] += sum_k W[n][k] X[m][k] over this wave's K range: two 32-row weight tiles (w0, w1 = w0 + 32 rows), activation
+// rows either from global or from LDS (same pointer arithmetic).  The lane's pointers already carry its row and 8 * hh.
+__device__ __forceinline__ void dec_mfma_krange(const half_t* w0, const half_t* w1, const half_t* xr, int kq, f32x16& a0, f32x16& a1) {
+  int k = 0;
+  for (; k + 64 <= kq; k += 64) {
+    half8 xf[4], f0[4], f1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { xf[u] = *(const half8*)(xr + k + 16 * u); f0[u] = *(const half8*)(w0 + k + 16 * u); f1[u] = *(const half8*)(w1 + k + 16 * u); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0[u], xf[u], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1[u], xf[u], a1, 0, 0, 0);
+    }
+  }
+  for (; k < kq; k += 16) {
+    const half8 xf = *(const half8*)(xr + k);
+    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)(w0 + k), xf, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)(w1 + k), xf, a1, 0, 0, 0);
+  }
+}
+
+#define DECQ_STR 72      // sQ row stride in halfs (144 B: rows start in different 16-byte slots)
+// grid = (H, ceil(M / 32)); 256 threads.
+__global__ __launch_bounds__(256) void dec_cross_qk_kernel(DecQKArgs p) {
+  __shared__ float red[4 * 1024];
+  __shared__ __attribute__((aligned(16))) half_t sQ[32 * DECQ_STR];
+  const int h = blockIdx.x, m0 = blockIdx.y * 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int m = min(m0 + l31, p.M - 1);                            // clamped rows are computed and never stored
+  // ---- q_h [32 rows x 64] = W_q,h x : K = d in four contiguous quarters, one per wave ----
+  const int kq = p.d >> 2;
+  f32x16 a0, a1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+  {
+    const half_t* xr = p.x + (size_t)m * p.ldx + wave * kq + 8 * hh;
+    const half_t* w0 = p.wq + (size_t)(h * 64 + l31) * p.d + wave * kq + 8 * hh;
+    dec_mfma_krange(w0, w0 + (size_t)32 * p.d, xr, kq, a0, a1);
+  }
+  dec_tree_reduce2(a0, a1, red, wave, lane);
+  if (wave == 0) {
+    float rf = 1.f;
+    if (p.rowscale) rf = p.rowscale[m];
+    else if (p.ssq_in) rf = rk_row_factor(p.ssq_in + (size_t)m * p.nb_in, p.nb_in, p.d, p.eps, p.xs);
+    // C layout: lane holds activation row l31, weight rows (= q columns) 8 q + 4 hh + j of each 32-row tile
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      half4 o0, o1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o0[j] = f2h_sat(a0[4 * q + j] * rf); o1[j] = f2h_sat(a1[4 * q + j] * rf); }
+      *(half4*)(sQ + l31 * DECQ_STR + 8 * q + 4 * hh) = o0;
+      *(half4*)(sQ + l31 * DECQ_STR + 32 + 8 * q + 4 * hh) = o1;
+    }
+  }
+  __syncthreads();
+  // ---- qk_h [32 rows x d] = q_h W_k,h : K = 64, the d output columns in 32-column tiles dealt to the waves ----
+  half8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8*)(sQ + l31 * DECQ_STR + 16 * ks + 8 * hh);
+  const int ntile = p.d >> 5;
+  const bool row_ok = m0 + l31 < p.M;
+  half_t* orow = p.qk + ((size_t)(m0 + l31) * p.H + h) * p.d;
+#pragma unroll 2
+  for (int t = wave; t < ntile; t += 4) {
+    const half_t* wr = p.wkT + ((size_t)h * p.d + t * 32 + l31) * 64 + 8 * hh;
+    half8 wf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wf[ks] = *(const half8*)(wr + 16 * ks);
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], qf[ks], o, 0, 0, 0);
+    if (row_ok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const half4 v = {f2h_sat(o[4 * q]), f2h_sat(o[4 * q + 1]), f2h_sat(o[4 * q + 2]), f2h_sat(o[4 * q + 3])};
+        *(half4*)(orow + t * 32 + 8 * q + 4 * hh) = v;
+      }
+    }
+  }
+}
+
+struct DecCVArgs {
+  const float* part;     // [rows, nch, H, d]  partial sums of the chunk kernel (this pass's rows)
+  const float* stat;     // [rows, nch, H, 2]
+  const int* seq_off; const int* row_seq; int Ld, row0;   // decoder row -> encoder sequence (as XAttnArgs)
+  const half_t* wv;      // [H*64, d]  cross-attention W_v rows of this layer
+  half_t* out;           // [rows, ldo]  ctx (fp16), column h*64 + n
+  int nr, d, H, nch, ldo;
+  int R;                 // decoder rows per workgroup (<= 32; the host picks it from the row count - results do not depend on it)
+};
+#define DECV_MAXCH 64    // chunks per row this kernel handles (sequences up to 4096 keys); longer: the unfused pair
+// dynamic LDS: max(32 x (d + 8) halfs, 16 KiB) [merged rows, later the reduction tree] + 2 x 32 x 64 floats [chunk tables] + 64 ints
+__host__ __device__ inline size_t dec_cv_lds_bytes(int d) {
+  size_t rows = (size_t)32 * (d + 8) * 2;
+  if (rows < 16384) rows = 16384;
+  return rows + 2 * 32 * DECV_MAXCH * 4 + 64 * 4;
+}
+// grid = (H, ceil(nr / R)); 256 threads.
+__global__ __launch_bounds__(256) void dec_cross_cv_kernel(DecCVArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char decv_smem[];
+  const int wstr = p.d + 8;
+  size_t rows_bytes = (size_t)32 * wstr * 2;
+  if (rows_bytes < 16384) rows_bytes = 16384;
+  half_t* sWS = (half_t*)decv_smem;
+  float* red = (float*)decv_smem;                                   // aliases sWS once every wave has its fragments
+  float* sWt = (float*)(decv_smem + rows_bytes);                    // [32][64] chunk maxima, then weights
+  float* sSm = sWt + 32 * DECV_MAXCH;                               // [32][64] chunk sums
+  int* sNv = (int*)(sSm + 32 * DECV_MAXCH);                         // [32] chunks with keys;  float view [32..63]: 1 / denominator
+  float* sInv = (float*)(sNv + 32);
+  const int h = blockIdx.x, mbase = blockIdx.y * p.R;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  // ---- chunk statistics of the workgroup's rows -> weights (xattn_combine_kernel's arithmetic, per row in chunk order) ----
+  for (int idx = tid; idx < p.R * DECV_MAXCH; idx += 256) {
+    const int r = idx / DECV_MAXCH, ck = idx % DECV_MAXCH, m = mbase + r;
+    if (m < p.nr) {
+      const int b = p.row_seq ? p.row_seq[p.row0 + m] : (p.row0 + m) / p.Ld;
+      const int L = p.seq_off[b + 1] - p.seq_off[b];
+      const int nv = min(p.nch, (L + 63) >> 6);
+      if (ck < nv) {
+        const float2 ms = *(const float2*)(p.stat + (((size_t)m * p.nch + ck) * p.H + h) * 2);
+        sWt[r * DECV_MAXCH + ck] = ms.x; sSm[r * DECV_MAXCH + ck] = ms.y;
+      }
+      if (ck == 0) sNv[r] = nv;
+    } else if (ck == 0) sNv[r] = 0;
+  }
+  __syncthreads();
+  if (tid < p.R) {
+    const int nv = sNv[tid];
+    float* w = sWt + tid * DECV_MAXCH;
+    const float* sm = sSm + tid * DECV_MAXCH;
+    float gmax = -1e30f;
+    for (int ck = 0; ck < nv; ++ck) gmax = fmaxf(gmax, w[ck]);
+    float den = 0.f;
+    for (int ck = 0; ck < nv; ++ck) den += __expf(w[ck] - gmax) * sm[ck];
+    for (int ck = 0; ck < nv; ++ck) w[ck] = __expf(w[ck] - gmax);
+    sInv[tid] = nv > 0 ? 1.0f / den : 0.f;
+  }
+  __syncthreads();
+  // ---- merged, normalised sums of the raw encoder rows -> fp16 rows in LDS: wave w takes rows w, w + 4, ...; a lane owns
+  //      columns 4 lane + 256 i (whole 1-KiB pieces per load instruction) ----
+  const int npc = (p.d + 255) >> 8;                                 // 256-column pieces (<= 8: d <= 2048 per pass of 8)
+  for (int r = wave; r < p.R; r += 4) {
+    const int m = mbase + r;
+    if (m >= p.nr) continue;                                        // (rows beyond the pass: their MFMA columns are never stored)
+    const int nv = sNv[r];
+    const float* w = sWt + r * DECV_MAXCH;
+    const float inv = sInv[r];
+    const float* prow = p.part + (((size_t)m * p.nch) * p.H + h) * p.d + 4 * lane;
+    const size_t cstride = (size_t)p.H * p.d;
+    for (int c0 = 0; c0 < npc; c0 += 4) {                           // four pieces (1024 columns) per sweep over the chunks
+      f32x4 acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int ck = 0; ck < nv; ++ck) {
+        const float wk = w[ck];
+        f32x4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int col = (c0 + i) * 256 + 4 * lane;
+          v[i] = col < p.d ? *(const f32x4*)(prow + ck * cstride + (c0 + i) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][0] += wk * v[i][0]; acc[i][1] += wk * v[i][1]; acc[i][2] += wk * v[i][2]; acc[i][3] += wk * v[i][3]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = (c0 + i) * 256 + 4 * lane;
+        if (col < p.d) {
+          const half4 o = {f2h_sat(acc[i][0] * inv), f2h_sat(acc[i][1] * inv), f2h_sat(acc[i][2] * inv), f2h_sat(acc[i][3] * inv)};
+          *(half4*)(sWS + r * wstr + col) = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- ctx_h [32 rows x 64] = W_v,h (.) : K = d in four contiguous quarters, one per wave; fixed-order LDS tree ----
+  const int kq = p.d >> 2;
+  f32x16 a0, a1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+  {
+    const half_t* xr = sWS + l31 * wstr + wave * kq + 8 * hh;       // (rows >= R hold stale LDS: only their own, unstored, columns see it)
+    const half_t* w0 = p.wv + (size_t)(h * 64 + l31) * p.d + wave * kq + 8 * hh;
+    dec_mfma_krange(w0, w0 + (size_t)32 * p.d, xr, kq, a0, a1);
+  }
+  __syncthreads();                                                  // every wave has read its sWS fragments: the tree may overwrite them
+  dec_tree_reduce2(a0, a1, red, wave, lane);
+  if (wave == 0 && l31 < p.R && mbase + l31 < p.nr) {
+    half_t* orow = p.out + (size_t)(mbase + l31) * p.ldo + h * 64;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const half4 o0 = {f2h_sat(a0[4 * q]), f2h_sat(a0[4 * q + 1]), f2h_sat(a0[4 * q + 2]), f2h_sat(a0[4 * q + 3])};
+      const half4 o1 = {f2h_sat(a1[4 * q]), f2h_sat(a1[4 * q + 1]), f2h_sat(a1[4 * q + 2]), f2h_sat(a1[4 * q + 3])};
+      *(half4*)(orow + 8 * q + 4 * hh) = o0;
+      *(half4*)(orow + 32 + 8 * q + 4 * hh) = o1;
+    }
+  }
+}

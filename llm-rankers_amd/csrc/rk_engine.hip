@@ -22,6 +22,7 @@
 
 #include "../../include/rk_engine.h"
 #include "attention.h"
+#include "decoder_kernels.h"
 #include "gemm.h"
 #include "llama_kernels.h"
 #include "misc_kernels.h"
@@ -106,7 +107,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1;
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
@@ -664,11 +665,13 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
       gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.o, I, sl.dhidden, dm, M, dm, I, 0, 0, 1.f, 1, 0, 0, 0, ws, dfold ? with_prod(GemmFold()) : GemmFold());
       if (dfold) flip();
     }
-    if (dfold) {
-      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxraw[cur], dm, w.cq_f, dm, sl.dq, I, M, I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws, cons());
-    } else {
-      rmsnorm(e, st, sl.dhidden, w.ln1, sl.dxn, nullptr, M);
-      gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.cq, dm, sl.dq, I, M, I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
+    // Query-side cross-attention with the projections around it fused per (head, row slab) - decoder_kernels.h: the q
+    // projection + W_k^T q in one launch, the chunk merge + W_v in another (dec_fuse = 1, the default): 3 launches instead of 5
+    const bool fuse = e->opt_dec_fuse && !sl.have_cross_kv;
+    if (!dfold) rmsnorm(e, st, sl.dhidden, w.ln1, sl.dxn, nullptr, M);
+    if (!fuse) {
+      if (dfold) gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxraw[cur], dm, w.cq_f, dm, sl.dq, I, M, I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws, cons());
+      else gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxn, dm, w.cq, dm, sl.dq, I, M, I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws);
     }
     if (!sl.have_cross_kv) {
       // query-side cross-attention: qk = W_k^T q per head; scores/softmax/weighted sum over the raw encoder states;
@@ -678,8 +681,17 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
       const half_t* wv = e->cross_kv_w + ((size_t)l * 2 * I + I) * dm;
       for (int r0 = 0; r0 < M; r0 += blk) {
         const int nr = std::min(blk, M - r0);
-        gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dq + (size_t)r0 * I, I, w.ckT, 64, sl.xqk, H * dm, nr, dm, 64, 0, 0, 1.f, H, 64, (long)dm * 64, dm);
+        if (fuse) {
+          const GemmFold cf = dfold ? cons() : GemmFold();
+          DecQKArgs qa{(dfold ? sl.dxraw[cur] : sl.dxn) + (size_t)r0 * dm, dm, dfold ? w.cq_f : w.cq, w.ckT, sl.xqk, nr, dm, H,
+                       cf.rowscale ? cf.rowscale + r0 : nullptr, cf.ssq_in ? cf.ssq_in + (size_t)r0 * cf.nb_in : nullptr, cf.nb_in, d.eps, RK_XRAW_SCALE};
+          Bracket br(e, st, PC_DEC_GEMM, 2.0 * nr * (double)dm * I * 2, 2.0 * ((double)I * dm * 2 + (double)nr * H * dm));
+          hipLaunchKernelGGL(dec_cross_qk_kernel, dim3(H, (nr + 31) / 32), dim3(256), 0, st, qa);
+        } else {
+          gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dq + (size_t)r0 * I, I, w.ckT, 64, sl.xqk, H * dm, nr, dm, 64, 0, 0, 1.f, H, 64, (long)dm * 64, dm);
+        }
         XAttnArgs xa{sl.xqk, sl.enc_out, sl.d_seq_off, sl.xpart, sl.xstat, sl.xctx, Ld, H, dm, nch, r0, tree ? tree->seq : nullptr};
+        const bool fuse_cv = fuse && nch <= DECV_MAXCH;
         {
           Bracket br(e, st, PC_DEC_ATTN, 4.0 * nr * (double)sl.maxL * H * dm, (double)sl.T * dm * 2.0 * 2);
           // MFMA form (weighted sums on the matrix cores, the chunk's encoder rows staged in LDS by a loader wave) whenever
@@ -691,9 +703,21 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
             hipLaunchKernelGGL(xattn_part_kernel<16>, dim3(nch, nr, (H + 15) / 16), dim3(256), 0, st, xa);
           else
             hipLaunchKernelGGL(xattn_part_kernel<4>, dim3(nch, nr, (H + 3) / 4), dim3(256), 0, st, xa);
-          hipLaunchKernelGGL(xattn_combine_kernel, dim3(H, nr), dim3(256), 0, st, xa);
+          if (!fuse_cv) hipLaunchKernelGGL(xattn_combine_kernel, dim3(H, nr), dim3(256), 0, st, xa);
         }
-        gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.xctx, H * dm, wv, dm, sl.dctx + (size_t)r0 * I, I, nr, 64, dm, 0, 0, 1.f, H, dm, (long)64 * dm, 64);
+        if (fuse_cv) {
+          // rows per workgroup: the largest slab that still gives about half the chip a workgroup (results do not depend on it)
+          int R = 32;
+          while (R > 4 && (long)((nr + R - 1) / R) * H < e->n_cu / 2) R >>= 1;
+          DecCVArgs ca{sl.xpart, sl.xstat, sl.d_seq_off, tree ? tree->seq : nullptr, Ld, r0, wv, sl.dctx + (size_t)r0 * I, nr, dm, H, nch, I, R};
+          const size_t lds = dec_cv_lds_bytes(dm);
+          static std::atomic<uint64_t> attr_done{0};
+          ensure_dynamic_lds((const void*)dec_cross_cv_kernel, 160 * 1024, attr_done);
+          Bracket br(e, st, PC_DEC_GEMM, 2.0 * nr * (double)dm * I, 2.0 * (double)I * dm + 4.0 * (double)nr * nch * H * dm);
+          hipLaunchKernelGGL(dec_cross_cv_kernel, dim3(H, (nr + R - 1) / R), dim3(256), lds, st, ca);
+        } else {
+          gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.xctx, H * dm, wv, dm, sl.dctx + (size_t)r0 * I, I, nr, 64, dm, 0, 0, 1.f, H, dm, (long)64 * dm, 64);
+        }
       }
     } else {
       const half_t* kv = sl.cross_kv + (size_t)l * d.max_tokens * 2 * I;
@@ -2043,6 +2067,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
   if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 5 (any non-zero value but 6) DMA kernel, two groups per workgroup; 6 one group; 0 tiled kernel
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
+  if (!strcmp(key, "dec_fuse")) { e->opt_dec_fuse = value != 0; return RK_OK; }   // few-row decoder: projections around the query-side cross-attention fused per (head, row slab) (1) or separate GEMMs (0)
   if (!strcmp(key, "gemm_split")) { e->opt_gemm_split = value != 0; return RK_OK; }   // rows beyond the ping-pong kernel's last whole round on a fill-in tile variant (1) or one launch (0)
   if (!strcmp(key, "gemm_group_n")) { e->opt_gemm_group_n = value; return RK_OK; }   // ping-pong GEMM: column-panel width of the tile order in tiles (0 = default 8)
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream

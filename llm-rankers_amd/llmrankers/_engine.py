@@ -318,7 +318,7 @@ class RkEngine:
 
     def comm_destroy(self):
         self._chk(self.lib.rk_comm_destroy(self.h))
-        self.comm_world = 1
+        self.comm_rank, self.comm_world, self.comm_capacity = 0, 1, 0
 
     # -- measurement -------------------------------------------------------------------------------------
     def timer_begin(self):

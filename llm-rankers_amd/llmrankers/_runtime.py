@@ -154,7 +154,12 @@ class T5Runtime:
     COMM_FLOATS_PER_RANK = 65536      # send-buffer capacity (256 KB per rank): hits / world x outputs per passage
 
     def comm_ready(self) -> bool:
-        return getattr(self.engine, "comm_world", 1) > 1
+        """an engine communicator exists (any world size: one rank gathers with itself over the same calls)"""
+        return self.comm_capacity > 0
+
+    def comm_rank_world(self):
+        """(rank, world) of the engine communicator"""
+        return int(getattr(self.engine, "comm_rank", 0)), int(getattr(self.engine, "comm_world", 1))
 
     def comm_init_from_process_group(self, max_floats_per_rank: int = 0):
         """One process per GPU under torchrun: take rank / world from the initialised torch.distributed group, use it

@@ -131,6 +131,8 @@ class PointwiseLlmRanker(LlmRanker):
         ref: llmrankers/pointwise.py:20-24."""
         from . import _dist
         rank, ws = _dist.world()
+        if ws == 1 and getattr(self.llm, "comm_ready", lambda: False)():
+            rank, ws = self.llm.comm_rank_world()               # a communicator built without a torch process group
         bounds = _dist.shard_bounds(len(ranking), ws)
         s, e = bounds[rank]
         width = max(b - a for a, b in bounds)
@@ -169,7 +171,9 @@ class PointwiseLlmRanker(LlmRanker):
     def rerank(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
         if self.shard_candidates:
             from . import _dist
-            if _dist.world()[1] > 1:
+            # more than one rank - or an engine communicator that already exists (a one-rank communicator walks the same
+            # append / gather path: that is how the GPU tests reach it on a one-GPU box)
+            if _dist.world()[1] > 1 or getattr(self.llm, "comm_ready", lambda: False)():
                 return self._rerank_sharded(query, ranking)
         self._reset()
         spec = self._spec(query, ranking)

@@ -231,6 +231,40 @@ def test_config1_flan_t5_small_vs_hf_golden():
     eng.close()
 
 
+def test_fused_decoder_projections_match_the_separate_gemms():
+    """decoder_kernels.h (round 4): the q projection + W_k^T q, and the chunk merge + W_v projection, each fused per (head,
+    row slab) on the matrix cores (engine option dec_fuse, default on) against the five-launch form they replace: same
+    rounding points, another fp32 summation order over K -> logits equal to a few fp16 ulps of the stream, yes/no
+    probabilities within a tenth of the score tolerance, greedy tokens identical; and the fused path against the oracle.
+    Shapes: toy (d = 128: partial 256-column pieces, two k16 steps per wave), flan-t5-small dims (6 heads, d = 512) and
+    flan-t5-large dims; one and three decoder positions, the tree form of rk_t5_greedy2, ragged rows (1 .. 4 key chunks)."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle
+    for dims, n, lo, hi in ((_synth.TOY_GATED_UNTIED, 37, 3, 250), (_synth.FLAN_T5_SMALL, 40, 20, 184), (_synth.FLAN_T5_LARGE, 70, 60, 184)):
+        state = _synth.synth_state_dict(dims, seed=5, gain=1.0, threads=16)
+        eng = _engine(dims, state, max_tokens=16384, max_seqs=80, max_dec_len=8)
+        seqs = _synth.synth_token_batch(n, lo, hi, dims.vocab, seed=77)
+        ids = [21 % dims.vocab, 22 % dims.vocab, 50 % dims.vocab]
+        outs = {}
+        for fuse in (1, 0):
+            eng.set_option("dec_fuse", fuse)
+            outs[fuse] = (eng.score(seqs, [0], ids), eng.score(seqs[:9], [0, 7, 9], ids),
+                          eng.greedy(seqs[:5], [0, 7], 2, 1, 0, candidates=ids)[0], eng.greedy(seqs[:5], [0, 7], 2, 1, 0)[0])
+        eng.set_option("dec_fuse", 1)
+        for a, b in zip(outs[1][:2], outs[0][:2]):
+            scale = float(np.abs(b).max())
+            assert np.abs(a - b).max() < 4e-3 * max(scale, 1.0), (dims.d_model, np.abs(a - b).max(), scale)
+            assert np.abs(_sigm(a[:, 0] - a[:, 1]) - _sigm(b[:, 0] - b[:, 1])).max() < 0.1 * SCORE_TOL
+        np.testing.assert_array_equal(outs[1][2], outs[1][3])            # speculative two-token pass == two steps (fused path)
+        # batch independence of the fused path across the rows-per-workgroup choices (70 / 9 / 1 rows pick different slabs)
+        np.testing.assert_array_equal(eng.score(seqs[3:4], [0], ids)[0], outs[1][0][3])
+        np.testing.assert_array_equal(eng.score(seqs[:9], [0], ids), outs[1][0][:9])
+        if dims.d_model <= 512:
+            want = T5Oracle(dims, state).score_last(seqs[:6], [0, 7, 9], ids)
+            assert np.abs(outs[1][1][:6] - want).max() < LOGIT_TOL, np.abs(outs[1][1][:6] - want).max()
+        eng.close()
+
+
 def test_flan_t5_large_dims_vs_oracle_and_properties():
     """BASELINE.json configs[1] model shape: a few sequences vs the fp32 oracle, then size-independent
     properties on the full B=32 x L=184 batch (batch independence, permutation equivariance)."""
@@ -927,10 +961,17 @@ def test_llama3_rope_scaling_on_the_engine_vs_hf_golden():
 
 
 def test_llama_3_8b_full_depth_vs_oracle_golden():
-    """BASELINE.json configs[4] at FULL depth: Llama-3-8B dimensions, all 32 layers, one 700-token setwise-sized prompt; the
-    label logits and the greedy token against the fp32 oracle's (tests/golden/llama8b_full_depth.json, generated once by
-    tools/make_llama8b_golden.py - 32 GB of fp32 weights do not fit a test run on the host).  The 8 G synthetic weights are
-    regenerated here from their counters and streamed into the engine."""
+    """BASELINE.json configs[4] at FULL depth: Llama-3-8B dimensions, all 32 layers.  (1) one 700-token setwise-sized prompt:
+    the label logits and the greedy token against the fp32 oracle's (tests/golden/llama8b_full_depth.json, generated once by
+    tools/make_llama8b_golden.py - 32 GB of fp32 weights do not fit a test run on the host).  (2) the whole setwise heapsort
+    query of tests/golden/llama_setwise_query.json (hits=100, num_child=10, k=10, generation; its oracle run exists at two
+    layers only, test_gpu_rerank.py) through SetwiseLlmRanker at the full depth, for its properties: the run is
+    deterministic, the level-batched driver and four queries in lockstep (rerank_many) give the one-by-one rankings and
+    counters (batch independence), the counters add up, and generations are labels.  The 8 G synthetic weights are
+    regenerated here from their counters and streamed into the engine; the lm_head rows of the 23 label tokens are boosted
+    (x6, like the fixture checkpoints) so that greedy tokens are labels - part (1) therefore reads the golden's un-boosted
+    rows, and checks the fused arg-max head against the logits of the boosted rows and the golden's top token."""
+    import contextlib, io
     from llmrankers import _synth
     from llmrankers._engine import RkLlamaEngine
     path = os.path.join(GOLD, "llama8b_full_depth.json")
@@ -938,20 +979,81 @@ def test_llama_3_8b_full_depth_vs_oracle_golden():
         pytest.skip("golden not generated")
     with open(path) as f:
         gold = json.load(f)
+    qpath = os.path.join(GOLD, "llama_setwise_query.json")
+    qgold = json.load(open(qpath)) if os.path.exists(qpath) else None
+    boost_ids = list(qgold["boost_ids"]) if qgold else []
+    boost = float(qgold["boost"]) if qgold else 1.0
     dims = _synth.NAMED_DIMS[gold["dims"]]
-    eng = RkLlamaEngine(dims, device=0, max_tokens=2048, max_seqs=4)
-    eng.load_state(_synth.synth_tensors(dims, seed=gold["seed"], threads=min(48, os.cpu_count() or 8)))
+
+    def tensors():
+        for name, arr in _synth.synth_tensors(dims, seed=gold["seed"], threads=min(48, os.cpu_count() or 8)):
+            if name == "lm_head.weight" and boost_ids:
+                arr = np.array(arr, dtype=np.float32, copy=True)
+                rows = np.asarray(boost_ids, dtype=np.int64)
+                arr[rows] = (arr[rows] * np.float32(boost)).astype(np.float16).astype(np.float32)
+            yield name, arr
+    eng = RkLlamaEngine(dims, device=0, max_tokens=16384, max_seqs=16)
+    eng.load_state(tensors())
     ids = _synth.synth_token_batch(1, gold["prompt_len"], gold["prompt_len"], dims.vocab, seed=gold["prompt_seed"])
-    got = eng.last_logits(ids, gold["label_ids"])[0]
-    want = np.asarray(gold["label_logits"], dtype=np.float32)
+    keep = [k for k, t in enumerate(gold["label_ids"]) if t not in boost_ids]
+    got = eng.last_logits(ids, [gold["label_ids"][k] for k in keep])[0]
+    want = np.asarray(gold["label_logits"], dtype=np.float32)[keep]
     scale = gold["logit_abs_max"]
     err = float(np.abs(got - want).max())
     print(f"[llama8b full depth] max |label logit - oracle| = {err:.4f} at logit scale {scale:.3f}")
     assert err < 4e-3 * scale, (err, scale)            # measured 6e-4 of the scale: 32 layers of fp16 operands, fp32 stream
     top = eng.last_logits(ids, gold["top_ids"])[0]
     assert np.abs(top - np.asarray(gold["top_logits"], dtype=np.float32)).max() < 4e-3 * scale
-    if gold["top_logits"][0] - gold["top_logits"][1] > 4e-2 * scale:
-        assert int(eng.greedy1(ids)[0]) == gold["top_ids"][0]
+    # fused arg-max head: the greedy token is the best of (the golden's top token, the boosted label rows)
+    cand = [gold["top_ids"][0]] + boost_ids
+    cl = eng.last_logits(ids, cand)[0]
+    best2 = np.sort(cl)[-2:]
+    if (not boost_ids and gold["top_logits"][0] - gold["top_logits"][1] > 4e-2 * scale) or (boost_ids and best2[1] - best2[0] > 4e-2 * scale):
+        assert int(eng.greedy1(ids)[0]) == cand[int(np.argmax(cl))]
+    if qgold:
+        from transformers import AutoTokenizer
+        from llmrankers._runtime import LlamaRuntime
+        from llmrankers.rankers import SearchResult
+        from llmrankers.setwise import SetwiseLlmRanker
+        rt = LlamaRuntime.from_engine(eng, dims)
+        tok = AutoTokenizer.from_pretrained(os.path.join(GOLD, "tok_llama"))
+
+        def fresh():
+            return [SearchResult(docid=f"d{i}", score=float(100 - i), text=t) for i, t in enumerate(qgold["docs"])]
+
+        def run(batched):
+            rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring="generation", method="heapsort")
+            rk.batch_independent_compares = batched
+            lens = []
+            orig = rt.greedy1
+            rt.greedy1 = lambda seqs: (lens.extend(len(s_) for s_ in seqs), orig(seqs))[1]
+            sink = io.StringIO()
+            try:
+                with contextlib.redirect_stdout(sink):
+                    res = rk.rerank(qgold["query"], fresh())
+            finally:
+                rt.greedy1 = orig
+            return rk, [[r.docid, r.score] for r in res], lens, sink.getvalue().count("Unexpected output")
+        rk_a, res_a, lens_a, bad_a = run(False)
+        rk_b, res_b, lens_b, _ = run(False)
+        assert res_a == res_b and lens_a == lens_b                                   # deterministic
+        assert len(res_a) == 100 and sorted(d for d, _ in res_a) == sorted(f"d{i}" for i in range(100))
+        assert rk_a.total_compare == len(lens_a) and rk_a.total_prompt_tokens == sum(lens_a)
+        assert rk_a.total_completion_tokens == sum(lens_a) + len(lens_a)             # prompt + one new token per compare
+        assert bad_a <= 0.1 * len(lens_a), bad_a                                     # generations are labels (boosted rows)
+        rk_c, res_c, lens_c, _ = run(True)                                           # level-batched build phase
+        assert res_c == res_a and sorted(lens_c) == sorted(lens_a)
+        assert (rk_c.total_compare, rk_c.total_prompt_tokens, rk_c.total_completion_tokens) == \
+               (rk_a.total_compare, rk_a.total_prompt_tokens, rk_a.total_completion_tokens)
+        rk_m = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring="generation", method="heapsort")
+        q2 = qgold["query"].split()
+        queries = [qgold["query"], " ".join(reversed(q2)), " ".join(q2[1:] + q2[:1]), qgold["query"]]
+        with contextlib.redirect_stdout(io.StringIO()):
+            many, counters = rk_m.rerank_many([(q, fresh()) for q in queries])       # four heapsorts in lockstep
+        assert [[r.docid, r.score] for r in many[0]] == res_a and [[r.docid, r.score] for r in many[3]] == res_a
+        assert tuple(counters[0]) == (rk_a.total_compare, rk_a.total_prompt_tokens, rk_a.total_completion_tokens)
+        print(f"[llama8b full depth] setwise query: {rk_a.total_compare} compares, {rk_a.total_prompt_tokens} prompt tokens, "
+              f"{bad_a} non-label generations; top-10 {[d for d, _ in res_a[:10]]}")
     eng.close()
 
 

@@ -247,6 +247,122 @@ def test_config3_full_size_setwise_query_flan_t5_large():
     eng.close()
 
 
+def test_config4_flan_t5_xl_qlm_full_query_through_the_sharded_ranker():
+    """BASELINE.json configs[3] at full size THROUGH THE RANKER: flan-t5-xl dimensions, pointwise qlm, ONE query of hits=100
+    (ref: llmrankers/pointwise.py:41-82) run by PointwiseLlmRanker(shard_candidates=True) on the HIP engine with a one-rank
+    RCCL communicator - the candidate-sharding path of DESIGN.md section 6: the share takes three engine calls (max_seqs = 40),
+    each appended to the send buffer on the device, token counts appended from the host, ONE gather - against
+    tests/golden/xl_qlm_query.json (the same ranker on the fp32 oracle, tools/make_xl_qlm_golden.py).  Scores within the qlm
+    tolerance, the same order wherever the oracle's scores differ by more than twice that tolerance, identical counters.
+    The measured error is printed: a qlm score is a SUM of ~15-33 log-probabilities of magnitude ~10 each (here |score| ~
+    150-350), so BASELINE.md section 2's 1e-3 reads as a RELATIVE bound for it."""
+    from transformers import T5Tokenizer
+    from llmrankers import _synth
+    from llmrankers._engine import RkEngine
+    from llmrankers._runtime import T5Runtime
+    from llmrankers.pointwise import PointwiseLlmRanker
+    from llmrankers.rankers import SearchResult
+    path = os.path.join(GOLD, "xl_qlm_query.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/xl_qlm_query.json not generated yet (tools/make_xl_qlm_golden.py)")
+    with open(path) as f:
+        gold = json.load(f)
+    dims = _synth.NAMED_DIMS[gold["dims"]]
+    state = _synth.synth_state_dict(dims, seed=gold["weight_seed"], threads=min(32, os.cpu_count() or 8))
+    eng = RkEngine(dims, 0, max_tokens=8192, max_seqs=40, max_dec_len=40).load_state(state.items())
+    del state
+    try:
+        rt = T5Runtime.from_engine(eng, dims)
+        eng.comm_init(eng.comm_unique_id(), 0, 1, 1024)                     # one-rank communicator: same calls as N ranks
+        tok = T5Tokenizer.from_pretrained(os.path.join(GOLD, "tok"))
+        rk = PointwiseLlmRanker.from_runtime(rt, tok, method="qlm", batch_size=gold["batch_size"], shard_candidates=True)
+        n = len(gold["docs"])
+        ranking = [SearchResult(docid=f"d{i}", score=float(n - i), text=t) for i, t in enumerate(gold["docs"])]
+        res = rk.rerank(gold["query"], ranking)
+        got = np.array([d.score for d in ranking])                           # scored in place, passage order
+        want = np.array(gold["scores"])
+        err = np.abs(got - want)
+        rel = float(err.max() / np.abs(want).max())
+        print(f"[xl qlm query] {n} passages, |score| up to {np.abs(want).max():.1f}: max abs error {err.max():.4f}, relative {rel:.2e}")
+        assert rel < 2e-4, (err.max(), rel)                    # measured 6.4e-5 (max abs 0.011 at |score| 166)
+        tol = 2e-4 * float(np.abs(want).max())
+        order = {d.docid: i for i, d in enumerate(res)}
+        for i in range(n):
+            for j in range(n):
+                if want[i] - want[j] > 2 * tol:
+                    assert order[f"d{i}"] < order[f"d{j}"], (i, j, want[i], want[j], got[i], got[j])
+        assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == gold["counters"]
+        # the same query without sharding: the same bits (batch independence across the two call patterns)
+        rk1 = PointwiseLlmRanker.from_runtime(rt, tok, method="qlm", batch_size=gold["batch_size"])
+        ranking1 = [SearchResult(docid=f"d{i}", score=float(n - i), text=t) for i, t in enumerate(gold["docs"])]
+        res1 = rk1.rerank(gold["query"], ranking1)
+        assert [d.docid for d in res1] == [d.docid for d in res] and [d.score for d in ranking1] == [d.score for d in ranking]
+        assert [rk1.total_compare, rk1.total_prompt_tokens, rk1.total_completion_tokens] == gold["counters"]
+    finally:
+        eng.comm_destroy()
+        eng.close()
+
+
+def test_config5_llama_8b_widths_setwise_query_vs_oracle_golden():
+    """BASELINE.json configs[4] call shape through the ranker: ONE setwise heapsort query (hits=100, num_child=10, k=10,
+    generation) with Llama-3-8B widths and two layers (the depth the oracle affords for ~50 compares) through SetwiseLlmRanker
+    on the HIP engine (chat template + " Passage:", prefill, one greedy token; ref: llmrankers/setwise.py:159-177) against
+    tests/golden/llama_setwise_query.json: the recorded compare sequence (greedy tokens), ranking, caller-list order and
+    counters - demanded exactly when the smallest recorded margin is above the fp16 noise floor of this model scale, and
+    compare by compare up to the first decision below the floor otherwise.  The full 32-layer depth of the same query is run
+    for its properties in test_gpu_kernels.py::test_llama_3_8b_full_depth_vs_oracle_golden."""
+    from transformers import AutoTokenizer
+    from llmrankers import _synth
+    from llmrankers._engine import RkLlamaEngine
+    from llmrankers._runtime import LlamaRuntime
+    from llmrankers.rankers import SearchResult
+    from llmrankers.setwise import SetwiseLlmRanker
+    path = os.path.join(GOLD, "llama_setwise_query.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/llama_setwise_query.json not generated yet (tools/make_llama_setwise_golden.py)")
+    with open(path) as f:
+        gold = json.load(f)
+    dims = _synth.LlamaDims(vocab=128256, hidden=4096, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336,
+                            n_layers=gold["n_layers"], bos_token_id=128000, eos_token_id=128001)
+    state = _synth.synth_state_dict(dims, seed=gold["weight_seed"], threads=min(32, os.cpu_count() or 8))
+    head = state["lm_head.weight"].copy()
+    ids = np.asarray(gold["boost_ids"], dtype=np.int64)
+    head[ids] = (head[ids] * np.float32(gold["boost"])).astype(np.float16).astype(np.float32)
+    state["lm_head.weight"] = head
+    eng = RkLlamaEngine(dims, device=0, max_tokens=16384, max_seqs=16).load_state(state.items())
+    del state, head
+    try:
+        rt = LlamaRuntime.from_engine(eng, dims)
+        seen = []
+        orig = rt.greedy1
+        rt.greedy1 = lambda seqs: (lambda out: (seen.extend(int(t) for t in out), out)[1])(orig(seqs))
+        tok = AutoTokenizer.from_pretrained(os.path.join(GOLD, "tok_llama"))
+        rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring="generation", method="heapsort")
+        rk.batch_independent_compares = False                    # the recorded one-by-one compare order
+        ranking = [SearchResult(docid=f"d{i}", score=float(100 - i), text=t) for i, t in enumerate(gold["docs"])]
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = rk.rerank(gold["query"], ranking)
+        recs = gold["compares"]
+        # noise floor: the engine's logits are within 4e-3 of the logit scale of the oracle's at these widths (test_gpu_kernels)
+        floor = 8e-3 * max(r["logit_abs_max"] for r in recs)
+        first_low = next((i for i, r in enumerate(recs) if r["margin"] <= floor), len(recs))
+        assert first_low >= 0.5 * len(recs), (first_low, len(recs), floor)
+        assert seen[:first_low] == [r["token"] for r in recs[:first_low]]
+        if first_low == len(recs):
+            assert [[r.docid, r.score] for r in res] == gold["ranking"]
+            assert [d.docid for d in ranking] == gold["caller_list_after"]
+            assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == gold["counters"]
+        # the shipped, level-batched driver: same ranking and counters as one compare at a time on the engine
+        rk2 = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring="generation", method="heapsort")
+        ranking2 = [SearchResult(docid=f"d{i}", score=float(100 - i), text=t) for i, t in enumerate(gold["docs"])]
+        with contextlib.redirect_stdout(io.StringIO()):
+            res2 = rk2.rerank(gold["query"], ranking2)
+        assert [[r.docid, r.score] for r in res2] == [[r.docid, r.score] for r in res]
+        assert (rk2.total_compare, rk2.total_prompt_tokens, rk2.total_completion_tokens) == (rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens)
+    finally:
+        eng.close()
+
+
 def test_rerank_many_equals_one_query_at_a_time_on_the_engine(cases, stack):
     """rerank_many on the HIP engine: the recorded reference cases of one checkpoint handed over together - pointwise: all
     batches in one launch sequence; setwise heapsort and bubblesort: the queries' sort chains in lockstep, one engine call
