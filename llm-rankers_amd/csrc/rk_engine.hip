@@ -107,7 +107,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0;
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
@@ -667,7 +667,7 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
     }
     // Query-side cross-attention with the projections around it fused per (head, row slab) - decoder_kernels.h: the q
     // projection + W_k^T q in one launch, the chunk merge + W_v in another (dec_fuse = 1, the default): 3 launches instead of 5
-    const bool fuse = e->opt_dec_fuse && !sl.have_cross_kv;
+    const bool fuse = e->opt_dec_fuse && !sl.have_cross_kv && dm % 128 == 0;   // (eight K ranges of whole k16 steps per workgroup)
     if (!dfold) rmsnorm(e, st, sl.dhidden, w.ln1, sl.dxn, nullptr, M);
     if (!fuse) {
       if (dfold) gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxraw[cur], dm, w.cq_f, dm, sl.dq, I, M, I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws, cons());
@@ -684,9 +684,11 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
         if (fuse) {
           const GemmFold cf = dfold ? cons() : GemmFold();
           DecQKArgs qa{(dfold ? sl.dxraw[cur] : sl.dxn) + (size_t)r0 * dm, dm, dfold ? w.cq_f : w.cq, w.ckT, sl.xqk, nr, dm, H,
-                       cf.rowscale ? cf.rowscale + r0 : nullptr, cf.ssq_in ? cf.ssq_in + (size_t)r0 * cf.nb_in : nullptr, cf.nb_in, d.eps, RK_XRAW_SCALE};
+                       cf.rowscale ? cf.rowscale + r0 : nullptr, cf.ssq_in ? cf.ssq_in + (size_t)r0 * cf.nb_in : nullptr, cf.nb_in, d.eps, RK_XRAW_SCALE, 32};
+          if (e->opt_dec_fuse_rows > 0) qa.R = std::min(32, e->opt_dec_fuse_rows);
+          else if (nr <= 16) qa.R = 16;   // (a setwise pass: 13 rows - half the MFMA columns, half the x rows; measured at 320 rows: 32 > 16 > 8)
           Bracket br(e, st, PC_DEC_GEMM, 2.0 * nr * (double)dm * I * 2, 2.0 * ((double)I * dm * 2 + (double)nr * H * dm));
-          hipLaunchKernelGGL(dec_cross_qk_kernel, dim3(H, (nr + 31) / 32), dim3(256), 0, st, qa);
+          hipLaunchKernelGGL(dec_cross_qk_kernel, dim3(H, (nr + qa.R - 1) / qa.R), dim3(64 * DEC_NW), 0, st, qa);
         } else {
           gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dq + (size_t)r0 * I, I, w.ckT, 64, sl.xqk, H * dm, nr, dm, 64, 0, 0, 1.f, H, 64, (long)dm * 64, dm);
         }
@@ -707,14 +709,15 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
         }
         if (fuse_cv) {
           // rows per workgroup: the largest slab that still gives about half the chip a workgroup (results do not depend on it)
-          int R = 32;
+          // (16 rows: 41 KiB of LDS at d = 1024, three workgroups per CU hide each other's load latency)
+          int R = 16;
           while (R > 4 && (long)((nr + R - 1) / R) * H < e->n_cu / 2) R >>= 1;
           DecCVArgs ca{sl.xpart, sl.xstat, sl.d_seq_off, tree ? tree->seq : nullptr, Ld, r0, wv, sl.dctx + (size_t)r0 * I, nr, dm, H, nch, I, R};
-          const size_t lds = dec_cv_lds_bytes(dm);
+          const size_t lds = dec_cv_lds_bytes(dm, R);
           static std::atomic<uint64_t> attr_done{0};
           ensure_dynamic_lds((const void*)dec_cross_cv_kernel, 160 * 1024, attr_done);
           Bracket br(e, st, PC_DEC_GEMM, 2.0 * nr * (double)dm * I, 2.0 * (double)I * dm + 4.0 * (double)nr * nch * H * dm);
-          hipLaunchKernelGGL(dec_cross_cv_kernel, dim3(H, (nr + R - 1) / R), dim3(256), lds, st, ca);
+          hipLaunchKernelGGL(dec_cross_cv_kernel, dim3(H, (nr + R - 1) / R), dim3(64 * DEC_NW), lds, st, ca);
         } else {
           gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.xctx, H * dm, wv, dm, sl.dctx + (size_t)r0 * I, I, nr, 64, dm, 0, 0, 1.f, H, dm, (long)64 * dm, 64);
         }
@@ -2067,6 +2070,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
   if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 5 (any non-zero value but 6) DMA kernel, two groups per workgroup; 6 one group; 0 tiled kernel
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
+  if (!strcmp(key, "dec_fuse_rows")) { e->opt_dec_fuse_rows = value; return RK_OK; }   // rows per workgroup of dec_cross_qk_kernel (0 = auto; A/B)
   if (!strcmp(key, "dec_fuse")) { e->opt_dec_fuse = value != 0; return RK_OK; }   // few-row decoder: projections around the query-side cross-attention fused per (head, row slab) (1) or separate GEMMs (0)
   if (!strcmp(key, "gemm_split")) { e->opt_gemm_split = value != 0; return RK_OK; }   // rows beyond the ping-pong kernel's last whole round on a fill-in tile variant (1) or one launch (0)
   if (!strcmp(key, "gemm_group_n")) { e->opt_gemm_group_n = value; return RK_OK; }   // ping-pong GEMM: column-panel width of the tile order in tiles (0 = default 8)

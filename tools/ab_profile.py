@@ -68,7 +68,7 @@ def main():
     eng.close()
 
 
-DEFAULTS = {"dec_ffn_tiled": 1, "xattn_mfma": 1, "attn_short": 5, "attn_heads_per_wg": 0, "gemm_persistent": 1, "overlap": 1, "dec_graph": 1,
+DEFAULTS = {"dec_fuse": 1, "gemm_split": 1, "dec_ffn_tiled": 1, "xattn_mfma": 1, "attn_short": 5, "attn_heads_per_wg": 0, "gemm_persistent": 1, "overlap": 1, "dec_graph": 1,
             "fold_norm": 1, "dec_fold_norm": 1, "xattn_direct": 1, "gemm_variant": 0}
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@ def main():
     del state
     known = {"gemm_persistent": 1, "attn_short": 5, "gemm_variant": 0,
              "xattn_direct": 1, "overlap": 1, "gemm_glds": 1, "attn_heads_per_wg": 0, "fold_norm": 1, "dec_graph": 1, "attn_tiled_occ": 2,
-             "dec_fold_norm": 1, "gemm_s64_stages": 0, "attn_split": 1, "greedy_spec": 160, "gemm_split": 1, "gemm_group_n": 0,
+             "dec_fold_norm": 1, "gemm_s64_stages": 0, "attn_split": 1, "greedy_spec": 160, "gemm_split": 1, "gemm_group_n": 0, "dec_fuse": 1, "dec_fuse_rows": 0,
              "xattn_mfma": 1, "dec_ffn_tiled": 1, "consumer_stats": 1}
     defaults = {}
     for c in cfgs:
