@@ -26,6 +26,8 @@ struct DecQKArgs {
   const float* rowscale;         // row factors, or
   const float* ssq_in; int nb_in; float eps, xs;   // block sums of squares -> rk_row_factor; both null: factor 1
   int R;                         // decoder rows per workgroup (<= 32; results do not depend on it)
+  int CS;                        // workgroups per (head, slab): each recomputes q_h and takes 1 / CS of the output column pairs (few rows:
+                                 // more workgroups stream the weights; d / 64 must be a multiple of CS; results do not depend on it)
 };
 
 #define DEC_NW 8            // waves per workgroup of both kernels: K is split eight ways, the partial tiles meet in a fixed-order LDS tree
@@ -68,7 +70,7 @@ __device__ __forceinline__ void dec_mfma_krange(const half_t* w0, const half_t* 
 }
 
 #define DECQ_STR 72      // sQ row stride in halfs (144 B: rows start in different 16-byte slots)
-// grid = (H, ceil(M / R)); 512 threads.  d must be a multiple of 128 (eight K ranges of whole k16 steps).
+// grid = (H, ceil(M / R), CS); 512 threads.  d must be a multiple of 128 (eight K ranges of whole k16 steps).
 __global__ __launch_bounds__(64 * DEC_NW) void dec_cross_qk_kernel(DecQKArgs p) {
   __shared__ __attribute__((aligned(16))) float red[DEC_NW * 32 * DECQ_STR / 2];   // 36 KiB: the tree's 32 KiB, later eight 4.5-KiB output slabs
   __shared__ __attribute__((aligned(16))) half_t sQ[32 * DECQ_STR];
@@ -86,10 +88,12 @@ __global__ __launch_bounds__(64 * DEC_NW) void dec_cross_qk_kernel(DecQKArgs p) 
   // the W_k^T tiles of this wave's first two output tiles travel while the q projection is computed and reduced.  A wave
   // owns PAIRS of adjacent 32-column tiles (2 w, 2 w + 1), (2 w + 16, 2 w + 17), ...: 64 columns = one 128-byte line per row
   const int ntile = p.d >> 5;
+  const int ppw = (ntile >> 1) / p.CS;                              // column pairs of this workgroup: [pair0, pair0 + ppw)
+  const int pair0 = blockIdx.z * ppw;
   half8 wpre[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int t = min(2 * wave + i, ntile - 1);
+    const int t = min(2 * (pair0 + min(wave, ppw - 1)) + i, ntile - 1);
     const half_t* wr = p.wkT + ((size_t)h * p.d + t * 32 + l31) * 64 + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) wpre[i][ks] = *(const half8*)(wr + 16 * ks);
@@ -126,11 +130,12 @@ __global__ __launch_bounds__(64 * DEC_NW) void dec_cross_qk_kernel(DecQKArgs p) 
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8*)(sQ + l31 * DECQ_STR + 16 * ks + 8 * hh);
   half_t* stage = (half_t*)red + wave * (32 * DECQ_STR);            // 4.5 KiB per wave of the 32 KiB tree scratch
   const int prow = lane >> 3, pch = lane & 7;                       // write-back: 8 rows x 8 16-byte pieces per instruction
-  for (int t0 = 2 * wave; t0 < ntile; t0 += 2 * DEC_NW) {
+  for (int pr = wave; pr < ppw; pr += DEC_NW) {
+    const int t0 = 2 * (pair0 + pr);
     half8 wf[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (t0 == 2 * wave) {
+      if (pr == wave) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wf[i][ks] = wpre[i][ks];
       } else {
@@ -231,7 +236,15 @@ __global__ __launch_bounds__(64 * DEC_NW) void dec_cross_cv_kernel(DecCVArgs p) 
   //      columns 4 lane + 256 i (whole 1-KiB pieces per load instruction); four chunks x four pieces (16 loads) in flight,
   //      the last round of chunks predicated by a zero weight (clamped address), never serial ----
   const int npc = (p.d + 255) >> 8;                                 // 256-column pieces
-  for (int r = wave; r < p.R; r += DEC_NW) {
+  const int ngr = (npc + 3) >> 2;                                   // groups of four pieces (1024 columns)
+  // work items (row, piece group) dealt to the waves; few rows with many chunks (a setwise prompt: 23) split a row's
+  // columns over the waves as well: items (row, single piece)
+  const bool fine = p.R * ngr < DEC_NW;
+  const int nitem = fine ? p.R * npc : p.R * ngr;
+  for (int it = wave; it < nitem; it += DEC_NW) {
+    const int r = fine ? it / npc : it / ngr;
+    const int c0 = fine ? it % npc : 4 * (it % ngr);
+    const int cn = fine ? 1 : 4;                                    // pieces of this item
     const int m = mbase + r;
     if (m >= p.nr) continue;                                        // (rows beyond the pass: their MFMA columns are never stored)
     const int nv = sNv[r];
@@ -239,11 +252,11 @@ __global__ __launch_bounds__(64 * DEC_NW) void dec_cross_cv_kernel(DecCVArgs p) 
     const float inv = sInv[r];
     const float* prow = p.part + (((size_t)m * p.nch) * p.H + h) * p.d + 4 * lane;
     const size_t cstride = (size_t)p.H * p.d;
-    for (int c0 = 0; c0 < npc; c0 += 4) {                           // four pieces (1024 columns) per sweep over the chunks
-      f32x4 acc[4];
+    f32x4 acc[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int ck0 = 0; ck0 < nv; ck0 += 4) {
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!fine) {
+      for (int ck0 = 0; ck0 < nv; ck0 += 4) {                       // 4 chunks x 4 pieces = 16 loads in flight
         f32x4 v[4][4];
         float wk[4];
 #pragma unroll
@@ -259,15 +272,33 @@ __global__ __launch_bounds__(64 * DEC_NW) void dec_cross_cv_kernel(DecCVArgs p) 
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { acc[i][0] += wk[u] * v[u][i][0]; acc[i][1] += wk[u] * v[u][i][1]; acc[i][2] += wk[u] * v[u][i][2]; acc[i][3] += wk[u] * v[u][i][3]; }
-      }
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int col = (c0 + i) * 256 + 4 * lane;
-        if (col < p.d) {
-          const half4 o = {f2h_sat(acc[i][0] * inv), f2h_sat(acc[i][1] * inv), f2h_sat(acc[i][2] * inv), f2h_sat(acc[i][3] * inv)};
-          *(half4*)(sWS + r * wstr + col) = o;
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(wk[u], v[u][i][j], acc[i][j]);   // explicit fma: the two item shapes must round alike
+      }
+    } else {
+      const int col = c0 * 256 + 4 * lane;
+      for (int ck0 = 0; ck0 < nv; ck0 += 16) {                      // one piece: 16 chunks in flight
+        f32x4 v[16];
+        float wk[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int ck = min(ck0 + u, nv - 1);
+          wk[u] = ck0 + u < nv ? w[ck] : 0.f;
+          v[u] = col < p.d ? *(const f32x4*)(prow + ck * cstride + c0 * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_fmaf(wk[u], v[u][j], acc[0][j]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = (c0 + i) * 256 + 4 * lane;
+      if (i < cn && col < p.d) {
+        const half4 o = {f2h_sat(acc[i][0] * inv), f2h_sat(acc[i][1] * inv), f2h_sat(acc[i][2] * inv), f2h_sat(acc[i][3] * inv)};
+        *(half4*)(sWS + r * wstr + col) = o;
       }
     }
   }

@@ -667,7 +667,11 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
     }
     // Query-side cross-attention with the projections around it fused per (head, row slab) - decoder_kernels.h: the q
     // projection + W_k^T q in one launch, the chunk merge + W_v in another (dec_fuse = 1, the default): 3 launches instead of 5
-    const bool fuse = e->opt_dec_fuse && !sl.have_cross_kv && dm % 128 == 0;   // (eight K ranges of whole k16 steps per workgroup)
+    // Measured (r04): at 100-320 rows (pointwise, one decoder position) the fused pair is 9 us per layer faster and the grouped
+    // pipeline gains 1.2 %; at the 13 rows x 23 chunks of a setwise compare it is 4 us per layer SLOWER (the separate GEMMs spread
+    // the cold weights of a layer over 512 + 5120 workgroups).  The family follows from the CALL SHAPE, never from the batch
+    // (the two round differently): fused for one decoder position, separate beyond (dec_fuse = 2 forces the fused form: tests)
+    const bool fuse = (e->opt_dec_fuse == 2 || (e->opt_dec_fuse == 1 && Ld == 1)) && !sl.have_cross_kv && dm % 128 == 0;   // (eight K ranges of whole k16 steps per workgroup)
     if (!dfold) rmsnorm(e, st, sl.dhidden, w.ln1, sl.dxn, nullptr, M);
     if (!fuse) {
       if (dfold) gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxraw[cur], dm, w.cq_f, dm, sl.dq, I, M, I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws, cons());
@@ -684,11 +688,13 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
         if (fuse) {
           const GemmFold cf = dfold ? cons() : GemmFold();
           DecQKArgs qa{(dfold ? sl.dxraw[cur] : sl.dxn) + (size_t)r0 * dm, dm, dfold ? w.cq_f : w.cq, w.ckT, sl.xqk, nr, dm, H,
-                       cf.rowscale ? cf.rowscale + r0 : nullptr, cf.ssq_in ? cf.ssq_in + (size_t)r0 * cf.nb_in : nullptr, cf.nb_in, d.eps, RK_XRAW_SCALE, 32};
+                       cf.rowscale ? cf.rowscale + r0 : nullptr, cf.ssq_in ? cf.ssq_in + (size_t)r0 * cf.nb_in : nullptr, cf.nb_in, d.eps, RK_XRAW_SCALE, 32, 1};
           if (e->opt_dec_fuse_rows > 0) qa.R = std::min(32, e->opt_dec_fuse_rows);
           else if (nr <= 16) qa.R = 16;   // (a setwise pass: 13 rows - half the MFMA columns, half the x rows; measured at 320 rows: 32 > 16 > 8)
+          // few rows: several workgroups per (head, slab) share the output columns, each streaming 1 / CS of W_k^T (and all of W_q,h)
+          while (qa.CS < 8 && (dm / 64) % (2 * qa.CS) == 0 && (long)((nr + qa.R - 1) / qa.R) * H * qa.CS < e->n_cu / 2) qa.CS *= 2;
           Bracket br(e, st, PC_DEC_GEMM, 2.0 * nr * (double)dm * I * 2, 2.0 * ((double)I * dm * 2 + (double)nr * H * dm));
-          hipLaunchKernelGGL(dec_cross_qk_kernel, dim3(H, (nr + qa.R - 1) / qa.R), dim3(64 * DEC_NW), 0, st, qa);
+          hipLaunchKernelGGL(dec_cross_qk_kernel, dim3(H, (nr + qa.R - 1) / qa.R, qa.CS), dim3(64 * DEC_NW), 0, st, qa);
         } else {
           gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dq + (size_t)r0 * I, I, w.ckT, 64, sl.xqk, H * dm, nr, dm, 64, 0, 0, 1.f, H, 64, (long)dm * 64, dm);
         }
@@ -711,7 +717,7 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
           // rows per workgroup: the largest slab that still gives about half the chip a workgroup (results do not depend on it)
           // (16 rows: 41 KiB of LDS at d = 1024, three workgroups per CU hide each other's load latency)
           int R = 16;
-          while (R > 4 && (long)((nr + R - 1) / R) * H < e->n_cu / 2) R >>= 1;
+          while (R > 2 && (long)((nr + R - 1) / R) * H < e->n_cu / 2) R >>= 1;
           DecCVArgs ca{sl.xpart, sl.xstat, sl.d_seq_off, tree ? tree->seq : nullptr, Ld, r0, wv, sl.dctx + (size_t)r0 * I, nr, dm, H, nch, I, R};
           const size_t lds = dec_cv_lds_bytes(dm, R);
           static std::atomic<uint64_t> attr_done{0};
@@ -2071,7 +2077,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 5 (any non-zero value but 6) DMA kernel, two groups per workgroup; 6 one group; 0 tiled kernel
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
   if (!strcmp(key, "dec_fuse_rows")) { e->opt_dec_fuse_rows = value; return RK_OK; }   // rows per workgroup of dec_cross_qk_kernel (0 = auto; A/B)
-  if (!strcmp(key, "dec_fuse")) { e->opt_dec_fuse = value != 0; return RK_OK; }   // few-row decoder: projections around the query-side cross-attention fused per (head, row slab) (1) or separate GEMMs (0)
+  if (!strcmp(key, "dec_fuse")) { e->opt_dec_fuse = value; return RK_OK; }   // few-row decoder: projections around the query-side cross-attention fused per (head, row slab): 1 = at one decoder position (default), 2 = always, 0 = separate GEMMs
   if (!strcmp(key, "gemm_split")) { e->opt_gemm_split = value != 0; return RK_OK; }   // rows beyond the ping-pong kernel's last whole round on a fill-in tile variant (1) or one launch (0)
   if (!strcmp(key, "gemm_group_n")) { e->opt_gemm_group_n = value; return RK_OK; }   // ping-pong GEMM: column-panel width of the tile order in tiles (0 = default 8)
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream

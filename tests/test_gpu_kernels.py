@@ -247,10 +247,10 @@ def test_fused_decoder_projections_match_the_separate_gemms():
         ids = [21 % dims.vocab, 22 % dims.vocab, 50 % dims.vocab]
         outs = {}
         for fuse in (1, 0):
-            eng.set_option("dec_fuse", fuse)
+            eng.set_option("dec_fuse", 2 * fuse)             # 2: the fused form for every decoder length (default 1: one position only)
             outs[fuse] = (eng.score(seqs, [0], ids), eng.score(seqs[:9], [0, 7, 9], ids),
                           eng.greedy(seqs[:5], [0, 7], 2, 1, 0, candidates=ids)[0], eng.greedy(seqs[:5], [0, 7], 2, 1, 0)[0])
-        eng.set_option("dec_fuse", 1)
+        eng.set_option("dec_fuse", 2)
         for a, b in zip(outs[1][:2], outs[0][:2]):
             scale = float(np.abs(b).max())
             assert np.abs(a - b).max() < 4e-3 * max(scale, 1.0), (dims.d_model, np.abs(a - b).max(), scale)
@@ -261,7 +261,9 @@ def test_fused_decoder_projections_match_the_separate_gemms():
         np.testing.assert_array_equal(outs[1][2], outs[1][3])            # speculative two-token pass == two steps (fused path)
         # batch independence of the fused path across the rows-per-workgroup choices (70 / 9 / 1 rows pick different slabs)
         np.testing.assert_array_equal(eng.score(seqs[3:4], [0], ids)[0], outs[1][0][3])
-        np.testing.assert_array_equal(eng.score(seqs[:9], [0], ids), outs[1][0][:9])
+        for k in (2, 9, 17, 33):                                         # (slab heights 2 .. 16, column splits 1 .. 8, both merge item shapes)
+            np.testing.assert_array_equal(eng.score(seqs[:k], [0], ids), outs[1][0][:k])
+        np.testing.assert_array_equal(eng.score(seqs[:4], [0, 7, 9], ids), outs[1][1][:4])
         if dims.d_model <= 512:
             want = T5Oracle(dims, state).score_last(seqs[:6], [0, 7, 9], ids)
             assert np.abs(outs[1][1][:6] - want).max() < LOGIT_TOL, np.abs(outs[1][1][:6] - want).max()
