@@ -946,6 +946,18 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 #ifndef GEMM_PP2_SETPRIO
 #define GEMM_PP2_SETPRIO 1
 #endif
+// LDS-DMA instructions of the ping-pong loop written out (round 4): saddr form - SGPR base + 32-bit lane offset, M0 set by hand.
+// The builtin widens every lane offset to a 64-bit address: 16 VGPRs for the eight offsets of a wave (of 256) and a
+// v_lshl_add_u64 per DMA instruction among the MFMAs.  Bit-identical; grouped pipeline +1.6 .. 2.0 % (7 220-7 290 -> 7 360-7 400
+// passages/s in two alternations on one box, profiles/r04_gemm_feed_experiments.txt).
+// Tried with it and dropped: a "mixed feed" - the W half-tiles through registers (global_load_dwordx4 in one super-phase,
+// ds_write_b128 into the same LDS image in the next) instead of LDS-DMA, which the r03 probe and the r04 knock-outs (no W DMA
+// at all: +6.5 .. 8.6 % on the loop) had suggested: 7-15 % SLOWER (QKV 405 -> 433 us, FFN-in 730 -> 840 us at M = 58 880).  A
+// register load has to land within ONE super-phase (the 8 staging registers are all the kernel can spare; the DMA runs three
+// super-phases ahead), so its wait sits at the head of every MFMA section.  The patch is kept in profiles/r04_wreg_experiment.patch.
+#ifndef GEMM_PP2_ASMDMA
+#define GEMM_PP2_ASMDMA 1
+#endif
 // RS: consumer side of the folded RMSNorm - the accumulators of row m are multiplied by p.rowscale[m] (gemm_epilogue_staged)
 template <int EPI, int KO = 0, bool RS = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
@@ -983,12 +995,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     }
   };
   // buffer of (kind, stage) at (kind * 2 + stage) * 16 KiB
+  const int nk = p.K >> 6;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)gemm_smem);
   auto issue1 = [&](auto kindc, int stage, int tile, auto jc) {
     constexpr int kind = decltype(kindc)::value, j = decltype(jc)::value;
     const char* base = (const char*)((kind < 2 ? p.A : p.W) + tile * 64);
+#if GEMM_PP2_ASMDMA
+    const unsigned dst = lds0 + (unsigned)(((kind * 2 + stage) * HALF + (wave * 2 + j) * 512) * 2);
+    const unsigned o = off[kind][j];                      // (asm operands cannot name a captured array element)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(o), "s"(base) : "memory");
+#else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[kind][j]),
                                      (__attribute__((address_space(3))) void*)(smem + (kind * 2 + stage) * HALF + (wave * 2 + j) * 512),
                                      16, 0, kind < 2 ? GEMM_A_AUX : GEMM_W_AUX);
+#endif
   };
   using std::integral_constant;
   using I0 = integral_constant<int, 0>; using I1 = integral_constant<int, 1>;
@@ -1088,7 +1108,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   using Yes = integral_constant<bool, true>; using No = integral_constant<bool, false>;
   using W4 = integral_constant<int, 4>; using W2 = integral_constant<int, 2>; using W0c = integral_constant<int, 0>;
   using WN = integral_constant<int, -1>;
-  const int nk = p.K >> 6;
   int tile = blockIdx.x;
   set_tile(tile);
   issue_prologue();
