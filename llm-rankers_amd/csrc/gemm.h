@@ -954,7 +954,11 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // ds_write_b128 into the same LDS image in the next) instead of LDS-DMA, which the r03 probe and the r04 knock-outs (no W DMA
 // at all: +6.5 .. 8.6 % on the loop) had suggested: 7-15 % SLOWER (QKV 405 -> 433 us, FFN-in 730 -> 840 us at M = 58 880).  A
 // register load has to land within ONE super-phase (the 8 staging registers are all the kernel can spare; the DMA runs three
-// super-phases ahead), so its wait sits at the head of every MFMA section.  The patch is kept in profiles/r04_wreg_experiment.patch.
+// super-phases ahead), so its wait sits at the head of every MFMA section.  Second form, with the 20 registers the asm DMA freed:
+// two staging sets, two super-phases between a load and its ds_write (waits that are always satisfied): still 6 % slower in the
+// pipeline (7 180 against 7 660-7 700 passages/s) - it is not the latency; eight more VMEM instructions and four ds_write_b128 per
+// K tile among the MFMAs cost more than the DMA pieces they replace.  The patch (second form) is kept in
+// profiles/r04_wreg_experiment.patch.
 #ifndef GEMM_PP2_ASMDMA
 #define GEMM_PP2_ASMDMA 1
 #endif
