@@ -110,5 +110,9 @@ def test_pingpong_gemm_k_loop_keeps_loads_in_flight(isa, epi, rs):
     kloop = max(loops, key=lambda b: sum("v_mfma" in l for l in b))
     assert sum("v_mfma" in l for l in kloop) == 32, "two super-phases of 16 MFMA per K tile"
     assert sum("global_load_lds_dwordx4" in l for l in kloop) == 8
+    # round 4: the DMA instructions are written out in the saddr form (SGPR base pair + one 32-bit lane offset register): no
+    # 64-bit address pairs, no v_lshl_add_u64 among the MFMAs - worth 8 VGPRs of offsets and ~2 % of the grouped pipeline
+    assert all(re.search(r"global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]", l) for l in kloop if "global_load_lds_dwordx4" in l)
+    assert not any("v_lshl_add_u64" in l for l in kloop)
     assert not any(re.search(r"vmcnt\(0\)", l) for l in kloop), "the K loop drains the DMA queue"
     assert sum("s_barrier" in l for l in kloop) == 4
