@@ -962,6 +962,15 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 #ifndef GEMM_PP2_ASMDMA
 #define GEMM_PP2_ASMDMA 1
 #endif
+// How many of a super-phase's four DMA instructions go out in its READ section (behind the fragment reads, in front of the
+// counted wait) instead of among its MFMAs: 0, 2 (the first half-tile) or 4.  An MFMA section is 16 x 32 = 512 matrix-pipe cycles
+// plus what its wave spends issuing DMA (~60 cycles a piece); the partner wave's read section next to it is ~300 cycles.
+// Measured (r04, separately compiled libraries alternated on one box): 0 / 2 / 4 = 7 694-7 731 / 7 678-7 766 / 7 644-7 731 passages/s -
+// no difference: it is not the issuing wave's stall that sets the 2 us of a K tile but the CU's LDS-DMA throughput beside a busy
+// matrix pipe (64 pieces x ~50 cycles; probe r03), wherever the instructions sit.  Left at 0.
+#ifndef GEMM_PP2_RISSUE
+#define GEMM_PP2_RISSUE 0
+#endif
 // RS: consumer side of the folded RMSNorm - the accumulators of row m are multiplied by p.rowscale[m] (gemm_epilogue_staged)
 template <int EPI, int KO = 0, bool RS = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
@@ -1060,9 +1069,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
         for (int ks = 0; ks < 4; ++ks) { aF[0][ks] = *(const half8*)(sa + koff[ks]); aF[1][ks] = *(const half8*)(sa + 2048 + koff[ks]); }
       }
     }
+    constexpr int RISSUE = KO == 0 ? GEMM_PP2_RISSUE : 0;
+    if constexpr (ISSUE && RISSUE > 0) {
+      // this super-phase's first (RISSUE = 2) or both (4) half-tiles are requested here: their buffers were last read one
+      // super-phase ago - those ds_reads were ISSUED before the barrier in front of this section, and a read issued earlier
+      // returns the old bytes whatever lands later (MI355X_MICROARCH.md: LDS-DMA ordering)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SP == 0) {
+        issue1(I3{}, st ^ 1, t + 1, I0{}); issue1(I3{}, st ^ 1, t + 1, I1{});
+        if constexpr (RISSUE == 4) { issue1(I1{}, st ^ 1, t + 1, I0{}); issue1(I1{}, st ^ 1, t + 1, I1{}); }
+      } else {
+        issue1(I0{}, st, t + 2, I0{}); issue1(I0{}, st, t + 2, I1{});
+        if constexpr (RISSUE == 4) { issue1(I2{}, st, t + 2, I0{}); issue1(I2{}, st, t + 2, I1{}); }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // (knock-outs 8 / 16 drop the W / A half of the DMA: the counted waits follow the number of instructions still issued)
     constexpr int NA = (KO & 16) ? 0 : 2, NW = (KO & 8) ? 0 : 2;
-    constexpr int WAITK = WAIT == 4 ? NA + NW : (WAIT == 2 ? NA : WAIT);
+    constexpr int WAITK = (WAIT == 4 ? NA + NW : (WAIT == 2 ? NA : WAIT)) + ((ISSUE && WAIT > 0) ? RISSUE : 0);
     if constexpr (WAIT >= 0 && !(KO & 1)) gemm_wait_vmcnt<WAITK >= 0 ? WAITK : 0>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -1084,11 +1108,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
             __builtin_amdgcn_sched_barrier(0);
             // SP0 of tile t prefetches W1(t+1), A1(t+1); SP1 prefetches A0(t+2), W0(t+2)  (stage of tile t+1 = st^1, t+2 = st)
             if constexpr (SP == 0) {
-              if constexpr (!(KO & 8)) { if (ks == 0) issue1(I3{}, st ^ 1, t + 1, I0{}); if (ks == 1) issue1(I3{}, st ^ 1, t + 1, I1{}); }
-              if constexpr (!(KO & 16)) { if (ks == 2) issue1(I1{}, st ^ 1, t + 1, I0{}); if (ks == 3) issue1(I1{}, st ^ 1, t + 1, I1{}); }
+              if constexpr (!(KO & 8) && RISSUE < 2) { if (ks == 0) issue1(I3{}, st ^ 1, t + 1, I0{}); if (ks == 1) issue1(I3{}, st ^ 1, t + 1, I1{}); }
+              if constexpr (!(KO & 16) && RISSUE < 4) { if (ks == 2) issue1(I1{}, st ^ 1, t + 1, I0{}); if (ks == 3) issue1(I1{}, st ^ 1, t + 1, I1{}); }
             } else {
-              if constexpr (!(KO & 16)) { if (ks == 0) issue1(I0{}, st, t + 2, I0{}); if (ks == 1) issue1(I0{}, st, t + 2, I1{}); }
-              if constexpr (!(KO & 8)) { if (ks == 2) issue1(I2{}, st, t + 2, I0{}); if (ks == 3) issue1(I2{}, st, t + 2, I1{}); }
+              if constexpr (!(KO & 16) && RISSUE < 2) { if (ks == 0) issue1(I0{}, st, t + 2, I0{}); if (ks == 1) issue1(I0{}, st, t + 2, I1{}); }
+              if constexpr (!(KO & 8) && RISSUE < 4) { if (ks == 2) issue1(I2{}, st, t + 2, I0{}); if (ks == 3) issue1(I2{}, st, t + 2, I1{}); }
             }
             __builtin_amdgcn_sched_barrier(0);
           }
