@@ -9,6 +9,9 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef ATTD_Q_EARLY
+#define ATTD_Q_EARLY 1   // the next item's Q loads: 1 = right behind the score tiles (a whole softmax in front of the counted V wait), 0 = behind the V barrier
+#endif
 struct AttnEncArgs {
   const half_t* qkv;     // [T, ld]: q at column 0, k at column I, v at column 2I (output of the fused QKV GEMM)
   half_t* ctx;           // [T, ldctx]
@@ -699,8 +702,8 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
   // ACTIVE: this wave has query rows in THIS item (wave-uniform per item - items span sequences of different lengths in the
   // persistent launch, so `q0 < L` is re-evaluated per item; the two forms are separate straight-line bodies: guarded by a
   // run-time `if`, values defined in one guarded block and used in the next stayed allocated in between).  INVARIANT the
-  // counted vmcnt(10) below relies on: the ACTIVE and the !ACTIVE body issue the SAME number of loads behind V_h - the line
-  // touch + table entry (2), four K rows of the next item, four Q loads of the next item - in any mix of lengths
+  // counted vmcnt(4) below relies on: the ACTIVE and the !ACTIVE body issue the SAME loads behind V_h - the line touch + table
+  // entry (2), four K rows of the next item - and the four Q loads of the next item behind the wait, in any mix of lengths
   // (tests/test_isa_guards.py counts them per body; the ragged GPU test mixes L <= 32, 64 < L <= 128 and L = 192 in one launch)
   auto head = [&](auto lastc, auto nktc, auto activec, int n) {
     constexpr bool LAST = decltype(lastc)::value;
@@ -734,6 +737,12 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+#if ATTD_Q_EARLY
+    if constexpr (!LAST) {
+      issue_q(lane_ctx(opaque_lane()), nxt);              // qf has been dead since the score tiles (every wave, active or not)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     ATTD_STAMP(2);
     // ---- whole-row softmax (attention.h: ATT_ROW_MAXL): one maximum, one sum, P packed to fp16 as it is formed ----
     // (every phase re-derives what it needs of the lane context from a fresh opaque lane number: nothing but the score
@@ -779,19 +788,27 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
     if constexpr (!LAST) {
       const int lane4 = opaque_lane();
       if (!ATTD_KO(0)) issue_rows(lane4, 1, nb, nxt);
-      __builtin_amdgcn_sched_barrier(0);
-      issue_q(lane_ctx(lane4), nxt);                      // qf has been dead since the score tiles (every wave, active or not: same vmcnt counts)
     }
     __builtin_amdgcn_sched_barrier(0);
-    // V_h: this wave's four DMA instructions are the oldest loads in flight (behind them: the line touch + the table entry,
-    // 4 K rows and the 4 Q loads of the next item; the context stores of the previous head are older but at most 4, and
-    // can only make the wait stricter)
-    // (10 = 2 + 4 + 4 loads issued behind V_h by EVERY wave, active or not: see the ACTIVE note at the top of `head`)
+    // V_h: this wave's four DMA instructions are awaited with a COUNTED wait that holds whatever the order in which plain
+    // loads and LDS-DMA loads retire relative to each other (round 4: they do not share one order - gemm.h, row factors).  In
+    // flight behind V_h: the line touch + the table entry (two plain loads, issued an item ago) and the four K rows of the next
+    // item (LDS-DMA: behind V_h in the DMA's own order).  At most 4 outstanding <=> at least 6 of those 10 retired, and the K rows
+    // cannot be among them before V_h is: V_h has landed.  (Until round 4 the next item's four Q loads went out in front of this
+    // wait and it read vmcnt(10): four plain loads overtaking V_h would have satisfied it.  They now follow the barrier below -
+    // still a whole P V ahead of their use.  The context stores of the previous head are older, at most 4, and can only make
+    // the wait stricter.)  Every wave, active or not, issues the same loads: see the ACTIVE note at the top of `head`.
     if constexpr (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     ATTD_STAMP(5);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#if !ATTD_Q_EARLY
+    if constexpr (!LAST) {
+      issue_q(lane_ctx(opaque_lane()), nxt);              // qf has been dead since the score tiles (every wave, active or not)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     ATTD_STAMP(6);
     f32x16 o0, o1;                                        // (local to the head: nothing of them lives across the softmax)
     if constexpr (ACTIVE) {

@@ -231,6 +231,37 @@ def test_config1_flan_t5_small_vs_hf_golden():
     eng.close()
 
 
+def test_pipelined_slots_with_decoder_graphs_match_blocking_calls_at_bench_shape():
+    """Stress of the counted-wait kernels under the conditions of the bench pipeline: flan-t5-large dims, one query's hits=100
+    x 184 tokens per slot, both slots in flight (the decoder chain of one - replayed as a HIP graph - beside the encoder of
+    the other), six launch sequences; every slot's scores must be the bits of a blocking call.  Round 4 found a wait that
+    only failed here: the ping-pong GEMM counted its four row-factor loads (plain loads) against the next tile's twelve LDS-DMA
+    instructions issued behind them, and the two kinds do not retire in one order - a few rows per launch were scaled by stale
+    registers (scores off by up to 0.5) once the compiler's own vmcnt(0) in front of the barrier was gone (asm form of the
+    DMA).  The serial tests never saw it; bench.py --mode shard's recomputation check did."""
+    from llmrankers import _synth
+    dims = _synth.FLAN_T5_LARGE
+    state = _synth.synth_state_dict(dims, seed=929, threads=16)
+    eng = _engine(dims, state, max_tokens=100 * 256, max_seqs=128, max_dec_len=4)
+    qs = [_synth.synth_token_batch(100, 184, 184, dims.vocab, seed=4000 + q) for q in range(2)]
+    ids = [2163, 465]
+    for opts in ({}, {"dec_fuse": 0}, {"gemm_split": 0}, {"overlap": 0}):
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        for rep in range(2):
+            for s_ in range(2):
+                eng.stage(qs[s_], slot=s_)
+            for it in range(6):
+                eng.score_staged([0], ids, slot=it % 2)
+            eng.sync()
+            staged = [eng.read_scores(s_) for s_ in range(2)]
+            for s_ in range(2):
+                np.testing.assert_array_equal(eng.score(qs[s_], [0], ids), staged[s_], err_msg=f"{opts} rep {rep} slot {s_}")
+        for k in opts:
+            eng.set_option(k, 1)
+    eng.close()
+
+
 def test_fused_decoder_projections_match_the_separate_gemms():
     """decoder_kernels.h (round 4): the q projection + W_k^T q, and the chunk merge + W_v projection, each fused per (head,
     row slab) on the matrix cores (engine option dec_fuse, default on) against the five-launch form they replace: same
