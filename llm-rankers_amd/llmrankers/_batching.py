@@ -152,11 +152,12 @@ def padded_token_count(seqs: Sequence[Sequence[int]]) -> int:
 def default_queries_per_call(kind: str, hits: int) -> int:
     """How many queries run.py hands to a ranker's rerank_many at once when --queries_per_call is left at 0 (auto).
     Results, caller lists and counters are those of one query at a time (tests); what changes is what one engine launch
-    sequence holds.  pointwise: enough queries for >= 256 passages (the encoder GEMMs then run at M >= 47k tokens and one
-    decoder chain serves them all: 6.4k against 5.6k passages/s through the API, bench line `per_query`); setwise: four
-    heapsorts in lockstep (49 against 106 ms per query); anything else one query at a time."""
+    sequence holds.  pointwise: enough queries for >= 512 passages - the runtime cuts them into launch sequences of up to 256
+    prompts that pipeline over the engine's two slots, so every decoder chain but the last hides under the next encoder
+    (tools/per_call_sweep.py at hits=100, one box: 1 / 2 / 3 / 4 / 5 / 6 / 8 queries per call = 5 650 / 6 403 / 6 589 / 6 768 / 6 903 /
+    6 974 / 6 863 passages/s); setwise: four heapsorts in lockstep (49 against 106 ms per query); anything else one query at a time."""
     if kind == "pointwise":
-        return max(1, min(8, -(-256 // max(1, int(hits)))))
+        return max(1, min(8, -(-512 // max(1, int(hits)))))
     if kind == "setwise":
         return 4
     return 1
