@@ -79,17 +79,22 @@ class WordSpliceTokenizer:
             return False
 
     def _splice(self, prompts: Sequence[str]) -> List[List[int]]:
-        pieces = [[w for w in p.replace("\n", " ").split(" ") if w] for p in prompts]
+        # (spliced prompts are printable ASCII + newlines - _plain - so str.split() cuts exactly at the blanks and newlines the
+        # pre-tokenizer cuts at, in C)
+        pieces = [p.split() for p in prompts]
         words = self.words
-        missing = {w for ws in pieces for w in ws if w not in words}
-        if missing:
-            if len(words) + len(missing) > self.MAX_WORDS:
-                words.clear()
-                missing = {w for ws in pieces for w in ws}
-            order = list(missing)
-            for w, ids in zip(order, self.tokenizer(order, add_special_tokens=False)["input_ids"]):
-                words[w] = tuple(ids)
         suffix = self.suffix
+        try:                                       # the common case: every word is known - one pass, no membership scan
+            return [list(chain.from_iterable(map(words.__getitem__, ws))) + suffix for ws in pieces]
+        except KeyError:
+            pass
+        missing = {w for ws in pieces for w in ws if w not in words}
+        if len(words) + len(missing) > self.MAX_WORDS:
+            words.clear()
+            missing = {w for ws in pieces for w in ws}
+        order = list(missing)
+        for w, ids in zip(order, self.tokenizer(order, add_special_tokens=False)["input_ids"]):
+            words[w] = tuple(ids)
         return [list(chain.from_iterable(map(words.__getitem__, ws))) + suffix for ws in pieces]
 
     @staticmethod
