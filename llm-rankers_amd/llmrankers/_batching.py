@@ -160,9 +160,10 @@ def default_queries_per_call(kind: str, hits: int) -> int:
     sequence holds.  pointwise: enough queries for >= 512 passages - the runtime cuts them into launch sequences of up to 256
     prompts that pipeline over the engine's two slots, so every decoder chain but the last hides under the next encoder
     (tools/per_call_sweep.py at hits=100, one box: 1 / 2 / 3 / 4 / 5 / 6 / 8 queries per call = 5 650 / 6 403 / 6 589 / 6 768 / 6 903 /
-    6 974 / 6 863 passages/s); setwise: four heapsorts in lockstep (49 against 106 ms per query); anything else one query at a time."""
+    6 974 / 6 863 passages/s); setwise: eight heapsorts in lockstep (tools/bench_setwise_query.py, configs[2] shape: 1 / 4 / 6 / 8
+    queries = 106 / 47.7 / 41.0 / 37.4 ms per query, `likelihood`); anything else one query at a time."""
     if kind == "pointwise":
         return max(1, min(8, -(-512 // max(1, int(hits)))))
     if kind == "setwise":
-        return 4
+        return 8
     return 1

@@ -451,7 +451,7 @@ def build_parser():
                          "RCCL, 0 deals whole queries to the ranks")
     rp.add_argument("--queries_per_call", type=int, default=0,
                     help="pointwise / setwise: queries handed to the engine together (same rankings and counters as one at a time); "
-                         "0 = auto: pointwise enough queries for >= 512 passages per call (6 at hits=100), setwise 4; "
+                         "0 = auto: pointwise enough queries for >= 512 passages per call (6 at hits=100), setwise 8; "
                          "1 = the reference's one query at a time")
     pw = commands.add_parser("pointwise")
     pw.add_argument("--method", type=str, default="yes_no", choices=["qlm", "yes_no"])
