@@ -209,16 +209,16 @@ def ragged_leg(eng, dims, B, G, n_slots):
 def setwise_leg(state):
     """SURVEY 8d S3 / BASELINE configs[2]: one setwise heapsort query (hits=100, num_child=10, k=10) end to end through
     SetwiseLlmRanker.rerank on its own engine (label rows of the head boosted so that generations are labels, as with a
-    trained checkpoint), both scorings; and four queries in lockstep (rerank_many).  tools/bench_setwise_query.py."""
+    trained checkpoint), both scorings; and eight queries in lockstep (rerank_many, the CLI's default).  tools/bench_setwise_query.py."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("rk_bench_setwise", os.path.join(REPO, "tools", "bench_setwise_query.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    res = mod.run(state=state, reps=2, many=4, one_by_one=False)
+    res = mod.run(state=state, reps=2, many=8, one_by_one=False)
     for v in res.values():
         v.pop("top10", None)
     res["workload"] = "S3: flan-t5-large dims, setwise heapsort, hits=100 num_child=10 k=10, 60-word passages (fixture tokenizer), " \
-                      "level-batched build phase; *_many4 = four queries ranked in lockstep (SetwiseLlmRanker.rerank_many)"
+                      "level-batched build phase; *_many8 = eight queries ranked in lockstep (SetwiseLlmRanker.rerank_many = run.py's default for setwise)"
     return res
 
 

@@ -43,7 +43,9 @@ def run(state=None, reps=3, many=None, one_by_one=True):
     from transformers import T5Tokenizer
     tok = T5Tokenizer.from_pretrained(os.path.join(REPO, "tests", "golden", "tok"))
     dims = _synth.FLAN_T5_LARGE
-    eng = RkEngine(dims, 0, max_tokens=max(32768, 12000 * int(os.environ.get("RK_MANY", "4"))), max_seqs=256, max_dec_len=8)
+    nq_cap = int(os.environ.get("RK_MANY", "4")) if many is None else many
+    # (this tool's runtime wrapper does not chunk: the build phase of NQ queries in lockstep is 9 NQ prompts of ~900 tokens)
+    eng = RkEngine(dims, 0, max_tokens=max(32768, 12000 * nq_cap), max_seqs=256, max_dec_len=8)
     # random weights would generate arbitrary tokens ("Unexpected output" on every compare): like the goldens
     # (tests/golden/setwise_large.json) the lm_head rows of the passage labels a prompt can hold (A .. K at num_child = 10)
     # and EOS are scaled x6, so that a generation is "<label> </s>" as with a trained checkpoint - the case the product
