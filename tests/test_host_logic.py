@@ -425,3 +425,11 @@ def test_setwise_rerank_many_equals_one_query_at_a_time(runtimes, scoring):
         got, _ = perm.rerank_many([(queries[0], make(6, 0)), (queries[2], make(5, 2))])
         random.seed(5)
         assert [[d.docid for d in r] for r in got] == [[d.docid for d in ref.rerank(queries[0], make(6, 0))], [d.docid for d in ref.rerank(queries[2], make(5, 2))]]
+
+
+def test_default_queries_per_call():
+    """run.py --queries_per_call 0 (auto): pointwise enough queries for 512 passages per call, capped at 8; setwise eight
+    heapsorts in lockstep; everything else one query at a time (llmrankers/_batching.py)."""
+    from llmrankers._batching import default_queries_per_call as d
+    assert [d("pointwise", h) for h in (1000, 512, 100, 64, 20, 4, 0)] == [1, 1, 6, 8, 8, 8, 8]
+    assert d("setwise", 100) == 8 and d("pairwise", 100) == 1 and d("other", 100) == 1

@@ -116,3 +116,15 @@ def test_pingpong_gemm_k_loop_keeps_loads_in_flight(isa, epi, rs):
     assert not any("v_lshl_add_u64" in l for l in kloop)
     assert not any(re.search(r"vmcnt\(0\)", l) for l in kloop), "the K loop drains the DMA queue"
     assert sum("s_barrier" in l for l in kloop) == 4
+
+
+@pytest.mark.parametrize("name", ["_Z19dec_cross_qk_kernel9DecQKArgs", "_Z19dec_cross_cv_kernel9DecCVArgs"])
+def test_fused_decoder_kernels_fit_two_workgroups_per_cu(isa, name):
+    """decoder_kernels.h (round 4): eight-wave workgroups whose load latency is hidden by a second (third) workgroup on the CU -
+    at most 128 VGPRs (four waves per SIMD) and no scratch."""
+    body = kernel_body(isa, name)
+    assert not any("scratch_" in l for l in body), "fused decoder kernel spills"
+    tail = "\n".join(isa[isa.index(body[-1]):isa.index(body[-1]) + 400])
+    m = re.search(r"NumVgprs: (\d+)", tail)
+    assert m and int(m.group(1)) <= 128, m and m.group(1)
+    assert sum("v_mfma_f32_32x32x16_f16" in l for l in body) >= 8
