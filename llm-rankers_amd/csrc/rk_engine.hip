@@ -1021,6 +1021,24 @@ void comm_release(rk_engine* e) {
   e->gather_cap = 0; e->comm_world = 1; e->comm_rank = 0;
 }
 
+// the gather / send / staging buffers of a communicator just created (rk_comm_init); on an error the caller releases everything
+int comm_alloc_buffers(rk_engine* e) {
+  const int world = e->comm_world;
+  for (int i = 0; i < RK_SLOTS; ++i) {
+    HIPCHK(e, hipMalloc((void**)&e->d_gather[i], e->gather_cap * world * sizeof(float)));
+    HIPCHK(e, hipHostMalloc((void**)&e->h_gather[i], e->gather_cap * world * sizeof(float), hipHostMallocDefault));
+    HIPCHK(e, hipEventCreateWithFlags(&e->ev_gather[i], hipEventDisableTiming));
+  }
+  HIPCHK(e, hipMalloc((void**)&e->d_gsend, e->gather_cap * sizeof(float)));
+  HIPCHK(e, hipMemset(e->d_gsend, 0, e->gather_cap * sizeof(float)));
+  HIPCHK(e, hipMalloc((void**)&e->d_gall, e->gather_cap * world * sizeof(float)));
+  HIPCHK(e, hipHostMalloc((void**)&e->h_gall, e->gather_cap * world * sizeof(float), hipHostMallocDefault));
+  HIPCHK(e, hipHostMalloc((void**)&e->h_gstage, e->gather_cap * sizeof(float), hipHostMallocDefault));
+  HIPCHK(e, hipEventCreateWithFlags(&e->ev_gall, hipEventDisableTiming));
+  HIPCHK(e, hipEventCreateWithFlags(&e->ev_append, hipEventDisableTiming));
+  return RK_OK;
+}
+
 }  // namespace
 
 // =============================================== C ABI =======================================================
@@ -1855,18 +1873,12 @@ int rk_comm_init(rk_engine* e, const uint8_t* id_bytes, int n_bytes, int rank, i
   const ncclResult_t nrc = r->CommInitRank(&e->comm, world, id, rank);   // collective over all ranks
   if (nrc != ncclSuccess) { e->comm = nullptr; return fail(e, RK_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, r->GetErrorString(nrc)); }
   e->comm_rank = rank; e->comm_world = world; e->gather_cap = (size_t)max_floats_per_rank;
-  for (int i = 0; i < RK_SLOTS; ++i) {
-    HIPCHK(e, hipMalloc((void**)&e->d_gather[i], e->gather_cap * world * sizeof(float)));
-    HIPCHK(e, hipHostMalloc((void**)&e->h_gather[i], e->gather_cap * world * sizeof(float), hipHostMallocDefault));
-    HIPCHK(e, hipEventCreateWithFlags(&e->ev_gather[i], hipEventDisableTiming));
+  if ((rc = comm_alloc_buffers(e))) {     // a half-built communicator must not report a capacity: tear it down, keep the message
+    const std::string why = e->err;
+    comm_release(e);
+    e->err = why;
+    return rc;
   }
-  HIPCHK(e, hipMalloc((void**)&e->d_gsend, e->gather_cap * sizeof(float)));
-  HIPCHK(e, hipMemset(e->d_gsend, 0, e->gather_cap * sizeof(float)));
-  HIPCHK(e, hipMalloc((void**)&e->d_gall, e->gather_cap * world * sizeof(float)));
-  HIPCHK(e, hipHostMalloc((void**)&e->h_gall, e->gather_cap * world * sizeof(float), hipHostMallocDefault));
-  HIPCHK(e, hipHostMalloc((void**)&e->h_gstage, e->gather_cap * sizeof(float), hipHostMallocDefault));
-  HIPCHK(e, hipEventCreateWithFlags(&e->ev_gall, hipEventDisableTiming));
-  HIPCHK(e, hipEventCreateWithFlags(&e->ev_append, hipEventDisableTiming));
   return RK_OK;
 }
 
