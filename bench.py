@@ -350,7 +350,14 @@ def main():
     elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     elif local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+        if torch.cuda.device_count() == 1 and os.environ.get("RK_BENCH_MASKED_DEVICES", "1") == "1":
+            # a launcher that masks the devices per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = one GPU each): this rank's
+            # GPU is device 0.  (Ranks that really share one GPU fail loudly further down: RCCL refuses duplicate devices.)
+            print(f"[bench] rank {rank}: LOCAL_RANK {local_rank}, one GPU visible: using device 0 (devices masked per rank)", file=sys.stderr)
+            local_rank = 0
+            torch.cuda.set_device(0)
+        else:
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     else:
         torch.cuda.set_device(local_rank)
     if world > 1:
