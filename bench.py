@@ -313,7 +313,8 @@ def per_query_numbers(eng, dims, B, L):
                              "note": "PointwiseLlmRanker.rerank incl. prompt building, host tokenisation (fixture tokenizer), sort"}
         try:
             # (c) the same through PointwiseLlmRanker.rerank_many with run.py's DEFAULT queries per call (--queries_per_call 0 =
-            # auto: enough queries for >= 512 passages, 6 at hits=100) - identical rankings and counters, the engine's grouped
+            # auto: enough queries for >= 1 600 passages, 16 at hits=100; launches start while later queries are still being
+            # tokenised, T5Runtime.score_stream) - identical rankings and counters, the engine's grouped
             # throughput instead of its one-query-at-a-time one: this is what `python run.py run ... pointwise` delivers
             from llmrankers._batching import default_queries_per_call
             queries = [" ".join(rs.choice(words, 30)) for _ in range(default_queries_per_call("pointwise", 100))]

@@ -157,13 +157,15 @@ def padded_token_count(seqs: Sequence[Sequence[int]]) -> int:
 def default_queries_per_call(kind: str, hits: int) -> int:
     """How many queries run.py hands to a ranker's rerank_many at once when --queries_per_call is left at 0 (auto).
     Results, caller lists and counters are those of one query at a time (tests); what changes is what one engine launch
-    sequence holds.  pointwise: enough queries for >= 512 passages - the runtime cuts them into launch sequences of up to 256
-    prompts that pipeline over the engine's two slots, so every decoder chain but the last hides under the next encoder
-    (tools/per_call_sweep.py at hits=100, one box: 1 / 2 / 3 / 4 / 5 / 6 / 8 queries per call = 5 650 / 6 403 / 6 589 / 6 768 / 6 903 /
-    6 974 / 6 863 passages/s); setwise: eight heapsorts in lockstep (tools/bench_setwise_query.py, configs[2] shape: 1 / 4 / 6 / 8
-    queries = 106 / 47.7 / 41.0 / 37.4 ms per query, `likelihood`); anything else one query at a time."""
+    sequence holds.  pointwise: enough queries for >= 1 600 passages, at most 16 - the runtime cuts them into launch sequences of
+    up to 256 prompts that pipeline over the engine's two slots AND launches while the later queries are still being tokenised
+    (T5Runtime.score_stream), so per call only the first launch sequence's tokenisation and the last one's decoder chain are
+    exposed (tools/per_call_sweep.py at hits=100, one box, round 4: 6 / 8 / 12 / 16 queries per call = 7 430 / 7 432 / 7 649 / 7 749
+    passages/s; before the streaming launch 6 / 8 = 7 098 / 6 992 and the default was 6); setwise: eight heapsorts in lockstep
+    (tools/bench_setwise_query.py, configs[2] shape: 1 / 4 / 6 / 8 queries = 106 / 47.7 / 41.0 / 37.4 ms per query, `likelihood`);
+    anything else one query at a time."""
     if kind == "pointwise":
-        return max(1, min(8, -(-512 // max(1, int(hits)))))
+        return max(1, min(16, -(-1600 // max(1, int(hits)))))
     if kind == "setwise":
         return 8
     return 1

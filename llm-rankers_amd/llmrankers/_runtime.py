@@ -237,29 +237,57 @@ class T5Runtime:
     def score(self, seqs, dec_prefix, out_ids) -> np.ndarray:
         return np.concatenate([self.engine.score(c, dec_prefix, out_ids) for c in self._chunks(seqs)], axis=0)
 
-    def score_batches(self, batches, dec_prefix, out_ids) -> List[np.ndarray]:
-        """Score several independent batches, keeping the engine's batch slots full: batch i+1 is staged and its
-        encoder enqueued while the decoder chain of batch i still runs (rk_t5_stage_slot / rk_t5_score_slot).
-        Results are identical to calling score() per batch; only the waiting is overlapped."""
+    def score_stream(self, groups, dec_prefix, out_ids) -> np.ndarray:
+        """Scores [n, len(out_ids)] of the token sequences that the iterable `groups` yields (lists of sequences, e.g. one
+        query's prompts at a time), in order.  `groups` is consumed LAZILY: as soon as the sequences pulled so far fill an
+        engine call (max_seqs / max_tokens - the same greedy cut as _chunks over the flat list) the call is staged and
+        enqueued on the next batch slot, and the host goes on pulling - i.e. tokenising - the following sequences while the
+        GPU works (rk_t5_stage_slot / rk_t5_score_slot return at once; only reading a slot's scores waits).  A call of six
+        queries thus leaves the tokenisation of the first launch sequence exposed instead of all of it.  Same bits as
+        score() on the flat list: a sequence's scores do not depend on what shares its call."""
         eng = self.engine
         n_slots = eng.num_slots
-        # The reference's batch_size only shapes its host loop; results do not depend on batch composition (ragged
-        # execution), so consecutive batches are merged up to the engine's capacity: one launch sequence then covers
-        # ~one query's candidates - better GEMM tile quantisation and ONE decoder chain instead of one per batch.
-        flat = [s for b in batches for s in b]
-        work = list(self._chunks(flat))
-        parts = []
-        pending = []                                                   # slots in submission order
-        for k, chunk in enumerate(work):
-            slot = k % n_slots
+        parts, pending = [], []                                         # slots in submission order
+        launched = 0
+        cur, tok = [], 0
+
+        def launch(chunk):
+            nonlocal launched
+            slot = launched % n_slots
             if len(pending) == n_slots:                                # the slot we are about to reuse must be drained
                 parts.append(eng.read_scores(pending.pop(0)))
             eng.stage(chunk, slot=slot)
             eng.score_staged(dec_prefix, out_ids, slot=slot)
             pending.append(slot)
-        for s0 in pending:
-            parts.append(eng.read_scores(s0))
-        allsc = np.concatenate(parts, axis=0) if parts else np.zeros((0, len(out_ids)), np.float32)
+            launched += 1
+
+        try:
+            for group in groups:
+                for s in group:
+                    if len(s) > self.max_tokens:
+                        raise ValueError(f"a prompt of {len(s)} tokens exceeds the engine capacity {self.max_tokens}")
+                    if cur and (tok + len(s) > self.max_tokens or len(cur) == self.max_seqs):
+                        launch(cur)
+                        cur, tok = [], 0
+                    cur.append(s)
+                    tok += len(s)
+            if cur:
+                launch(cur)
+        finally:
+            # whatever happened above (a prompt too long, the caller's generator raising): no slot stays in flight
+            for s0 in pending:
+                parts.append(eng.read_scores(s0))
+        return np.concatenate(parts, axis=0) if parts else np.zeros((0, len(out_ids)), np.float32)
+
+    def score_batches(self, batches, dec_prefix, out_ids) -> List[np.ndarray]:
+        """Score several independent batches, keeping the engine's batch slots full: batch i+1 is staged and its
+        encoder enqueued while the decoder chain of batch i still runs (rk_t5_stage_slot / rk_t5_score_slot).
+        Results are identical to calling score() per batch; only the waiting is overlapped."""
+        # The reference's batch_size only shapes its host loop; results do not depend on batch composition (ragged
+        # execution), so consecutive batches are merged up to the engine's capacity: one launch sequence then covers
+        # ~one query's candidates - better GEMM tile quantisation and ONE decoder chain instead of one per batch.
+        batches = list(batches)
+        allsc = self.score_stream(batches, dec_prefix, out_ids)
         out, pos = [], 0
         for b in batches:
             out.append(allsc[pos:pos + len(b)])

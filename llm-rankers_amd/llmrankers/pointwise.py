@@ -206,14 +206,23 @@ class PointwiseLlmRanker(LlmRanker):
                 out.append(self.rerank(query, ranking))
                 counters.append((self.total_compare, self.total_prompt_tokens, self.total_completion_tokens))
             return out, counters
-        chunks, counters, sizes = [], [], []
-        for (query, ranking), spec in zip(items, specs):
-            self._reset()
-            prompts, _, _, _, dec_len, _ = spec
-            chunks.extend(self._counted_batches(prompts, dec_len))
-            counters.append((self.total_compare, self.total_prompt_tokens, self.total_completion_tokens))
-            sizes.append(len(prompts))
-        raw = self._raw(chunks, "score", specs[0][2], specs[0][3])
+        counters, sizes = [], []
+
+        def tokenised_queries():
+            # one query's prompts at a time: the runtime launches as soon as an engine call is full and keeps pulling, so the
+            # later queries are tokenised while the GPU already scores the first ones (T5Runtime.score_stream)
+            for (query, ranking), spec in zip(items, specs):
+                self._reset()
+                prompts, _, _, _, dec_len, _ = spec
+                chunks = self._counted_batches(prompts, dec_len)
+                counters.append((self.total_compare, self.total_prompt_tokens, self.total_completion_tokens))
+                sizes.append(len(prompts))
+                yield chunks
+
+        if hasattr(self.llm, "score_stream"):
+            raw = self.llm.score_stream(([s for c in chunks for s in c] for chunks in tokenised_queries()), specs[0][2], specs[0][3])
+        else:                                                        # a runtime without batch slots (test doubles): batch by batch
+            raw = self._raw([c for chunks in tokenised_queries() for c in chunks], "score", specs[0][2], specs[0][3])
         out, pos = [], 0
         for (query, ranking), spec, n in zip(items, specs, sizes):
             for doc, sc in zip(ranking, spec[5](raw[pos:pos + n])):

@@ -214,7 +214,7 @@ def test_queries_per_call_gives_the_same_run_and_statistics(runmod, tmp_path, ck
     stats1 = run(tmp_path / "one.trec", ["--queries_per_call", "1"])               # the reference's loop: one query at a time
     n1 = len(engine_calls)
     del engine_calls[:]
-    stats_auto = run(tmp_path / "auto.trec")                                       # default = auto: 256 / hits -> capped at 8 queries per call
+    stats_auto = run(tmp_path / "auto.trec")                                       # default = auto (enough queries for 1 600 passages, at most 16 per call)
     assert (tmp_path / "auto.trec").read_text() == (tmp_path / "one.trec").read_text() and stats_auto == stats1
     assert engine_calls == [20]                                                    # all 5 queries x 4 passages in ONE engine call
     del engine_calls[:]

@@ -428,8 +428,113 @@ def test_setwise_rerank_many_equals_one_query_at_a_time(runtimes, scoring):
 
 
 def test_default_queries_per_call():
-    """run.py --queries_per_call 0 (auto): pointwise enough queries for 512 passages per call, capped at 8; setwise eight
+    """run.py --queries_per_call 0 (auto): pointwise enough queries for 1 600 passages per call, capped at 16; setwise eight
     heapsorts in lockstep; everything else one query at a time (llmrankers/_batching.py)."""
     from llmrankers._batching import default_queries_per_call as d
-    assert [d("pointwise", h) for h in (1000, 512, 100, 64, 20, 4, 0)] == [1, 1, 6, 8, 8, 8, 8]
+    assert [d("pointwise", h) for h in (2000, 1000, 512, 100, 64, 20, 4, 0)] == [1, 2, 4, 16, 16, 16, 16, 16]
     assert d("setwise", 100) == 8 and d("pairwise", 100) == 1 and d("other", 100) == 1
+
+
+class _EventEngine:
+    """DryEngine (tools/dry_engine.py) that records the order of engine calls - to see WHEN the runtime launches."""
+
+    def __new__(cls, events, **kw):
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        from dry_engine import DryEngine
+        from llmrankers import _synth
+
+        class Rec(DryEngine):
+            def stage(self, seqs, slot=0):
+                events.append(("stage", slot, len(seqs)))
+                return super().stage(seqs, slot)
+
+            def read_scores(self, slot=0):
+                events.append(("read", slot))
+                return super().read_scores(slot)
+        return Rec(_synth.TOY_GATED_UNTIED, 0, **kw)
+
+
+def test_score_stream_launches_while_the_caller_still_produces_sequences():
+    """T5Runtime.score_stream: same scores and the same cuts as the flat list, launches as soon as a call is full (the groups
+    behind it are pulled - tokenised - after the launch), and no slot stays in flight when the producer raises."""
+    from llmrankers._runtime import T5Runtime
+    from llmrankers import _synth
+    events = []
+    eng = _EventEngine(events, max_tokens=400, max_seqs=5, max_dec_len=4)
+    rt = T5Runtime.from_engine(eng, _synth.TOY_GATED_UNTIED)
+    rs = random.Random(4)
+    groups = [[[rs.randrange(3, 90) for _ in range(rs.randrange(1, 120))] for _ in range(n)] for n in (4, 3, 0, 6, 1, 2)]
+    flat = [s for g in groups for s in g]
+
+    def produce():
+        for i, g in enumerate(groups):
+            events.append(("pull", i))
+            yield g
+    got = rt.score_stream(produce(), [0], [7, 9])
+    want = rt.score(flat, [0], [7, 9])
+    assert np.array_equal(got, want) and got.shape == (len(flat), 2)
+    cuts = [len(c) for c in rt._chunks(flat)]
+    assert [e[2] for e in events if e[0] == "stage"] == cuts and len(cuts) >= 4
+    order = [e[0] for e in events]
+    first_stage = order.index("stage")
+    assert ("pull", len(groups) - 1) in events[first_stage:], "the last group was produced before the first launch"
+    # two slots: a slot is read before it is staged again, and every staged slot is read exactly once
+    staged = [e[1] for e in events if e[0] == "stage"]
+    assert staged == [i % eng.num_slots for i in range(len(staged))]
+    assert sum(e[0] == "read" for e in events) == len(staged)
+    # score_batches = the same stream, cut back into the caller's batches (empty ones included)
+    parts = rt.score_batches(groups, [0], [7, 9])
+    assert [len(p) for p in parts] == [len(g) for g in groups] and np.array_equal(np.concatenate(parts), want)
+    assert rt.score_stream(iter([]), [0], [7, 9]).shape == (0, 2)
+
+    # a producer that fails mid-way: the exception arrives, the launches already made are drained
+    del events[:]
+
+    def bad():
+        yield groups[0]
+        yield groups[1]
+        raise RuntimeError("tokeniser fell over")
+    with pytest.raises(RuntimeError, match="fell over"):
+        rt.score_stream(bad(), [0], [7, 9])
+    assert sum(e[0] == "stage" for e in events) == sum(e[0] == "read" for e in events)
+    with pytest.raises(ValueError, match="exceeds the engine capacity"):
+        rt.score_stream([[list(range(3, 90)) * 6]], [0], [7, 9])
+
+
+def test_pointwise_rerank_many_streams_and_equals_one_query_at_a_time():
+    """PointwiseLlmRanker.rerank_many over the streaming runtime: rankings, scores and counters of rerank() per query; the
+    first engine launch happens before the last query has been tokenised."""
+    from transformers import T5Tokenizer
+    from llmrankers._runtime import T5Runtime
+    from llmrankers import _synth
+    events = []
+    eng = _EventEngine(events, max_tokens=4000, max_seqs=24, max_dec_len=4)
+    rt = T5Runtime.from_engine(eng, _synth.TOY_GATED_UNTIED)
+    tok = T5Tokenizer.from_pretrained(os.path.join(GOLD, "tok"))
+
+    rk = PointwiseLlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=4)
+    counted = rk._counted_batches
+
+    def noted(prompts, dec_len):                           # when a query's prompts are tokenised and cut into batches
+        events.append(("tokenise",))
+        return counted(prompts, dec_len)
+    rk._counted_batches = noted
+    rs = random.Random(1)
+    words = "alpha beta gamma delta search engine ranking neural index passage".split()
+
+    def items():
+        r = random.Random(2)
+        return [(" ".join(r.choice(words) for _ in range(5)),
+                 [SearchResult(docid=f"q{q}d{i}", score=float(20 - i), text=" ".join(r.choice(words) for _ in range(r.randrange(3, 40))))
+                  for i in range(n)]) for q, n in enumerate((10, 7, 10, 9, 10))]
+    many, counters = rk.rerank_many(items())
+    order = [e[0] for e in events]
+    assert "stage" in order and order.index("stage") < len(order) - 1 - order[::-1].index("tokenise"), \
+        "every query was tokenised before the first launch"
+    one = []
+    for q, ranking in items():
+        res = rk.rerank(q, ranking)
+        one.append(([(d.docid, d.score) for d in res], (rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens)))
+    assert [[(d.docid, d.score) for d in res] for res in many] == [o[0] for o in one]
+    assert counters == [o[1] for o in one]

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """How many queries should run.py hand to PointwiseLlmRanker.rerank_many at once?  hits=100 candidates of ~170 tokens per prompt
-(fixture tokenizer), text in, rankings out; ms per query for 1 (= rerank), 2 ... 8 queries per call."""
+(fixture tokenizer), text in, rankings out; ms per query for 1 (= rerank), 2 ... 8 queries per call.  An argument `6n` measures
+six queries per call WITHOUT the streaming launch (T5Runtime.score_stream hidden: every query is tokenised before the first
+launch, the behaviour up to round 4's last day) - `6 6n 6 6n` is the same-box A/B."""
 import json
 import os
 import sys
@@ -32,19 +34,29 @@ def main():
     words = "neural ranking model search engine index retrieval document answer question relevant topic passage".split()
     rs = np.random.RandomState(0)
     docs = [" ".join(rs.choice(words, 126)) for _ in range(100)]
-    for n in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5, 6, 8]:
+    class NoStream:                                       # the runtime without score_stream: rerank_many falls back to score_batches
+        def __init__(self, inner):
+            self._inner = inner
+
+        def __getattr__(self, name):
+            if name == "score_stream":
+                raise AttributeError(name)
+            return getattr(self._inner, name)
+    ranker_ns = PointwiseLlmRanker.from_runtime(NoStream(rt), tok, method="yes_no", batch_size=32)
+    for arg in sys.argv[1:] or ["1", "2", "3", "4", "5", "6", "8"]:
+        n, rk = int(arg.rstrip("n")), (ranker_ns if arg.endswith("n") else ranker)
         queries = [" ".join(rs.choice(words, 30)) for _ in range(n)]
         ts = []
         for _ in range(6):
             items = [(q, [SearchResult(docid=str(i), score=float(100 - i), text=d) for i, d in enumerate(docs)]) for q in queries]
             t = time.perf_counter()
             if n == 1:
-                ranker.rerank(*items[0])
+                rk.rerank(*items[0])
             else:
-                ranker.rerank_many(items)
+                rk.rerank_many(items)
             ts.append(time.perf_counter() - t)
         ms = float(np.median(ts[2:])) * 1e3 / n
-        print(json.dumps({"queries_per_call": n, "ms_per_query": round(ms, 2), "passages_per_s": round(1e5 / ms, 1)}), flush=True)
+        print(json.dumps({"queries_per_call": n, "streaming": not arg.endswith("n"), "ms_per_query": round(ms, 2), "passages_per_s": round(1e5 / ms, 1)}), flush=True)
     eng.close()
 
 
