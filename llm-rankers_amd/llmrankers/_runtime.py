@@ -294,6 +294,20 @@ class T5Runtime:
             pos += len(b)
         return out
 
+    def score_async(self, seqs, dec_prefix, out_ids, slot: int):
+        """Enqueue ONE engine call for `seqs` on batch slot `slot` and return at once -> a handle for score_collect, or None
+        when the sequences do not fit one call (the caller then uses score(), which cuts them).  The caller owns the slot
+        until it has collected: nothing else may be launched on it, and no blocking call may run, in between."""
+        if not (0 < len(seqs) <= self.max_seqs and sum(len(s) for s in seqs) <= self.max_tokens):
+            return None
+        self.engine.stage(seqs, slot=slot)
+        self.engine.score_staged(dec_prefix, out_ids, slot=slot)
+        return slot
+
+    def score_collect(self, handle) -> np.ndarray:
+        """[n, len(out_ids)] scores of the call score_async enqueued (waits for it)."""
+        return self.engine.read_scores(handle)
+
     def qlm(self, seqs, labels) -> np.ndarray:
         return np.concatenate([self.engine.qlm(c, labels) for c in self._chunks(seqs)], axis=0)
 

@@ -238,6 +238,33 @@ class SetwiseLlmRanker(LlmRanker):
                 print(f"Unexpected output: {output}")
         return outs, prompt_tokens, completion_tokens
 
+    # ---- the same compare, launched and collected separately (likelihood scoring on a runtime with batch slots) ----------
+    def _can_alternate(self) -> bool:
+        """Two groups of lockstep queries can alternate over the engine's batch slots: T5 likelihood scoring (one engine call
+        per step, no host decision inside it) on a runtime that launches without waiting (T5Runtime.score_async)."""
+        return (self.model_type != "llama" and self.scoring == "likelihood" and getattr(self, "alternate_groups", True)
+                and hasattr(self.llm, "score_async") and getattr(getattr(self.llm, "engine", None), "num_slots", 1) >= 2)
+
+    def _launch_windows(self, queries: List[str], doc_lists: List[List], slot: int):
+        """First half of `_compare_windows` (likelihood): prompts, tokens, ONE engine call enqueued on `slot`; returns at once.
+        None when the windows do not fit one engine call (the caller then takes the blocking path)."""
+        if any(len(docs) == 0 for docs in doc_lists):
+            raise IndexError("list index out of range")
+        texts = [self._prompt(q, self.CHARACTERS[:len(docs)], [d.text for d in docs]) for q, docs in zip(queries, doc_lists)]
+        ids = tokenize_prompts(self.tokenizer, texts)
+        nmax = max(len(docs) for docs in doc_lists)
+        handle = self.llm.score_async(ids, self.decoder_input_ids, self.target_token_ids[:nmax], slot)
+        if handle is None:
+            return None
+        return handle, [len(docs) for docs in doc_lists], [len(i) for i in ids]
+
+    def _collect_windows(self, launched):
+        """Second half: waits for the slot, -> (labels, prompt tokens per window, completion tokens per window)."""
+        handle, sizes, prompt_tokens = launched
+        lg = np.asarray(self.llm.score_collect(handle))
+        outs = [self.CHARACTERS[int(np.argmax(lg[r, :n]))] for r, n in enumerate(sizes)]
+        return outs, prompt_tokens, [0] * len(sizes)
+
     def _batched_ok(self) -> bool:
         # level-wise batching needs compare() to be ours (no subclass / instance override) and draw-free
         return (getattr(self, "batch_independent_compares", False) and self.num_permutation == 1
@@ -457,14 +484,16 @@ class SetwiseLlmRanker(LlmRanker):
                 pending[q] = next(gen)
             except StopIteration:
                 pass
-        while pending:
-            order = sorted(pending)
-            queries = [items[q][0] for q in order for _ in pending[q]]
-            windows = [w for q in order for w in pending[q]]
-            outs, ptok, ctok = self._compare_windows(queries, windows)
+
+        def windows_of(group):
+            order = sorted(group)
+            return order, [items[q][0] for q in order for _ in group[q]], [w for q in order for w in group[q]]
+
+        def advance(group, order, outs, ptok, ctok):
+            """hand every chain of the group its labels -> the group's next pending windows"""
             pos, nxt = 0, {}
             for q in order:
-                n = len(pending[q])
+                n = len(group[q])
                 counts[q][0] += n
                 counts[q][1] += sum(ptok[pos:pos + n])
                 counts[q][2] += sum(ctok[pos:pos + n])
@@ -473,7 +502,41 @@ class SetwiseLlmRanker(LlmRanker):
                 except StopIteration:
                     pass
                 pos += n
-            pending = nxt
+            return nxt
+
+        if len(pending) >= 4 and self._can_alternate():
+            # Two groups of chains alternate over the engine's two batch slots: while one group's call is on the GPU the host
+            # advances the other group's heaps, builds and tokenises its prompts and launches them - the launch-bound decoder
+            # chain of one call runs under the encoder of the next, and the host part of a step is hidden.  A chain sees the
+            # same labels as alone (batch independence), so rankings and counters do not change (tests).
+            groups = [{}, {}]
+            for i, q in enumerate(sorted(pending)):
+                groups[i % 2][q] = pending[q]
+            inflight = []                                            # [(group index, order, launched)] oldest first
+
+            def submit(g) -> bool:
+                order, queries, windows = windows_of(groups[g])
+                launched = self._launch_windows(queries, windows, slot=g)
+                if launched is None:                                 # does not fit one engine call: back to the blocking loop below
+                    return False
+                inflight.append((g, order, launched))
+                return True
+
+            ok = True
+            for g in (0, 1):
+                if ok and groups[g]:
+                    ok = submit(g)
+            while ok and inflight:
+                g, order, launched = inflight.pop(0)
+                groups[g] = advance(groups[g], order, *self._collect_windows(launched))
+                if groups[g]:
+                    ok = submit(g)
+            for g, order, launched in inflight:                      # (only after a call that did not fit)
+                groups[g] = advance(groups[g], order, *self._collect_windows(launched))
+            pending = {**groups[0], **groups[1]}
+        while pending:
+            order, queries, windows = windows_of(pending)
+            pending = advance(pending, order, *self._compare_windows(queries, windows))
         results = []
         for (query, ranking), original in zip(items, originals):
             ordered = list(reversed(ranking)) if heap else ranking

@@ -538,3 +538,54 @@ def test_pointwise_rerank_many_streams_and_equals_one_query_at_a_time():
         one.append(([(d.docid, d.score) for d in res], (rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens)))
     assert [[(d.docid, d.score) for d in res] for res in many] == [o[0] for o in one]
     assert counters == [o[1] for o in one]
+
+
+@pytest.mark.parametrize("method", ["heapsort", "bubblesort"])
+def test_setwise_lockstep_alternates_two_groups_over_the_slots(method):
+    """SetwiseLlmRanker.rerank_many, likelihood scoring on a runtime with batch slots: the chains run as two groups that
+    alternate over slots 0 and 1 (a launch on one slot happens while the other is still uncollected), rankings and counters
+    are those of rerank() one query at a time; a call that does not fit the engine sends the rest down the blocking loop."""
+    from transformers import T5Tokenizer
+    from llmrankers._runtime import T5Runtime
+    from llmrankers import _synth
+    tok = T5Tokenizer.from_pretrained(os.path.join(GOLD, "tok"))
+    words = "alpha beta gamma delta search engine ranking neural index passage".split()
+
+    def items():
+        r = random.Random(7)
+        return [(" ".join(r.choice(words) for _ in range(4)),
+                 [SearchResult(docid=f"q{q}d{i}", score=float(50 - i), text=" ".join(r.choice(words) for _ in range(r.randrange(3, 12))))
+                  for i in range(n)]) for q, n in enumerate((14, 9, 14, 12, 13, 5, 14))]
+
+    def run(max_tokens, alternate=True):
+        events = []
+        eng = _EventEngine(events, max_tokens=max_tokens, max_seqs=64, max_dec_len=4)
+        rt = T5Runtime.from_engine(eng, _synth.TOY_GATED_UNTIED)
+        rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=3, k=4, scoring="likelihood", method=method)
+        rk.alternate_groups = alternate
+        with contextlib.redirect_stdout(io.StringIO()):
+            many, counters = rk.rerank_many(items())
+            one = []
+            for q, ranking in items():
+                res = rk.rerank(q, ranking)
+                one.append(([(d.docid, d.score) for d in res], (rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens)))
+        assert [[(d.docid, d.score) for d in res] for res in many] == [o[0] for o in one]
+        assert counters == [o[1] for o in one]
+        return events, eng
+
+    events, eng = run(100000)
+    stages = [e for e in events if e[0] == "stage"]
+    assert any(e[1] == 1 for e in stages), "slot 1 was never used: the groups did not alternate"
+    # somewhere a slot is staged while the other slot's scores have not been read yet
+    outstanding, overlapped = set(), False
+    for e in events:
+        if e[0] == "stage":
+            overlapped |= bool(outstanding - {e[1]})
+            outstanding.add(e[1])
+        elif e[0] == "read":
+            outstanding.discard(e[1])
+    assert overlapped
+    ev_single, _ = run(100000, alternate=False)
+    assert all(e[1] == 0 for e in ev_single if e[0] == "stage")
+    # an engine too small for a group's call: same results through the blocking loop (asserted inside run)
+    run(260)

@@ -28,6 +28,14 @@ class EngineRuntime:
     def score(self, seqs, dec_prefix, out_ids):
         return self.engine.score(seqs, dec_prefix, out_ids)
 
+    def score_async(self, seqs, dec_prefix, out_ids, slot):      # T5Runtime.score_async (capacity: this tool sizes the engine itself)
+        self.engine.stage(seqs, slot=slot)
+        self.engine.score_staged(dec_prefix, out_ids, slot=slot)
+        return slot
+
+    def score_collect(self, handle):
+        return self.engine.read_scores(handle)
+
     supports_greedy_candidates = True
 
     def greedy(self, seqs, dec_prefix, max_new, eos_id=1, pad_id=0, candidates=None):
@@ -95,8 +103,11 @@ def run(state=None, reps=3, many=None, one_by_one=True):
     # advance in lockstep, their pending compares share an engine call; identical rankings, amortised time per query
     NQ = int(os.environ.get("RK_MANY", "4")) if many is None else many
     qtexts = ["which passage mentions the most relevant words"] + [" ".join(rs.choice(vocab) for _ in range(7)) for _ in range(NQ - 1)]
-    for scoring in (("likelihood", "generation") if NQ > 1 else ()):
+    variants = [("likelihood", False), ("likelihood", True), ("generation", True)] if NQ > 1 else []
+    for scoring, alternate in variants:
+        # (likelihood: the chains as two groups alternating over the engine's slots - the default - and as one group)
         rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=10, k=10, scoring=scoring, method="heapsort")
+        rk.alternate_groups = alternate
         best, res0, n_tok = None, None, 0
         for rep in range(reps):
             items = [(q, [SearchResult(docid=d, score=s, text=rk.truncate(t, 128)) for d, s, t in docs]) for q in qtexts]
@@ -110,7 +121,7 @@ def run(state=None, reps=3, many=None, one_by_one=True):
         n_cmp = sum(c[0] for c in counters)
         avg_len = sum(c[1] for c in counters) / max(n_cmp, 1)
         tf = n_cmp * bench.algorithmic_gflop_per_passage(dims, avg_len, 2) / 1e3 / best
-        out[f"{scoring}_many{NQ}"] = {"ms_per_query": round(best * 1e3 / NQ, 1), "queries_per_call": NQ, "compares": n_cmp,
+        out[f"{scoring}_many{NQ}" + ("" if alternate else "_one_group")] = {"ms_per_query": round(best * 1e3 / NQ, 1), "queries_per_call": NQ, "compares": n_cmp,
                                       "algorithmic_tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / 2500.0, 4)}
     if os.environ.get("RK_HOSTPROF"):                       # where the host time of one query goes (stderr)
         import cProfile, pstats
