@@ -1016,7 +1016,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
 #if GEMM_PP2_ASMDMA
     const unsigned dst = lds0 + (unsigned)(((kind * 2 + stage) * HALF + (wave * 2 + j) * 512) * 2);
     const unsigned o = off[kind][j];                      // (asm operands cannot name a captured array element)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(o), "s"(base) : "memory");
+    // (M0 is written here: it is on the clobber list so that the compiler never keeps a value of its own in it across the statement)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(o), "s"(base) : "memory", "m0");
 #else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[kind][j]),
                                      (__attribute__((address_space(3))) void*)(smem + (kind * 2 + stage) * HALF + (wave * 2 + j) * 512),

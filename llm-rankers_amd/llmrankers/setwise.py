@@ -523,16 +523,27 @@ class SetwiseLlmRanker(LlmRanker):
                 return True
 
             ok = True
-            for g in (0, 1):
-                if ok and groups[g]:
-                    ok = submit(g)
-            while ok and inflight:
-                g, order, launched = inflight.pop(0)
-                groups[g] = advance(groups[g], order, *self._collect_windows(launched))
-                if groups[g]:
-                    ok = submit(g)
-            for g, order, launched in inflight:                      # (only after a call that did not fit)
-                groups[g] = advance(groups[g], order, *self._collect_windows(launched))
+            try:
+                for g in (0, 1):
+                    if ok and groups[g]:
+                        ok = submit(g)
+                while ok and inflight:
+                    g, order, launched = inflight.pop(0)
+                    groups[g] = advance(groups[g], order, *self._collect_windows(launched))
+                    if groups[g]:
+                        ok = submit(g)
+                while inflight:                                      # (only after a call that did not fit)
+                    g, order, launched = inflight.pop(0)
+                    groups[g] = advance(groups[g], order, *self._collect_windows(launched))
+            finally:
+                # whatever raised above (a tokenizer error, a capacity error of the other group's launch): a call still queued on
+                # its slot is collected before the exception leaves - score_async's contract is that nothing else runs on the
+                # engine until then, and the caller's next rerank() would
+                for _, _, launched in inflight:
+                    try:
+                        self._collect_windows(launched)
+                    except Exception:
+                        pass
             pending = {**groups[0], **groups[1]}
         while pending:
             order, queries, windows = windows_of(pending)

@@ -96,9 +96,44 @@ def read_run_lines(path):
 
 
 def part_files(save_path):
-    """Per-rank part files of a --resume run in query-replica mode (`<save_path>.rank<N>`), any world size."""
+    """Per-rank part files of a --resume run in query-replica mode (`<save_path>.rank<N>`, N decimal), any world size.
+    Anything else that happens to match the prefix (`.rank0.bak`, editor backups) is not a part file."""
     import glob
-    return sorted(glob.glob(glob.escape(save_path) + ".rank*"))
+    import re
+    pat = re.compile(re.escape(save_path) + r"\.rank[0-9]+$")
+    return sorted(f for f in glob.glob(glob.escape(save_path) + ".rank*") if pat.match(f))
+
+
+def complete_run_blocks(path, expected):
+    """{qid: [raw lines]} of the queries whose block in a (partial) run file is COMPLETE: exactly expected[qid] well-formed
+    lines (six fields), every one newline-terminated.  A process killed in the middle of an append leaves a short block or a
+    cut last line: such a query is not done - it is ranked again and its partial block is dropped (never merged).
+    qids that `expected` does not know (another query set) are kept as they are."""
+    blocks = {}
+    for qid, lines in read_run_lines_raw(path).items():
+        ok = all(l.endswith("\n") and len(l.split()) == 6 for l in lines)
+        if ok and (qid not in expected or len(lines) == expected[qid]):
+            blocks[qid] = lines
+    return blocks
+
+
+def read_run_lines_raw(path):
+    """{qid: [raw lines, exactly as in the file]} of a (partial) run file, qids in file order."""
+    out = {}
+    try:
+        with open(path) as f:
+            for line in f:
+                parts = line.split()
+                if parts:
+                    out.setdefault(parts[0], []).append(line)
+    except FileNotFoundError:
+        pass
+    return out
+
+
+def _auto_per_call(kind, hits):
+    from llmrankers._batching import default_queries_per_call
+    return default_queries_per_call(kind, hits)
 
 
 def split_into_shards(data, num_shards):
@@ -293,14 +328,27 @@ def main(args):
         first_stage = all_shards[rank]
     writer = rank == 0                                               # candidate sharding: every rank holds every ranking
     resume = bool(getattr(args.run, "resume", False))
-    done = set(read_run_qids(args.run.save_path)) if resume else set()
+    # a query is done only if its block is complete (as many lines as it has candidates, the last one newline-terminated)
+    expected = {qid: len(ranking) for qid, _, ranking in (item for shard in (all_shards or [first_stage]) for item in shard)}
+    done = set()
+    if resume:
+        kept = complete_run_blocks(args.run.save_path, expected)
+        done = set(kept)
+        if writer and set(read_run_qids(args.run.save_path)) - done:
+            # a cut block at the end of --save_path (killed mid-append): rewritten without it, so that the re-ranked query is
+            # not appended behind its own fragment
+            tmp = args.run.save_path + ".clean"
+            with open(tmp, "w") as f:
+                for lines in kept.values():
+                    f.writelines(lines)
+            os.replace(tmp, args.run.save_path)
     # query replicas under --resume: every rank appends ITS finished queries to <save_path>.rank<N> after every call (durable
     # like the single-process form, ref: Rank-R1/run_setwise.py:79-87); a restart - with any number of ranks - skips what any
     # part file holds, and rank 0 merges the parts into --save_path at the end
     my_part = f"{args.run.save_path}.rank{rank}" if (resume and replicas) else None
     if resume and replicas:
         for pf in part_files(args.run.save_path):
-            done.update(read_run_qids(pf))
+            done.update(complete_run_blocks(pf, expected))
     if done:
         print(f"{args.run.save_path} exists. Continue ranking ({len(done)} queries done)")
     first_stage_order = {qid: [d.docid for d in ranking] for qid, _, ranking in first_stage}
@@ -394,12 +442,13 @@ def main(args):
     print(f"Avg time per query: {(toc - tic) / n}")
     if replicas and resume:
         # merge: what --save_path already held, then every rank's part file (all flushed: the barrier above), in first-stage order
-        merged = read_run_lines(args.run.save_path)
+        merged = complete_run_blocks(args.run.save_path, expected)
         parts_now = part_files(args.run.save_path)
         for pf in parts_now:
-            for qid, lines in read_run_lines(pf).items():
+            for qid, lines in complete_run_blocks(pf, expected).items():
                 merged.setdefault(qid, lines)
-        order = [q for q in merged if q not in set(all_qids)] + [q for q in all_qids if q in merged]
+        qset = set(all_qids)
+        order = [q for q in merged if q not in qset] + [q for q in all_qids if q in merged]
         tmp = args.run.save_path + ".merge"
         with open(tmp, "w") as f:
             for q in order:
@@ -451,8 +500,10 @@ def build_parser():
                          "RCCL, 0 deals whole queries to the ranks")
     rp.add_argument("--queries_per_call", type=int, default=0,
                     help="pointwise / setwise: queries handed to the engine together (same rankings and counters as one at a time); "
-                         "0 = auto: pointwise enough queries for >= 512 passages per call (6 at hits=100), setwise 8; "
-                         "1 = the reference's one query at a time")
+                         "0 = auto (llmrankers._batching.default_queries_per_call): pointwise enough queries for >= 1600 passages "
+                         f"per call, at most 16 ({_auto_per_call('pointwise', 100)} at hits=100), setwise {_auto_per_call('setwise', 100)} "
+                         "heapsorts in lockstep; with --resume the run file is appended once per call, i.e. every that many queries; "
+                         "1 = the reference's one query at a time (and its per-query flush)")
     pw = commands.add_parser("pointwise")
     pw.add_argument("--method", type=str, default="yes_no", choices=["qlm", "yes_no"])
     pw.add_argument("--batch_size", type=int, default=2)

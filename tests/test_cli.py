@@ -130,6 +130,18 @@ def test_resume_appends_and_skips_done_queries(runmod, tmp_path, ckpt_dirs, monk
     del calls[:]
     run(part, ["--resume"])
     assert part.read_text() == full and calls == []                              # nothing left to do
+    # killed in the middle of an append: q2's block is short and its last line is cut - q2 is NOT done, its fragment goes
+    fl = full.splitlines()
+    part.write_text("".join(l + "\n" for l in fl[:6]) + fl[6][:9])
+    del calls[:]
+    run(part, ["--resume"])
+    assert part.read_text() == full and len(calls) == 2                          # q2 (again) and q3
+    # part files are `<save_path>.rank<N>` only; a complete block has as many well-formed lines as the query has candidates
+    for name in ("x.trec.rank0", "x.trec.rank12", "x.trec.rank0.bak", "x.trec.rankings"):
+        (tmp_path / name).write_text("")
+    assert [os.path.basename(f) for f in runmod.part_files(str(tmp_path / "x.trec"))] == ["x.trec.rank0", "x.trec.rank12"]
+    (tmp_path / "x.trec.rank0").write_text("".join(l + "\n" for l in fl[:7]))
+    assert list(runmod.complete_run_blocks(str(tmp_path / "x.trec.rank0"), {"q1": 4, "q2": 4})) == ["q1"]
     # query shards: two processes, each its half, together the whole run
     run(tmp_path / "s0.trec", ["--dataset_number_of_shards", "2", "--dataset_shard_index", "0"])
     run(tmp_path / "s1.trec", ["--dataset_number_of_shards", "2", "--dataset_shard_index", "1"])

@@ -116,6 +116,11 @@ def test_pingpong_gemm_k_loop_keeps_loads_in_flight(isa, epi, rs):
     assert not any("v_lshl_add_u64" in l for l in kloop)
     assert not any(re.search(r"vmcnt\(0\)", l) for l in kloop), "the K loop drains the DMA queue"
     assert sum("s_barrier" in l for l in kloop) == 4
+    # M0 belongs to the hand-written DMA statements (it is on their clobber list): nothing else in the kernel reads or writes it
+    for i, l in enumerate(body):
+        code = l.split(";")[0]
+        if re.search(r"\bm0\b", code):
+            assert re.match(r"\s*s_mov_b32 m0, s\d+", code) and "ASMSTART" in body[i - 1], f"M0 used outside the DMA statements: {l.strip()}"
 
 
 @pytest.mark.parametrize("name", ["_Z19dec_cross_qk_kernel9DecQKArgs", "_Z19dec_cross_cv_kernel9DecCVArgs"])

@@ -143,3 +143,44 @@ def test_llama3_rope_scaling_oracle_matches_hf():
     plain = LlamaOracle(_synth.LlamaDims(**{**dims.__dict__, "rope_scaling": None}), state).last_logits(seqs)
     assert np.abs(plain - g["last_logits"]).max() > 50 * 2e-4
 
+
+
+def test_hf_path_equals_reference_goldens(ckpt_dirs):
+    """The timed CPU baseline of bench.py (oracle/hf_path.py: build_hf_model + pointwise_yes_no, the restatement of
+    ref: llmrankers/pointwise.py:84-127 on pre-tokenised prompts) gives the scores the REAL reference recorded on the fixture
+    checkpoints (tests/golden/rerank_cases.json, tools/make_goldens.py imports /root/reference): every yes_no case, both
+    checkpoints (gated / untied head and relu / tied + scaled head), the reference's own batches (batch_size 4 and 32 - padded
+    to the batch's longest prompt like DataCollatorWithPadding does) - scores to 1e-6, order and counters exactly."""
+    from transformers import T5Tokenizer
+    from llmrankers.pointwise import PointwiseLlmRanker
+    from llmrankers.rankers import SearchResult
+    from oracle import hf_path
+
+    class HfPathRuntime:                       # PointwiseLlmRanker's runtime interface over the baseline port, batch by batch
+        model_type = "t5"
+        decoder_start_token_id = 0
+
+        def __init__(self, dims, state):
+            self.model, self.config, self.calls = hf_path.build_hf_model(dims, state), dims.to_hf_config(), 0
+
+        def score(self, seqs, dec_prefix, out_ids):
+            assert list(dec_prefix) == [0] and len(out_ids) == 2
+            self.calls += 1
+            return hf_path.pointwise_yes_no(self.model, [list(s) for s in seqs], len(seqs), out_ids[0], out_ids[1])
+
+    with open(os.path.join(GOLD, "rerank_cases.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["kind"] == "pointwise" and c["method"] == "yes_no"]
+    assert len(cases) >= 8 and {c["ckpt"] for c in cases} == {"ckpt_gated_untied", "ckpt_relu_tied"}
+    rts = {}
+    for case in cases:
+        ck = ckpt_dirs[case["ckpt"]]
+        if case["ckpt"] not in rts:
+            rts[case["ckpt"]] = (HfPathRuntime(*load_state(ck)), T5Tokenizer.from_pretrained(ck))
+        rt, tok = rts[case["ckpt"]]
+        ranker = PointwiseLlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=case["batch_size"])
+        before = rt.calls
+        res = ranker.rerank(case["query"], [SearchResult(docid=d, score=s, text=t) for d, s, t in case["input"]])
+        assert [r.docid for r in res] == [d for d, _ in case["result"]]
+        np.testing.assert_allclose([r.score for r in res], [s for _, s in case["result"]], atol=1e-6, rtol=0)
+        assert [ranker.total_compare, ranker.total_prompt_tokens, ranker.total_completion_tokens] == case["counters"]
+        assert rt.calls - before == case["counters"][0]            # one HF forward per reference batch
