@@ -22,6 +22,32 @@ def _tokenize_full(tokenizer, prompts: Sequence[str]) -> List[List[int]]:
 _PLAIN_RE = re.compile(r"[\x20-\x7e\n]*")      # printable ASCII and newlines (one C-level scan per prompt)
 
 
+class _MemoMismatch(Exception):
+    pass
+
+
+# normalisers that cannot act across a word boundary of printable-ASCII text (character-level maps); a Replace only in the
+# T5 form that collapses runs of blanks (the words are the same) or with a blank-free literal pattern
+_SAFE_NORMALIZERS = {"NFC", "NFD", "NFKC", "NFKD", "Precompiled", "Nmt", "Lowercase", "StripAccents"}
+
+
+def _normalizer_is_word_local(norm) -> bool:
+    if norm is None:
+        return True
+    t = norm.get("type")
+    if t == "Sequence":
+        return all(_normalizer_is_word_local(n) for n in norm.get("normalizers", []))
+    if t in _SAFE_NORMALIZERS:
+        return True
+    if t == "Replace":
+        pat = norm.get("pattern") or {}
+        if pat.get("Regex") == " {2,}" and norm.get("content") == " ":
+            return True
+        lit = pat.get("String")
+        return isinstance(lit, str) and lit != "" and not any(c.isspace() for c in lit) and not any(c.isspace() for c in norm.get("content", ""))
+    return False
+
+
 class WordSpliceTokenizer:
     """Exact memo of a whitespace-pre-tokenised sentencepiece tokenizer (host tokenisation).
 
@@ -32,8 +58,13 @@ class WordSpliceTokenizer:
     concatenation of the ids of its words, so each distinct word is tokenised once and a prompt becomes dictionary
     look-ups.  Only tokenizers whose backend says exactly that are handled (anything else - BPE with a regex
     pre-tokenizer, a Metaspace without the whitespace split - goes to the tokenizer as before), and the result is
-    compared with the tokenizer's own on the first prompts and then at a fixed stride; the first difference
-    switches the memo off for good.  `RK_TOKEN_CACHE=0` disables it.
+    checked as it runs: (a) every NEW word is verified IN CONTEXT the first time it is seen - the window {previous word,
+    the word, next word} of the first prompt that contains it goes to the tokenizer in the same call that tokenises the
+    word alone, and its ids must be the concatenation of the three words' ids; (b) whole prompts are compared with the
+    tokenizer's own on the first prompts and then at a fixed stride.  The first difference switches the memo off for good
+    and the pending call is re-tokenised by the tokenizer itself, so a call never returns ids the check has just
+    contradicted; the warning says how many prompts had been spliced since the last whole-prompt comparison.
+    `RK_TOKEN_CACHE=0` disables the memo.
     """
     # words are cut at ' ' and '\n' only: separators both before and after the normaliser; other blanks stay inside a "word"
     MAX_WORDS = 2_000_000
@@ -43,6 +74,7 @@ class WordSpliceTokenizer:
         self.words = {}
         self.verify_first, self.verify_every = verify_first, verify_every
         self.seen = 0
+        self.since_check = 0            # prompts returned since the last whole-prompt comparison (reported on a mismatch)
         self.suffix: List[int] = []
         self.enabled = os.environ.get("RK_TOKEN_CACHE", "1") != "0" and self._eligible(tokenizer)
         if self.enabled:
@@ -69,6 +101,8 @@ class WordSpliceTokenizer:
                     return False
             if (cfg.get("model") or {}).get("type") != "Unigram":
                 return False
+            if not _normalizer_is_word_local(cfg.get("normalizer")):
+                return False        # e.g. a regex Replace that can match across a blank: words are not independent
             post = cfg.get("post_processor")
             if post is not None:
                 single = post.get("single") if post.get("type") == "TemplateProcessing" else None
@@ -93,8 +127,22 @@ class WordSpliceTokenizer:
             words.clear()
             missing = {w for ws in pieces for w in ws}
         order = list(missing)
-        for w, ids in zip(order, self.tokenizer(order, add_special_tokens=False)["input_ids"]):
+        # the first context of every new word: (previous word, the word, next word) of the first prompt that holds it
+        windows, todo = [], set(missing)
+        for ws in pieces:
+            if not todo:
+                break
+            for i, w in enumerate(ws):
+                if w in todo:
+                    todo.discard(w)
+                    if len(ws) > 1:
+                        windows.append(ws[max(0, i - 1):i + 2])
+        got = self.tokenizer(order + [" ".join(win) for win in windows], add_special_tokens=False)["input_ids"]
+        for w, ids in zip(order, got):
             words[w] = tuple(ids)
+        for win, ids in zip(windows, got[len(order):]):
+            if list(chain.from_iterable(map(words.__getitem__, win))) != list(ids):
+                raise _MemoMismatch(" ".join(win))
         return [list(chain.from_iterable(map(words.__getitem__, ws))) + suffix for ws in pieces]
 
     @staticmethod
@@ -113,17 +161,23 @@ class WordSpliceTokenizer:
             rest_ids = iter(_tokenize_full(self.tokenizer, rest))
             plain_ids = iter(self([p for p, ok in zip(prompts, plain) if ok]) if any(plain) else [])
             return [next(plain_ids) if ok else next(rest_ids) for ok in plain]
-        out = self._splice(prompts)
-        for i in range(len(prompts)):
-            n = self.seen + i
-            if n < self.verify_first or n % self.verify_every == 0:
-                want = _tokenize_full(self.tokenizer, [prompts[i]])[0]
-                if want != out[i]:
-                    warnings.warn("word-level token memo disagrees with the tokenizer; switched off")
-                    self.enabled = False
-                    self.words.clear()
-                    return _tokenize_full(self.tokenizer, prompts)
+        try:
+            out = self._splice(prompts)
+            for i in range(len(prompts)):
+                n = self.seen + i
+                if n < self.verify_first or n % self.verify_every == 0:
+                    if _tokenize_full(self.tokenizer, [prompts[i]])[0] != out[i]:
+                        raise _MemoMismatch(prompts[i][:80])
+                    self.since_check = -i - 1          # (prompts of this call behind i are counted below)
+        except _MemoMismatch as exc:
+            warnings.warn(f"word-level token memo disagrees with the tokenizer ({str(exc)!r}); switched off - this call is "
+                          f"tokenised by the tokenizer itself; {max(self.since_check, 0)} prompt(s) of earlier calls had been "
+                          "spliced since the last whole-prompt comparison")
+            self.enabled = False
+            self.words.clear()
+            return _tokenize_full(self.tokenizer, prompts)
         self.seen += len(prompts)
+        self.since_check += len(prompts)
         return out
 
 

@@ -110,3 +110,58 @@ def test_non_plain_prompts_bypass_the_memo():
     memo._splice = lambda ps: (calls.append(list(ps)), orig(ps))[1]
     assert memo(prompts) == _tokenize_full(tok, prompts)
     assert calls and all(memo._plain(p) for c in calls for p in c)
+
+
+def test_every_new_word_is_verified_in_its_first_context(tok):
+    """Whole-prompt sampling switched off entirely: a word whose ids depend on having a neighbour is caught the first time it
+    appears, by the (previous, word, next) window that travels with the new words - the call that would have been wrong is
+    re-tokenised by the tokenizer, and the memo stays off."""
+    class NeighbourDependent:
+        """T5 backend; any text that holds the word 'magic' next to another word gets an extra id after it."""
+        backend_tokenizer = tok.backend_tokenizer
+
+        def __call__(self, texts, **kw):
+            single = isinstance(texts, str)
+            tl = [texts] if single else list(texts)
+            out = []
+            for ids, t in zip(tok(tl, **kw)["input_ids"], tl):
+                ids = list(ids)
+                ws = t.split()
+                if "magic" in ws and len(ws) > 1:
+                    k = len(tok(" ".join(ws[:ws.index("magic") + 1]), add_special_tokens=False)["input_ids"])
+                    ids.insert(k, 7)
+                out.append(ids)
+            return {"input_ids": out[0] if single else out}
+
+    fake = NeighbourDependent()
+    memo = WordSpliceTokenizer(fake, verify_first=0, verify_every=10 ** 9)
+    assert memo.enabled
+    warm = ["plain words only", "more plain words here"]
+    assert memo(warm) == fake(warm)["input_ids"] and memo.enabled
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = memo(["plain words", "some magic here", "words only"])
+    assert got == fake(["plain words", "some magic here", "words only"])["input_ids"]
+    assert not memo.enabled and w and "switched off" in str(w[0].message) and "1 prompt(s)" in str(w[0].message)   # (prompt 0 was a whole-prompt comparison)
+
+
+def test_a_normaliser_that_can_reach_across_a_blank_makes_the_tokenizer_ineligible(tok, tmp_path):
+    """Adversarial backend: the T5 pipeline plus a regex Replace that glues 'river water' into one word - the ids of 'water'
+    then depend on the word in front of it, and both words may be known before they first meet.  Such a tokenizer is not
+    spliced at all (the eligibility gate reads the normaliser); the T5 forms - none, NFKC / Precompiled, the blank-collapsing
+    Replace - still are."""
+    from tokenizers import Regex, Tokenizer, normalizers
+    from transformers import PreTrainedTokenizerFast
+    backend = Tokenizer.from_str(tok.backend_tokenizer.to_str())
+    backend.normalizer = normalizers.Sequence([normalizers.NFKC(), normalizers.Replace(Regex("river water"), "riverwater")])
+    glued = PreTrainedTokenizerFast(tokenizer_object=backend, eos_token="</s>", pad_token="<pad>", unk_token="<unk>")
+    memo = WordSpliceTokenizer(glued)
+    assert not memo.enabled
+    prompts = ["water", "river", "the river water flows", "river  water"]
+    assert memo(prompts) == full(glued, prompts)
+    assert full(glued, ["the river water flows"]) != [full(glued, ["the river"])[0][:-1] + full(glued, ["water flows"])[0]]   # (it IS context dependent)
+    backend.normalizer = normalizers.Sequence([normalizers.NFKC(), normalizers.Replace(Regex(" {2,}"), " ")])
+    t5like = PreTrainedTokenizerFast(tokenizer_object=backend, eos_token="</s>", pad_token="<pad>", unk_token="<unk>")
+    memo = WordSpliceTokenizer(t5like, verify_first=0, verify_every=10 ** 9)
+    assert memo.enabled
+    assert memo(prompts) == full(t5like, prompts) and memo.enabled
