@@ -86,7 +86,7 @@ def parse_args():
                     help="weak: every rank scores its own batches (throughput); shard: one query's hits=100 candidates cut over the ranks, one gather per query")
     ap.add_argument("--hits", type=int, default=100, help="shard mode: candidates per query")
     ap.add_argument("--regions", type=int, default=3, help="timed regions of exactly --steps steps each; the median is reported")
-    ap.add_argument("--no_extras", action="store_true", help="skip the ragged (S2) and setwise (S3) legs after the timed region")
+    ap.add_argument("--no_extras", action="store_true", help="skip the legs after the timed region: ragged (S2), one rank's shard share, setwise (S3), flan-t5-xl qlm (configs[3]), Llama-3-8B compare (configs[4])")
     ap.add_argument("--cpu_batch", type=int, default=32, help="batch size of the cpu_baseline leg (BASELINE.md section 3: 32)")
     ap.add_argument("--dry_ranks", action="store_true",
                     help="no GPU: N gloo ranks over tools/dry_engine.py walk the multi-rank control flow (communicator bring-up, "
@@ -214,12 +214,62 @@ def setwise_leg(state):
     spec = importlib.util.spec_from_file_location("rk_bench_setwise", os.path.join(REPO, "tools", "bench_setwise_query.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    res = mod.run(state=state, reps=2, many=8, one_by_one=False)
+    # 140-word passages are cut to the full 128 tokens of run.py's default --passage_length and the query is ~31 tokens: prompts
+    # of ~1.56k tokens = S3's 11 x 134 + 32 + 30 (rounds 1-4 ran this leg on 60-word passages: ~0.9k-token prompts)
+    res = mod.run(state=state, reps=2, many=8, one_by_one=False, words=140, query_words=24)
     for v in res.values():
         v.pop("top10", None)
-    res["workload"] = "S3: flan-t5-large dims, setwise heapsort, hits=100 num_child=10 k=10, 60-word passages (fixture tokenizer), " \
-                      "level-batched build phase; *_many8 = eight queries ranked in lockstep (SetwiseLlmRanker.rerank_many = run.py's default for setwise)"
+    res["workload"] = "S3 at its stated size: flan-t5-large dims, setwise heapsort, hits=100 num_child=10 k=10, 128-token passages + " \
+                      "~31-token query (fixture tokenizer; avg_prompt_tokens per compare is reported), level-batched build phase; " \
+                      "*_many8 = eight queries ranked in lockstep (SetwiseLlmRanker.rerank_many = run.py's default for setwise)"
     return res
+
+
+def _tool(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rk_" + name, os.path.join(REPO, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def qlm_xl_leg():
+    """BASELINE configs[3]: flan-t5-xl dims, pointwise qlm, hits=100 through PointwiseLlmRanker.rerank (tools/bench_qlm_xl.py), and
+    the 13-passage share one of eight ranks scores of the doc-sharded query."""
+    mod = _tool("bench_qlm_xl")
+    res = mod.run(reps=5)
+    try:
+        share = mod.run(reps=5, shard=8)
+        res["share_of_8_ranks"] = {k: share[k] for k in ("workload", "ms_per_query", "passages_per_s", "frac_of_mfma_peak")}
+        res["share_of_8_ranks"]["predicted_8gpu_passages_per_s"] = round(100.0 / share["ms_per_query"] * 1e3, 1)
+    except Exception as exc:
+        res["share_of_8_ranks"] = {"error": repr(exc)[:300]}
+    return res
+
+
+def llama_leg():
+    """BASELINE configs[4]: Llama-3-8B dims at full depth, one setwise generation compare (tools/bench_llama.py)."""
+    return _tool("bench_llama").run(layers=32, L=1536, pool=True, iters=5, profile=True)
+
+
+def shard_share_leg(eng, dims, L, hits=100, world=8, steps=40):
+    """What ONE of `world` ranks does per query in --mode shard (strong scaling): its 13-passage share of a hits=100 query per
+    step through the two slots, no collective (one rank).  100 / (ms per step) is the 1-GPU prediction of the 8-GPU
+    strong-scaling number (the gather adds one ~20 us collective per query)."""
+    from llmrankers import _synth
+    from llmrankers._dist import shard_bounds
+    lo, hi = shard_bounds(hits, world)[0]
+    n_slots = eng.num_slots
+    queries = [_synth.synth_token_batch(hits, L, L, dims.vocab, seed=4000 + q) for q in range(n_slots)]
+    pipe = ShardPipeline(eng, [q[lo:hi] for q in queries], [0], [YES_ID, NO_ID], 1, hi - lo)
+    pipe.stage_all()
+    elapsed, _ = timed_run(eng, pipe, steps, 8, eng.sync)
+    ms = elapsed / steps * 1e3
+    gfl = algorithmic_gflop_per_passage(dims, L) * (hi - lo)
+    return {"workload": f"one rank's share of ONE query per step: {hi - lo} of hits={hits} candidates (world = {world}), L_e={L}, {steps} steps",
+            "ms_per_step": round(ms, 3), "share_passages_per_s": round((hi - lo) / ms * 1e3, 1),
+            "predicted_8gpu_strong_scaling_passages_per_s": round(hits / ms * 1e3, 1),
+            "frac_of_mfma_peak_per_gpu": round(gfl / ms / MFMA_PEAK_TFLOPS, 4)}
 
 
 def profile_pass(eng, pipe, G, M_tokens):
@@ -486,6 +536,11 @@ def main():
         except Exception as exc:                      # never take the headline number down
             extras["ragged"] = {"error": repr(exc)[:300]}
 
+        try:
+            extras["shard_share"] = shard_share_leg(eng, dims, L, args.hits)
+        except Exception as exc:
+            extras["shard_share"] = {"error": repr(exc)[:300]}
+
     per_query = None
     if rank == 0 and world == 1 and not args.no_per_query:
         per_query = per_query_numbers(eng, dims, B, L)
@@ -510,6 +565,14 @@ def main():
             extras["setwise_query"] = setwise_leg(state)
         except Exception as exc:
             extras["setwise_query"] = {"error": repr(exc)[:300]}
+        del state
+        for key, leg in (("qlm_xl", qlm_xl_leg), ("llama_compare", llama_leg)):
+            t_leg = time.time()
+            try:
+                extras[key] = leg()
+            except Exception as exc:
+                extras[key] = {"error": repr(exc)[:300]}
+            print(f"[bench] leg {key}: {time.time() - t_leg:.0f}s", file=sys.stderr)
 
     if rank == 0:
         passages = args.steps * (args.hits if shard else B * world)
@@ -539,7 +602,8 @@ def main():
                                               "the exact query-side form (DESIGN.md section 3)",
                        "whole_path_tflops_per_gpu": round(value / world * gfl / 1e3, 1),
                        "whole_path_frac_of_mfma_peak": round(value / world * gfl / 1e3 / MFMA_PEAK_TFLOPS, 4),
-                       "per_query": per_query, "ragged": extras.get("ragged"), "setwise_query": extras.get("setwise_query")},
+                       "per_query": per_query, "ragged": extras.get("ragged"), "shard_share": extras.get("shard_share"),
+                       "setwise_query": extras.get("setwise_query"), "qlm_xl": extras.get("qlm_xl"), "llama_compare": extras.get("llama_compare")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -311,6 +311,18 @@ class T5Runtime:
     def qlm(self, seqs, labels) -> np.ndarray:
         return np.concatenate([self.engine.qlm(c, labels) for c in self._chunks(seqs)], axis=0)
 
+    def qlm_batches(self, batches, labels) -> List[np.ndarray]:
+        """qlm scores of several batches of ONE query (same labels): the reference's batch_size only shapes its host loop and a
+        passage's score does not depend on what shares its call, so the batches go to the engine merged up to its capacity -
+        one encoder / decoder / head sequence over the query's candidates instead of one per batch of 32."""
+        batches = list(batches)
+        allsc = self.qlm([s for b in batches for s in b], labels) if batches else np.zeros(0, np.float32)
+        out, pos = [], 0
+        for b in batches:
+            out.append(allsc[pos:pos + len(b)])
+            pos += len(b)
+        return out
+
     supports_greedy_candidates = True
 
     def greedy(self, seqs, dec_prefix, max_new, eos_id=1, pad_id=0, candidates=None) -> np.ndarray:

@@ -284,6 +284,41 @@ def synth_tensors(d, seed: int = 929, gain: float = 1.0, threads: int = 0) -> It
             yield res
 
 
+def synth_tensors_pool(d, seed: int = 929, pool_log2: int = 25) -> Iterator[Tuple[str, np.ndarray]]:
+    """TIMING-ONLY weights for the multi-billion-parameter bench legs (flan-t5-xl, Llama-3-8B): the same names, shapes and
+    per-tensor standard deviations as synth_tensors, but every tensor is a window into ONE pool of 2^pool_log2 counter-generated
+    standard normals (pre-scaled per distinct std, fp16), at a per-tensor offset.  Statistically the same operand bits for the
+    matrix cores (their power draw depends on the data) at a fraction of the host time: Llama-3-8B in seconds instead of two
+    minutes.  NOT for parity work - tensors overlap, and goldens are made from synth_tensors."""
+    specs = list(llama_tensor_specs(d) if isinstance(d, LlamaDims) else tensor_specs(d))
+    n_pool = 1 << pool_log2
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex:       # numpy ufuncs release the GIL
+        z = np.concatenate([r[1] for r in ex.map(_make_tensor, [(1000 + i, "pool", (1 << 22,), 1.0, False, seed, 1.0)
+                                                                 for i in range(n_pool >> 22)])])
+    pools = {}
+    for stream, (name, shape, std, is_norm) in enumerate(specs):
+        n = int(np.prod(shape))
+        if is_norm:
+            yield name, _fp16_round(1.0 + std * z[(stream * 7919) % 4096:][:n])
+            continue
+        if std not in pools:
+            pools[std] = (z * np.float32(std)).astype(np.float16)
+        pool = pools[std]
+        off = (stream * 2654435761) % (n_pool - min(n, n_pool - 1))
+        if n <= n_pool - off:
+            yield name, pool[off:off + n].reshape(shape)
+        else:                                           # a tensor larger than the pool (embedding / head of a 128k vocabulary)
+            out, pos, r = np.empty(n, dtype=np.float16), 0, 0
+            while pos < n:                                  # pool-sized pieces, each starting at its own offset (wrapping)
+                o = (off * (r + 1) + r * 104729) % n_pool
+                m = min(n_pool - o, n - pos)
+                out[pos:pos + m] = pool[o:o + m]
+                pos, r = pos + m, r + 1
+            yield name, out.reshape(shape)
+
+
 def synth_state_dict(d, seed: int = 929, gain: float = 1.0, threads: int = 0) -> Dict[str, np.ndarray]:
     return dict(synth_tensors(d, seed, gain, threads))
 

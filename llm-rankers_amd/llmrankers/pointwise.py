@@ -117,6 +117,8 @@ class PointwiseLlmRanker(LlmRanker):
         if not chunks:
             return np.zeros((0, len(out_ids)) if kind == "score" else (0,), np.float32)
         if kind == "qlm":
+            if hasattr(self.llm, "qlm_batches"):                 # one engine call for the query's batches (batch independence)
+                return np.concatenate([np.asarray(x, dtype=np.float32) for x in self.llm.qlm_batches(chunks, arg)])
             return np.concatenate([np.asarray(self.llm.qlm(c, arg), dtype=np.float32) for c in chunks])
         if hasattr(self.llm, "score_batches"):                   # pipelined across the engine's batch slots
             return np.concatenate(self.llm.score_batches(chunks, arg, out_ids), axis=0)

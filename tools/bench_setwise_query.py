@@ -46,14 +46,19 @@ class EngineRuntime:
         return toks
 
 
-def run(state=None, reps=3, many=None, one_by_one=True):
-    """-> dict of timings.  `state`: the synthetic flan-t5-large state dict if the caller already has it (bench.py)."""
+def run(state=None, reps=3, many=None, one_by_one=True, words=None, query_words=None):
+    """-> dict of timings.  `state`: the synthetic flan-t5-large state dict if the caller already has it (bench.py).
+    `words` per passage before truncate(128) (RK_WORDS, default 60 -> ~84-token passages, ~0.9k-token prompts with the fixture
+    tokenizer; 140 -> every passage is cut to the full 128 tokens of run.py's default --passage_length, prompts of ~1.5k
+    tokens = SURVEY 8d S3); `query_words` (RK_QUERY_WORDS, default 7; ~22 words = the 32-token query of S3)."""
     from transformers import T5Tokenizer
     tok = T5Tokenizer.from_pretrained(os.path.join(REPO, "tests", "golden", "tok"))
     dims = _synth.FLAN_T5_LARGE
     nq_cap = int(os.environ.get("RK_MANY", "4")) if many is None else many
+    words = int(os.environ.get("RK_WORDS", "60")) if words is None else words
+    query_words = int(os.environ.get("RK_QUERY_WORDS", "7")) if query_words is None else query_words
     # (this tool's runtime wrapper does not chunk: the build phase of NQ queries in lockstep is 9 NQ prompts of ~900 tokens)
-    eng = RkEngine(dims, 0, max_tokens=max(32768, 12000 * nq_cap), max_seqs=256, max_dec_len=8)
+    eng = RkEngine(dims, 0, max_tokens=max(32768, (20000 if words > 80 else 12000) * nq_cap), max_seqs=256, max_dec_len=8)
     # random weights would generate arbitrary tokens ("Unexpected output" on every compare): like the goldens
     # (tests/golden/setwise_large.json) the lm_head rows of the passage labels a prompt can hold (A .. K at num_child = 10)
     # and EOS are scaled x6, so that a generation is "<label> </s>" as with a trained checkpoint - the case the product
@@ -77,7 +82,8 @@ def run(state=None, reps=3, many=None, one_by_one=True):
     rs = random.Random(3)
     vocab = [tok.convert_ids_to_tokens(i).replace("\u2581", "") for i in range(10, 200)]
     vocab = [w for w in vocab if w.isalpha()] or ["a", "b", "c"]
-    docs = [(f"d{i}", float(100 - i), " ".join(rs.choice(vocab) for _ in range(60))) for i in range(100)]
+    docs = [(f"d{i}", float(100 - i), " ".join(rs.choice(vocab) for _ in range(words))) for i in range(100)]
+    query0 = "which passage mentions the most relevant words" if query_words == 7 else " ".join(rs.choice(vocab) for _ in range(query_words))
     out = {}
     for scoring in ("likelihood", "generation"):
         for batched in ((False, True) if one_by_one else (True,)):
@@ -89,7 +95,7 @@ def run(state=None, reps=3, many=None, one_by_one=True):
                 rk.total_compare = rk.total_prompt_tokens = rk.total_completion_tokens = 0
                 t0 = time.perf_counter()
                 with contextlib.redirect_stdout(io.StringIO()):
-                    res = rk.rerank("which passage mentions the most relevant words", ranking)
+                    res = rk.rerank(query0, ranking)
                 dt = time.perf_counter() - t0
                 best = dt if best is None else min(best, dt)
                 res0 = [r.docid for r in res][:10]
@@ -102,7 +108,7 @@ def run(state=None, reps=3, many=None, one_by_one=True):
     # several queries at once (SetwiseLlmRanker.rerank_many / run.py --queries_per_call): the dependency chains of NQ queries
     # advance in lockstep, their pending compares share an engine call; identical rankings, amortised time per query
     NQ = int(os.environ.get("RK_MANY", "4")) if many is None else many
-    qtexts = ["which passage mentions the most relevant words"] + [" ".join(rs.choice(vocab) for _ in range(7)) for _ in range(NQ - 1)]
+    qtexts = [query0] + [" ".join(rs.choice(vocab) for _ in range(query_words)) for _ in range(NQ - 1)]
     variants = [("likelihood", False), ("likelihood", True), ("generation", True)] if NQ > 1 else []
     for scoring, alternate in variants:
         # (likelihood: the chains as two groups alternating over the engine's slots - the default - and as one group)
