@@ -275,7 +275,9 @@ __device__ __forceinline__ void gemm_epilogue_lse(const GemmArgs& p, f32x16 (&ac
 #ifndef GEMM_EPI_NT
 #define GEMM_EPI_NT 7
 #endif
-template <int EPI, int NI, int MI, bool RESID_IN_ACC = false, int ROWS = 32, int DEPTH = 0>
+// PUBLISH (gemm_chain.h): the fp16 copy of the stream and the block sums are read by OTHER workgroups of the same launch -
+// they leave as write-through stores (agent-scope relaxed atomic stores = `global_store ... sc1`), see the hand-off there.
+template <int EPI, int NI, int MI, bool RESID_IN_ACC = false, int ROWS = 32, int DEPTH = 0, bool PUBLISH = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase,
                                                      int lane, unsigned char* stage, const float (&rsc)[MI]) {
   if constexpr (EPI == EPI_LSE_F32) {
@@ -396,9 +398,15 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             ss = row16_sum_f(ss);                                // the 16 lanes of one row
             if (ok) {
               half4 xr = {f2h_sat(v[0] * p.xs), f2h_sat(v[1] * p.xs), f2h_sat(v[2] * p.xs), f2h_sat(v[3] * p.xs)};
+              if constexpr (PUBLISH) {
+                __hip_atomic_store((unsigned long long*)(p.xraw + (size_t)m * p.ldx + n), __builtin_bit_cast(unsigned long long, xr),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ch == 0) __hip_atomic_store(p.ssq + (size_t)m * p.nb + (ncol0 >> 6), ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              } else {
               if constexpr ((GEMM_EPI_NT & 8) != 0) __builtin_nontemporal_store(xr, (half4*)(p.xraw + (size_t)m * p.ldx + n));
               else *(half4*)(p.xraw + (size_t)m * p.ldx + n) = xr;
               if (ch == 0) p.ssq[(size_t)m * p.nb + (ncol0 >> 6)] = ss;
+              }
             }
           }
         }

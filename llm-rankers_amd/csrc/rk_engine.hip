@@ -24,6 +24,7 @@
 #include "attention.h"
 #include "decoder_kernels.h"
 #include "gemm.h"
+#include "gemm_chain.h"
 #include "llama_kernels.h"
 #include "misc_kernels.h"
 
@@ -33,10 +34,13 @@ thread_local std::string g_create_error;
 
 enum ProfClass {
   PC_ENC_GEMM_QKV = 0, PC_ENC_GEMM_O, PC_ENC_GEMM_FFN_IN, PC_ENC_GEMM_FFN_OUT, PC_ENC_ATTN, PC_GEMM_CROSS_KV,
-  PC_NORM, PC_EMBED, PC_DEC_GEMM, PC_DEC_ATTN, PC_HEAD, PC_OTHER, PC_COUNT
+  PC_NORM, PC_EMBED, PC_DEC_GEMM, PC_DEC_ATTN, PC_HEAD, PC_OTHER,
+  PC_ENC_CHAIN_O_FFN, PC_ENC_CHAIN_FFO_QKV,      // chained launches (gemm_chain.h): O -> FFN-in, FFN-out -> next layer's QKV
+  PC_COUNT
 };
 const char* kProfNames[PC_COUNT] = {"enc_gemm_qkv", "enc_gemm_o", "enc_gemm_ffn_in", "enc_gemm_ffn_out", "enc_attn",
-                                    "gemm_cross_kv", "norm", "embed", "dec_gemm", "dec_attn", "head", "other"};
+                                    "gemm_cross_kv", "norm", "embed", "dec_gemm", "dec_attn", "head", "other",
+                                    "enc_chain_o_ffn_in", "enc_chain_ffn_out_qkv"};
 
 struct HostTensor {
   std::vector<half_t> h;   // 2-D matrices (fp16, the reference's accelerator dtype)
@@ -73,6 +77,10 @@ struct Slot {
   hipStream_t se = nullptr, sd = nullptr;   // this slot's encoder chain (MFMA-bound) | decoder chain (latency-bound)
   float* hidden = nullptr; half_t *xn = nullptr, *qkv = nullptr, *ctx = nullptr, *ffh = nullptr, *enc_out = nullptr;
   half_t* xraw = nullptr; float *ssq = nullptr, *rowscale = nullptr;   // folded RMSNorm: fp16 stream x RK_XRAW_SCALE, block sums of squares, row factors
+  // chained GEMM launches (gemm_chain.h): queue heads of every launch of an encoder pass (zeroed once per pass), arrival tickets
+  // and ready flags per row panel (epoch-tagged: never zeroed), the host-visible error word of a timed-out hand-off
+  int* chain_heads = nullptr; int* chain_cnt = nullptr; unsigned* chain_flag = nullptr; unsigned chain_epoch = 0; int* chain_err = nullptr;
+  int chain_heads_cap = 0;
   int* d_tokens = nullptr; int* d_seq_off = nullptr;
   int n_seq = 0, T = 0, maxL = 0; bool staged = false; int last_n_out = 0;
   half_t* cross_kv = nullptr;                                  // [n_dec][max_tokens][2I] encoder -> decoder hand-off
@@ -107,7 +115,8 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 1, opt_chain_lead = 3, opt_chain_min_panels = 64;
+  unsigned long long* chain_trace = nullptr;   // measurement builds only (option chain_trace)
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
@@ -376,14 +385,63 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a_in, int for
                                 // channels of real T5 checkpoints (fp16 max 65504 -> 1.0e6), exact (power of two)
 struct GemmFold { const float* rowscale = nullptr; half_t* xraw = nullptr; float* ssq = nullptr; const float* ssq_in = nullptr; int nb_in = 0; };
 
-void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int lda, const half_t* W, int ldw, void* C,
-          int ldc, int M, int N, int K, int n_split = 0, long split_stride = 0, float scale = 1.f,
-          int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0, bool weight_streaming = false, GemmFold fold = GemmFold()) {
-  if (M <= 0) return;
+GemmArgs make_gemm_args(const rk_engine* e, const half_t* A, int lda, const half_t* W, int ldw, void* C, int ldc, int M, int N, int K,
+                        int n_split, long split_stride, float scale, long bsA, long bsW, long bsC, const GemmFold& fold) {
   GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale, bsA, bsW, bsC};
   a.rowscale = fold.rowscale; a.xraw = fold.xraw; a.ssq = fold.ssq; a.ldx = N; a.nb = (N + 63) / 64; a.xs = RK_XRAW_SCALE;
   a.ssq_in = fold.ssq_in; a.nb_in = fold.nb_in ? fold.nb_in : (K + 63) / 64; a.eps_in = e->d.eps;       // (tiled producers: 64-column blocks)
   a.group_n = e->opt_gemm_group_n > 0 ? e->opt_gemm_group_n : GEMM_GROUP_N;
+  return a;
+}
+
+// ---- chained launch (gemm_chain.h): producer = an fp32 residual GEMM that writes the folded-norm stream, consumer = the GEMM
+// behind the norm.  Same tile loop and epilogues as the separate ping-pong launches: same bits. ----
+bool chain_ok(const rk_engine* e, int M, int Np, int Kp, int Nc, int Kc) {
+  return e->opt_chain && e->opt_fold_norm && e->opt_gemm_persistent == 1 && !e->opt_gemm_variant &&
+         (M + 255) / 256 >= e->opt_chain_min_panels && Kp >= 128 && Kc >= 128 && Kp % 64 == 0 && Kc % 64 == 0 && Np % 64 == 0 && Np == Kc &&
+         (long)M * std::max(std::max(Np, Nc), std::max(Kp, Kc)) * 2 < (1l << 32);      // (32-bit byte offsets of the DMA)
+}
+
+template <int EPI_C>
+void launch_chain(rk_engine* e, hipStream_t st, const ChainArgs& a) {
+  constexpr int smem = 163840;            // the ping-pong kernel's eight half-tile buffers + epilogue staging; scheduler words at the top
+  static std::atomic<uint64_t> attr_done{0};
+  ensure_dynamic_lds((const void*)gemm_chain_kernel<EPI_C>, smem, attr_done);
+  const long tiles = (long)((a.prod.M + 255) / 256) * (((a.prod.N + 255) / 256) + ((a.cons.N + 255) / 256));
+  const int wgs = e->n_cu & ~7;
+  hipLaunchKernelGGL((gemm_chain_kernel<EPI_C>), dim3((unsigned)(tiles < wgs ? tiles : wgs)), dim3(512), smem, st, a);
+}
+
+// prod: C (fp32 stream) += A W^T with xraw / ssq written; cons: Cc = epi_c(rowfactor x (xraw Wc^T))
+void chain_gemm(rk_engine* e, Slot& sl, hipStream_t st, int cls, int epi_c, const half_t* A, int lda, const half_t* W, int ldw, int Kp,
+                const half_t* Wc, int ldwc, void* Cc, int ldcc, int Nc, int T, int launch_index) {
+  const int dm = e->d.d_model;
+  GemmFold pf; pf.xraw = sl.xraw; pf.ssq = sl.ssq;
+  GemmFold cf; cf.rowscale = sl.rowscale;
+  ChainArgs a{};
+  a.prod = make_gemm_args(e, A, lda, W, ldw, sl.hidden, dm, T, dm, Kp, 0, 0, 1.f, 0, 0, 0, pf);
+  a.cons = make_gemm_args(e, sl.xraw, dm, Wc, ldwc, Cc, ldcc, T, Nc, dm, 0, 0, 1.f, 0, 0, 0, cf);
+  a.heads = sl.chain_heads + (size_t)launch_index * CHAIN_QUEUES;
+  a.cnt = sl.chain_cnt; a.flag = sl.chain_flag;
+  if (++sl.chain_epoch == 0) ++sl.chain_epoch;
+  a.epoch = sl.chain_epoch;
+  a.err = sl.chain_err; a.rowscale = sl.rowscale; a.lead_blocks = e->opt_chain_lead;
+  a.trace = e->chain_trace;
+  const double out_c = EPI_IS_GATED(epi_c) ? (double)T * Nc / 2 : (double)T * Nc;
+  Bracket br(e, st, cls, 2.0 * T * (double)dm * Kp + 2.0 * T * (double)Nc * dm,
+             2.0 * ((double)T * Kp + (double)dm * Kp) + (double)T * dm * 8.0 + 2.0 * ((double)T * dm + (double)Nc * dm) + out_c * 2.0);
+  switch (epi_c) {
+    case EPI_GEGLU_F16: launch_chain<EPI_GEGLU_F16>(e, st, a); break;
+    case EPI_RELU_F16: launch_chain<EPI_RELU_F16>(e, st, a); break;
+    default: launch_chain<EPI_STORE_F16>(e, st, a); break;
+  }
+}
+
+void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int lda, const half_t* W, int ldw, void* C,
+          int ldc, int M, int N, int K, int n_split = 0, long split_stride = 0, float scale = 1.f,
+          int batch = 1, long bsA = 0, long bsW = 0, long bsC = 0, bool weight_streaming = false, GemmFold fold = GemmFold()) {
+  if (M <= 0) return;
+  GemmArgs a = make_gemm_args(e, A, lda, W, ldw, C, ldc, M, N, K, n_split, split_stride, scale, bsA, bsW, bsC, fold);
   const double flops = 2.0 * M * (double)N * K * batch;
   const double out_elems = EPI_IS_GATED(epi) ? (double)M * N / 2 : (double)M * N;
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
@@ -530,9 +588,17 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
   const bool qkv_pp2 = !e->opt_consumer_stats || consumer_uses_pp2(e, EPI_STORE_F16, T, 3 * I, dm);
   const bool ffn_pp2 = !e->opt_consumer_stats || consumer_uses_pp2(e, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, T, d.gated_gelu ? 2 * F : F, dm);
   embed(e, st, sl.d_tokens, sl.hidden, T, fold ? sl.xraw : nullptr, fold ? sl.rowscale : nullptr);
+  // Chained form (gemm_chain.h; large batches): per layer {O -> FFN-in} and {FFN-out -> next layer's QKV} are ONE persistent launch
+  // each - 3 launches per layer instead of 7, same bits.  The queue heads of all the launches of this pass are zeroed here once.
+  const int Nffn = d.gated_gelu ? 2 * F : F;
+  const bool chain = fold && chain_ok(e, T, dm, I, Nffn, dm) && chain_ok(e, T, dm, F, 3 * I, dm) && 2 * d.n_enc_layers * CHAIN_QUEUES <= sl.chain_heads_cap;
+  int chain_i = 0;
+  if (chain) HIPCHK(e, hipMemsetAsync(sl.chain_heads, 0, (size_t)sl.chain_heads_cap * sizeof(int), st));
   for (int l = 0; l < d.n_enc_layers; ++l) {
     const EncLayerW& w = e->enc[l];
-    if (fold) {
+    if (chain && l > 0) {
+      // this layer's q/k/v rows were written by the previous layer's {FFN-out -> QKV} launch
+    } else if (fold) {
       gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xraw, dm, w.qkv_f, dm, sl.qkv, 3 * I, T, 3 * I, dm, 0, 0, 1.f, 1, 0, 0, 0, false,
            (l == 0 || qkv_pp2) ? cons : cons_ssq);            // layer 0: the embedding kernel wrote the row factors
     } else {
@@ -576,6 +642,13 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
         hipLaunchKernelGGL(attn_enc_kernel<2>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
       else
         hipLaunchKernelGGL(attn_enc_kernel<1>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
+    }
+    if (chain) {
+      const bool last = l + 1 == d.n_enc_layers;
+      chain_gemm(e, sl, st, PC_ENC_CHAIN_O_FFN, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, sl.ctx, I, w.o, I, I, w.ffn_in_f, dm, sl.ffh, F, Nffn, T, chain_i++);
+      if (!last) chain_gemm(e, sl, st, PC_ENC_CHAIN_FFO_QKV, EPI_STORE_F16, sl.ffh, F, w.ffn_out, F, F, e->enc[l + 1].qkv_f, dm, sl.qkv, 3 * I, 3 * I, T, chain_i++);
+      else gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, sl.ffh, F, w.ffn_out, F, sl.hidden, dm, T, dm, F);   // the final norm reads the fp32 stream itself
+      continue;
     }
     if (fold) {
       gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, I, w.o, I, sl.hidden, dm, T, dm, I, 0, 0, 1.f, 1, 0, 0, 0, false, prod);
@@ -794,12 +867,24 @@ int mark_decoder_done(rk_engine* e, Slot& sl) {
   return RK_OK;
 }
 
+// a chained launch whose row-panel hand-off timed out leaves an error word (gemm_chain.h: the GPU is never left spinning):
+// checked wherever the host has just waited for results
+int chain_check(rk_engine* e) {
+  for (Slot& sl : e->slots)
+    if (sl.chain_err && *(volatile int*)sl.chain_err != 0) {
+      *(volatile int*)sl.chain_err = 0;
+      for (Slot& s2 : e->slots) if (s2.chain_cnt) hipMemset(s2.chain_cnt, 0, ((size_t)(e->d.max_tokens + 255) / 256 + 1) * sizeof(int));   // a cut launch may have left tickets
+      return fail(e, RK_ERR_STATE, "chained GEMM launch: a row-panel hand-off timed out - results of this call are invalid (engine option chain=0 runs the separate launches)");
+    }
+  return RK_OK;
+}
+
 int sync_all(rk_engine* e) {
   for (Slot& sl : e->slots) {
     HIPCHK(e, hipStreamSynchronize(sl.se));
     HIPCHK(e, hipStreamSynchronize(sl.sd));
   }
-  return RK_OK;
+  return chain_check(e);
 }
 
 int ensure_logits(rk_engine* e, size_t rows) {
@@ -1117,6 +1202,7 @@ void rk_engine_destroy(rk_engine* e) {
   for (auto& sl : e->slots) {
     if (sl.h_scores) hipHostFree(sl.h_scores);
     if (sl.h_small) hipHostFree(sl.h_small);
+    if (sl.chain_err) hipHostFree(sl.chain_err);
     if (sl.ev_enc) hipEventDestroy(sl.ev_enc);
     if (sl.ev_dec) hipEventDestroy(sl.ev_dec);
   }
@@ -1334,6 +1420,14 @@ int rk_engine_finalize(rk_engine* e) {
     RC(dalloc(e, &sl.ctx, Tc * I)); RC(dalloc(e, &sl.ffh, Tc * F)); RC(dalloc(e, &sl.enc_out, Tc * dm));
     RC(dalloc(e, &sl.xraw, Tc * dm)); RC(dalloc(e, &sl.ssq, Tc * ((dm + 63) / 64))); RC(dalloc(e, &sl.rowscale, Tc + 512));   // padded: the ping-pong GEMM reads the row factors of a whole 256-row tile
     HIPCHK(e, hipMemset(sl.rowscale, 0, (Tc + 512) * sizeof(float)));
+    {
+      const size_t panels = (Tc + 255) / 256 + 1;
+      sl.chain_heads_cap = 2 * d.n_enc_layers * CHAIN_QUEUES;
+      RC(dalloc(e, &sl.chain_heads, (size_t)sl.chain_heads_cap)); RC(dalloc(e, &sl.chain_cnt, panels)); RC(dalloc(e, &sl.chain_flag, panels));
+      HIPCHK(e, hipMemset(sl.chain_cnt, 0, panels * sizeof(int))); HIPCHK(e, hipMemset(sl.chain_flag, 0, panels * sizeof(unsigned)));
+      HIPCHK(e, hipHostMalloc((void**)&sl.chain_err, 64, hipHostMallocDefault));
+      *sl.chain_err = 0;
+    }
     RC(dalloc(e, &sl.d_tokens, Tc)); RC(dalloc(e, &sl.d_seq_off, Bc + 1));
     RC(dalloc(e, &sl.cross_kv, (size_t)d.n_dec_layers * Tc * 2 * I));
     RC(dalloc(e, &sl.d_dec_ids, Mc)); RC(dalloc(e, &sl.d_last_rows, Bc)); RC(dalloc(e, &sl.d_out_ids, 8192));
@@ -1396,6 +1490,8 @@ int rk_t5_read_scores_slot(rk_engine* e, int slot, float* out_logits, int n_floa
   Slot& sl = e->slots[slot];
   if (n_floats > sl.n_seq * sl.last_n_out) return fail(e, RK_ERR_INVALID, "asked for %d floats, have %d", n_floats, sl.n_seq * sl.last_n_out);
   if (sl.dec_pending) { HIPCHK(e, hipEventSynchronize(sl.ev_dec)); sl.dec_pending = false; }
+  int rc = chain_check(e);
+  if (rc) return rc;
   memcpy(out_logits, sl.h_scores, (size_t)n_floats * sizeof(float));
   return RK_OK;
 }
@@ -2082,6 +2178,13 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
     return RK_OK;
   }
   if (!strcmp(key, "attn_ko")) { e->opt_attn_ko = value; return RK_OK; }   // timing-only knock-outs, see AttnEncArgs
+  if (!strcmp(key, "chain_trace")) {   // per workgroup and tile wall-clock stamps of the LAST chained launch (gemm_chain.h: ChainArgs::trace)
+    const size_t bytes = (size_t)256 * 64 * 4 * sizeof(unsigned long long);
+    if (value && !e->chain_trace) { if (hipMalloc(&e->chain_trace, bytes) != hipSuccess) return RK_ERR_HIP; }
+    if (e->chain_trace) hipMemset(e->chain_trace, 0, bytes);
+    if (!value && e->chain_trace) { hipFree(e->chain_trace); e->chain_trace = nullptr; }
+    return RK_OK;
+  }
 #endif
   if (!strcmp(key, "xattn_mfma")) { e->opt_xattn_mfma = value != 0; ++e->opt_epoch; return RK_OK; }   // query-side cross-attention: weighted sums on the matrix cores (1) or the VALU form (0)
   if (!strcmp(key, "attn_heads_per_wg")) { e->opt_attn_heads_per_wg = value; return RK_OK; }   // 0 auto
@@ -2090,6 +2193,9 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
   if (!strcmp(key, "dec_fuse_rows")) { e->opt_dec_fuse_rows = value; return RK_OK; }   // rows per workgroup of dec_cross_qk_kernel (0 = auto; A/B)
   if (!strcmp(key, "dec_fuse")) { e->opt_dec_fuse = value; return RK_OK; }   // few-row decoder: projections around the query-side cross-attention fused per (head, row slab): 1 = at one decoder position (default), 2 = always, 0 = separate GEMMs
+  if (!strcmp(key, "chain")) { e->opt_chain = value != 0; return RK_OK; }   // encoder: O -> FFN-in and FFN-out -> next QKV as chained launches (gemm_chain.h) when the batch is large enough (1) or always separate launches (0); same bits
+  if (!strcmp(key, "chain_lead")) { if (value < 1 || value > 16) return fail(e, RK_ERR_INVALID, "chain_lead 1..16"); e->opt_chain_lead = value; return RK_OK; }   // producer lead of a chained launch in blocks of four row panels
+  if (!strcmp(key, "chain_min_panels")) { if (value < 1) return fail(e, RK_ERR_INVALID, "chain_min_panels >= 1"); e->opt_chain_min_panels = value; return RK_OK; }   // fewest 256-row panels (M / 256) for the chained form
   if (!strcmp(key, "gemm_split")) { e->opt_gemm_split = value != 0; return RK_OK; }   // rows beyond the ping-pong kernel's last whole round on a fill-in tile variant (1) or one launch (0)
   if (!strcmp(key, "gemm_group_n")) { e->opt_gemm_group_n = value; return RK_OK; }   // ping-pong GEMM: column-panel width of the tile order in tiles (0 = default 8)
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
@@ -2183,6 +2289,7 @@ int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_fl
   if (n == "enc_hidden") { src = sl.hidden; cnt = (int64_t)sl.T * dm; is_half = false; }
 #ifdef RK_MEASURE
   else if (n == "attn_trace" && e->attn_trace) { src = e->attn_trace; cnt = 12 * 16 * 16; is_half = false; }
+  else if (n == "chain_trace" && e->chain_trace) { src = e->chain_trace; cnt = 256 * 64 * 4 * 2; is_half = false; }   // raw: two floats = one 64-bit stamp
 #endif
   else if (n == "enc_out") { src = sl.enc_out; cnt = (int64_t)sl.T * dm; }
   else if (n == "qkv") { src = sl.qkv; cnt = (int64_t)sl.T * 3 * I; }
