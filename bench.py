@@ -45,7 +45,15 @@ sys.path.insert(0, REPO)
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
 YES_ID, NO_ID = 2163, 465     # flan-t5 "Yes"/"No" ids quoted from memory; any two rows cost the same
-GEMM_CLASSES = ["enc_gemm_qkv", "enc_gemm_o", "enc_gemm_ffn_in", "enc_gemm_ffn_out", "gemm_cross_kv"]
+GEMM_CLASSES = ["enc_gemm_qkv", "enc_gemm_o", "enc_gemm_ffn_in", "enc_gemm_ffn_out", "gemm_cross_kv",
+                "enc_chain_o_ffn_in", "enc_chain_ffn_out_qkv"]     # the last two: chained launches (csrc/gemm_chain.h), two GEMMs each
+KERNEL_OF_CLASS = {
+    "enc_gemm_ffn_in": "gemm_pp2_kernel (256x256x64 ping-pong fp16 MFMA GEMM, fused GEGLU epilogue), M={M} N={N2F} K={D}",
+    "enc_chain_o_ffn_in": "gemm_chain_kernel<GEGLU> (ONE persistent launch: attention output projection + fp32 residual [M={M} N={D} K={I}] chained by "
+                          "row-panel flags into FFN-in + GEGLU [M={M} N={N2F} K={D}]; 256x256x64 ping-pong fp16 MFMA tiles)",
+    "enc_chain_ffn_out_qkv": "gemm_chain_kernel<STORE> (ONE persistent launch: FFN-out + fp32 residual [M={M} N={D} K={F}] chained by row-panel flags "
+                             "into the next layer's QKV projection [M={M} N={N3I} K={D}]; 256x256x64 ping-pong fp16 MFMA tiles)",
+}
 
 
 def algorithmic_gflop_per_passage(d, L_e, L_d=1):
@@ -284,12 +292,16 @@ def profile_pass(eng, pipe, G, M_tokens):
     rep = eng.profile_report()
     eng.profile(False)
     eng.set_option("overlap", 1)
-    fam_ms = sum(rep[c]["ms"] for c in GEMM_CLASSES)
-    fam_fl = sum(rep[c]["flops"] for c in GEMM_CLASSES)
-    fam_n = sum(rep[c]["launches"] for c in GEMM_CLASSES)
+    classes = [c for c in GEMM_CLASSES if c in rep]
+    fam_ms = sum(rep[c]["ms"] for c in classes)
+    fam_fl = sum(rep[c]["flops"] for c in classes)
+    fam_n = sum(rep[c]["launches"] for c in classes)
     total_ms = sum(v["ms"] for v in rep.values())
-    dom = max(GEMM_CLASSES, key=lambda c: rep[c]["ms"])       # the kernel with the largest share of GPU time
+    dom = max(classes, key=lambda c: rep[c]["ms"])            # the kernel with the largest share of GPU time
     d = rep[dom]
+    dd = eng.dims
+    kernel_desc = KERNEL_OF_CLASS.get(dom, "gemm_pp2_kernel (256x256x64 ping-pong fp16 MFMA GEMM)").format(
+        M=M_tokens, D=dd.d_model, I=dd.inner, F=dd.d_ff, N2F=(2 if dd.gated else 1) * dd.d_ff, N3I=3 * dd.inner)
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     # HBM-side traffic of the dominant kernel comes from rocprofv3 PMC passes of THIS command (tools/gpu_prof.sh:
     # FETCH_SIZE and WRITE_SIZE each in their own --pmc run; gfx950: FETCH_SIZE x2 for wide coalesced reads, KiB units;
@@ -300,8 +312,9 @@ def profile_pass(eng, pipe, G, M_tokens):
         with open(os.path.join(REPO, "profiles", "pmc_summary_latest.json")) as f:
             pm = json.load(f)
         if pm.get("tokens_per_launch") == M_tokens:
+            want = "gemm_chain" if dom.startswith("enc_chain") else "gemm_pp2"
             gk = [(v["stats"]["pct"], k, v) for k, v in pm["kernels"].items()
-                  if "gemm_" in k and v.get("stats") and "FETCH_SIZE" in v["pmc"] and "WRITE_SIZE" in v["pmc"]]
+                  if want in k and v.get("stats") and "FETCH_SIZE" in v["pmc"] and "WRITE_SIZE" in v["pmc"]]
             if gk:
                 _, kname, v = max(gk)
                 traffic = int((2 * v["pmc"]["FETCH_SIZE"]["avg_per_launch"] + v["pmc"]["WRITE_SIZE"]["avg_per_launch"]) * 1024)
@@ -310,10 +323,10 @@ def profile_pass(eng, pipe, G, M_tokens):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": f"{dom}: gemm_pp2_kernel (256x256x64 ping-pong fp16 MFMA GEMM, fused GEGLU epilogue), M={M_tokens} N={2 * eng.dims.d_ff} K={eng.dims.d_model}",
+            "kernel": f"{dom}: {kernel_desc}",
             "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2), "launches": int(d["launches"]),
             "algorithmic_gflop_per_launch": round(d["flops"] / max(d["launches"], 1) / 1e9, 1),
-            "family": {"kernel": "all tiled encoder GEMM launches (qkv, o, ffn_in+GEGLU, ffn_out)",
+            "family": {"kernel": "all tiled encoder GEMM launches (qkv, o, ffn_in+GEGLU, ffn_out; chained or separate)",
                        "achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 1) if fam_ms > 0 else None,
                        "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if fam_ms > 0 else None,
                        "launches": int(fam_n), "share_of_gpu_time": round(fam_ms / total_ms, 3) if total_ms else None},
