@@ -918,6 +918,43 @@ struct AttnDecArgs {
   const int* tree_keys; const int* tree_pos;
 };
 
+// The arithmetic of ONE query row of the decoder attention, shared by attn_dec_kernel (one workgroup per row: the tree form of
+// rk_t5_greedy2 and sequences with more keys than attn_dec_seq_kernel stages) and attn_dec_seq_kernel (one workgroup per
+// (head, sequence), a wave per row): explicit fma chains and fixed reduction trees, so that a row's context does not depend on
+// which of the two kernels its call shape selects (tests/test_gpu_kernels.py: bit-identical).
+__device__ __forceinline__ float dec_qk_dot(const float* sQ, const half_t* kr) {     // q . k over one head (64 columns)
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const half8 kk = *(const half8*)(kr + c * 8);
+    const f32x4 q0 = *(const f32x4*)(sQ + c * 8), q1 = *(const f32x4*)(sQ + c * 8 + 4);
+    s = __builtin_fmaf(q0[0], (float)kk[0], s); s = __builtin_fmaf(q0[1], (float)kk[1], s);
+    s = __builtin_fmaf(q0[2], (float)kk[2], s); s = __builtin_fmaf(q0[3], (float)kk[3], s);
+    s = __builtin_fmaf(q1[0], (float)kk[4], s); s = __builtin_fmaf(q1[1], (float)kk[5], s);
+    s = __builtin_fmaf(q1[2], (float)kk[6], s); s = __builtin_fmaf(q1[3], (float)kk[7], s);
+  }
+  return s;
+}
+__device__ __forceinline__ float dec_bias(const float* lut, int h, int j, int i) {
+  int rel = j - i;
+  rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
+  return lut[h * RK_LUT_N + rel + RK_LUT_R];
+}
+// sum_j P[j] V[j][d] over the keys j = w, w + 4, ... (the share of wave w of a four-wave workgroup), four interleaved chains
+template <class VF>
+__device__ __forceinline__ float dec_pv_part(const float* sP, int nk, int w, VF vf) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int j = w;
+  for (; j + 12 < nk; j += 16) {
+    a0 = __builtin_fmaf(sP[j], vf(j), a0);
+    a1 = __builtin_fmaf(sP[j + 4], vf(j + 4), a1);
+    a2 = __builtin_fmaf(sP[j + 8], vf(j + 8), a2);
+    a3 = __builtin_fmaf(sP[j + 12], vf(j + 12), a3);
+  }
+  for (; j < nk; j += 4) a0 = __builtin_fmaf(sP[j], vf(j), a0);
+  return (a0 + a1) + (a2 + a3);
+}
+
 __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
   extern __shared__ __attribute__((aligned(16))) float dec_smem[];
   float* sQ = dec_smem;            // [64]
@@ -939,20 +976,8 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
   __syncthreads();
   float mx = -1e30f;
   for (int j = tid; j < nk; j += 256) {
-    const half_t* kr = p.k + krow(j) * p.ldkv + h * 64;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const half8 kk = *(const half8*)(kr + c * 8);
-      const f32x4 q0 = *(const f32x4*)(sQ + c * 8), q1 = *(const f32x4*)(sQ + c * 8 + 4);
-      s += q0[0] * (float)kk[0] + q0[1] * (float)kk[1] + q0[2] * (float)kk[2] + q0[3] * (float)kk[3] +
-           q1[0] * (float)kk[4] + q1[1] * (float)kk[5] + q1[2] * (float)kk[6] + q1[3] * (float)kk[7];
-    }
-    if (p.bias_lut) {
-      int rel = j - i;
-      rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
-      s += p.bias_lut[h * RK_LUT_N + rel + RK_LUT_R];
-    }
+    float s = dec_qk_dot(sQ, p.k + krow(j) * p.ldkv + h * 64);
+    if (p.bias_lut) s += dec_bias(p.bias_lut, h, j, i);
     sP[j] = s;
     mx = fmaxf(mx, s);
   }
@@ -972,20 +997,78 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
   sum = (sRed[4] + sRed[5]) + (sRed[6] + sRed[7]);
   // P V: wave w takes keys w, w+4, ...; lane = d
   const half_t* vb = p.v + h * 64 + lane;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int j = wave;
-  for (; j + 12 < nk; j += 16) {
-    a0 += sP[j] * (float)vb[krow(j) * p.ldkv];
-    a1 += sP[j + 4] * (float)vb[krow(j + 4) * p.ldkv];
-    a2 += sP[j + 8] * (float)vb[krow(j + 8) * p.ldkv];
-    a3 += sP[j + 12] * (float)vb[krow(j + 12) * p.ldkv];
-  }
-  for (; j < nk; j += 4) a0 += sP[j] * (float)vb[krow(j) * p.ldkv];
-  sPart[wave * 64 + lane] = (a0 + a1) + (a2 + a3);
+  sPart[wave * 64 + lane] = dec_pv_part(sP, nk, wave, [&](int j) { return (float)vb[krow(j) * p.ldkv]; });
   __syncthreads();
   if (wave == 0) {
     const float acc = (sPart[lane] + sPart[64 + lane]) + (sPart[128 + lane] + sPart[192 + lane]);
     p.ctx[qrow * p.ldctx + h * 64 + lane] = f2h_sat(acc / sum);
+  }
+}
+
+// The same attention with ONE workgroup per (head, sequence) for decoder passes of several positions (qlm: ~30 label
+// positions, ref: llmrankers/pointwise.py:41-82; greedy prefixes): the per-row kernel above is launched as L_d x H x B
+// workgroups that each re-read the head's K and V rows of their sequence (27 x 36 KB through L2 per (head, sequence) in a
+// flan-t5-xl qlm call: 0.72 ms per launch, 34 of the 83 ms of a hits=100 query).  Here the K rows (144-byte stride: the lanes'
+// 16-byte reads fall on different banks) and V rows of the head are staged in LDS once, and the four waves take the query rows
+// in turn - a wave computes a row with the arithmetic above, walking the four key shares of the per-row kernel's waves one
+// after the other (same chains, same trees: bit-identical).  grid = (H, B); not for the tree form.
+#define ATTS_KSTR 72
+__host__ __device__ inline size_t attn_dec_seq_lds(int max_keys) {
+  const size_t kp = ((size_t)max_keys + 3) & ~(size_t)3;
+  return kp * ATTS_KSTR * 2 + kp * 64 * 2 + 4 * (64 + kp) * sizeof(float);
+}
+__global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float dec_smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int kp = (p.max_keys + 3) & ~3;
+  half_t* sK = (half_t*)dec_smem;                  // [kp][ATTS_KSTR]
+  half_t* sV = sK + (size_t)kp * ATTS_KSTR;        // [kp][64]
+  float* sQ = (float*)(sV + (size_t)kp * 64) + (size_t)wave * (64 + kp);   // [64]   (wave-private from here on)
+  float* sP = sQ + 64;                             // [kp]
+  int koff, Lk;
+  if (p.key_off) { koff = p.key_off[b]; Lk = p.key_off[b + 1] - koff; }
+  else { koff = b * p.Lq; Lk = p.Lq; }
+  for (int idx = tid; idx < Lk * 8; idx += 256) {
+    const int r = idx >> 3, c = idx & 7;
+    const size_t g = (size_t)(koff + r) * p.ldkv + h * 64 + c * 8;
+    *(half8*)(sK + r * ATTS_KSTR + c * 8) = *(const half8*)(p.k + g);
+    *(half8*)(sV + r * 64 + c * 8) = *(const half8*)(p.v + g);
+  }
+  __syncthreads();
+  for (int i = wave; i < p.Lq; i += 4) {
+    const int nk = p.causal ? (i + 1 < Lk ? i + 1 : Lk) : Lk;
+    const size_t qrow = (size_t)b * p.Lq + i;
+    sQ[lane] = (float)p.q[qrow * p.ldq + h * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    float mx = -1e30f;
+    for (int j = lane; j < nk; j += 64) {
+      float s = dec_qk_dot(sQ, sK + j * ATTS_KSTR);
+      if (p.bias_lut) s += dec_bias(p.bias_lut, h, j, i);
+      sP[j] = s;
+      mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float ssum[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {                  // the per-row kernel's thread tid = 64 w + lane owns keys tid, tid + 256, ...
+      float sum = 0.f;
+      for (int j = w * 64 + lane; j < nk; j += 256) {
+        const float e = __expf(sP[j] - mx);
+        sP[j] = e;
+        sum += e;
+      }
+      ssum[w] = wave_sum(sum);
+    }
+    const float sum = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+    __builtin_amdgcn_wave_barrier();
+    const half_t* vb = sV + lane;
+    float part[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) part[w] = dec_pv_part(sP, nk, w, [&](int j) { return (float)vb[j * 64]; });
+    const float acc = (part[0] + part[1]) + (part[2] + part[3]);
+    p.ctx[qrow * p.ldctx + h * 64 + lane] = f2h_sat(acc / sum);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

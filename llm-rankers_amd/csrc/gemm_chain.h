@@ -43,12 +43,19 @@ struct ChainArgs {
   float* rowscale;      // [M (padded)] row factors, written by the last-arriving producer tile of a panel
   int lead_blocks;      // producer lead in blocks of CHAIN_R panels
   unsigned long long* trace;   // measurement builds: per workgroup and tile {start, end of main loop, end of epilogue} wall clock
+  int debug;            // measurement builds: knock-outs for fault / bottleneck hunting (results are garbage): 1 no row-factor loads, 2 no flag
+                        // load / wait (always "ready"), 4 no publish, 8 no epilogues, 16 no DMA, 32 claims through the synchronous path only
 };
+#ifdef RK_MEASURE
+#define CHAIN_DBG(bit) ((a.debug & (bit)) != 0)
+#else
+#define CHAIN_DBG(bit) false
+#endif
 
 #define CHAIN_TIMEOUT_TICKS 20000000LL    // 0.2 s of the 100 MHz wall clock
 
 // one lane: wait until *flag == epoch.  Bounded: a lost hand-off becomes an error word, not a hung GPU.
-__device__ __noinline__ void chain_spin(const unsigned* flag, unsigned epoch, int* err) {
+__device__ __forceinline__ void chain_spin(const unsigned* flag, unsigned epoch, int* err) {
   const long long t0 = wall_clock64();
   while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
     __builtin_amdgcn_s_sleep(16);
@@ -112,6 +119,7 @@ __global__ __launch_bounds__(512, 2) void gemm_chain_kernel(ChainArgs a) {
     const char* base = (const char*)((kind < 2 ? curA : curW) + tile * 64);
     const unsigned dst = lds0 + (unsigned)(((kind * 2 + stage) * HALF + (wave * 2 + j) * 512) * 2);
     const unsigned o = off[kind][j];
+    if (CHAIN_DBG(16)) return;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(o), "s"(base) : "memory", "m0");
   };
   using std::integral_constant;
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_chain_kernel(ChainArgs a) {
   };
   // everyone: block until the tile's inputs are published (consumer tiles), then drop this CU's L1
   auto wait_ready = [&](int code) {
-    if (!chain_is_prod(code)) {
+    if (!chain_is_prod(code) && !CHAIN_DBG(2)) {
       if (tid == 0) chain_spin(a.flag + chain_tm(code), a.epoch, a.err);
       __syncthreads();
     }
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm_chain_kernel(ChainArgs a) {
     // the NEXT tile and the claim of the tile after it - all awaited together below, before anything else is issued
     const float tile_scale = is_prod ? a.prod.scale : a.cons.scale;
     float rsc[4] = {tile_scale, tile_scale, tile_scale, tile_scale};
-    if (!is_prod) {
+    if (!is_prod && !CHAIN_DBG(1)) {
       const unsigned roff = (unsigned)(m0 + wm * 128 + l31) * 4u;
       asm volatile("global_load_dword %0, %1, %2" : "=&v"(rsc[0]) : "v"(roff), "s"(a.rowscale));
       asm volatile("global_load_dword %0, %1, %2 offset:128" : "=&v"(rsc[1]) : "v"(roff), "s"(a.rowscale));
@@ -272,11 +280,11 @@ __global__ __launch_bounds__(512, 2) void gemm_chain_kernel(ChainArgs a) {
     int idxv = 0x7fffffff;
     const bool claim = wave == 0 && next >= 0 && tried < CHAIN_QUEUES;
     if (wave == 0) {
-      if (next >= 0 && !chain_is_prod(next)) {
+      if (next >= 0 && !chain_is_prod(next) && !CHAIN_DBG(2)) {
         const unsigned foff = (unsigned)chain_tm(next) * 4u;
         asm volatile("global_load_dword %0, %1, %2 sc1" : "=&v"(flagv) : "v"(foff), "s"(a.flag));
       }
-      if (claim && lane == 0) {
+      if (claim && lane == 0 && !CHAIN_DBG(32)) {
         const unsigned hoff = (unsigned)qcur * 4u;
         const int one = 1;
         asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=&v"(idxv) : "v"(hoff), "v"(one), "s"(a.heads) : "memory");
@@ -288,7 +296,8 @@ __global__ __launch_bounds__(512, 2) void gemm_chain_kernel(ChainArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(rsc[0]), "+v"(rsc[1]), "+v"(rsc[2]), "+v"(rsc[3]), "+v"(flagv), "+v"(idxv) :: "memory");
     if (wave == 0) {
       int n2 = -1;
-      if (claim) {
+      if (claim && CHAIN_DBG(32)) n2 = pull_sync();
+      else if (claim) {
         const int idx = __builtin_amdgcn_readfirstlane(idxv);
         // (the geometry goes through an opaque statement: the reciprocals of the decode's divisions are loop invariants that
         // would otherwise be formed in front of the tile loop and kept - spilled - across the main loop)
@@ -325,11 +334,12 @@ __global__ __launch_bounds__(512, 2) void gemm_chain_kernel(ChainArgs a) {
     int lane_e;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     if (was_prod) {
+      if (!CHAIN_DBG(8))
       gemm_epilogue_staged<EPI_RESID_F32, 2, 4, false, 16, 0, true>(a.prod, acc, mbase, nbase, lane_e, gemm_smem + 114688 + wave * 4608, rsc);
       // ---- publish: write-through stores drained by every wave, then ONE arrival ticket for the row panel ----
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) sched[2] = (__hip_atomic_fetch_add(a.cnt + tm_cur, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NP - 1) ? 1 : 0;
+      if (tid == 0) sched[2] = CHAIN_DBG(4) ? 0 : (__hip_atomic_fetch_add(a.cnt + tm_cur, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NP - 1) ? 1 : 0;
       __syncthreads();
       if (__builtin_amdgcn_readfirstlane(sched[2]) != 0) {            // last producer tile of the panel: block sums -> row factors, then the flag
         asm volatile("buffer_inv sc1" ::: "memory");
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void gemm_chain_kernel(ChainArgs a) {
           __hip_atomic_store(a.flag + tm_cur, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-    } else {
+    } else if (!CHAIN_DBG(8)) {
       gemm_epilogue_staged<EPI_C, 2, 4, false, 32>(a.cons, acc, mbase, nbase, lane_e, gemm_smem + 114688 + wave * 4608, rsc);
     }
 #ifdef RK_MEASURE

@@ -115,7 +115,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 1, opt_chain_lead = 3, opt_chain_min_panels = 64;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 1, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_chain_debug = 0, opt_chain_only = 0;
   unsigned long long* chain_trace = nullptr;   // measurement builds only (option chain_trace)
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
@@ -426,7 +426,7 @@ void chain_gemm(rk_engine* e, Slot& sl, hipStream_t st, int cls, int epi_c, cons
   if (++sl.chain_epoch == 0) ++sl.chain_epoch;
   a.epoch = sl.chain_epoch;
   a.err = sl.chain_err; a.rowscale = sl.rowscale; a.lead_blocks = e->opt_chain_lead;
-  a.trace = e->chain_trace;
+  a.trace = e->chain_trace; a.debug = e->opt_chain_debug;
   const double out_c = EPI_IS_GATED(epi_c) ? (double)T * Nc / 2 : (double)T * Nc;
   Bracket br(e, st, cls, 2.0 * T * (double)dm * Kp + 2.0 * T * (double)Nc * dm,
              2.0 * ((double)T * Kp + (double)dm * Kp) + (double)T * dm * 8.0 + 2.0 * ((double)T * dm + (double)Nc * dm) + out_c * 2.0);
@@ -592,11 +592,12 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
   // each - 3 launches per layer instead of 7, same bits.  The queue heads of all the launches of this pass are zeroed here once.
   const int Nffn = d.gated_gelu ? 2 * F : F;
   const bool chain = fold && chain_ok(e, T, dm, I, Nffn, dm) && chain_ok(e, T, dm, F, 3 * I, dm) && 2 * d.n_enc_layers * CHAIN_QUEUES <= sl.chain_heads_cap;
+  const bool chainA = chain && e->opt_chain_only != 2, chainB = chain && e->opt_chain_only != 1;   // (chain_only: measurement switch, 0 = both)
   int chain_i = 0;
   if (chain) HIPCHK(e, hipMemsetAsync(sl.chain_heads, 0, (size_t)sl.chain_heads_cap * sizeof(int), st));
   for (int l = 0; l < d.n_enc_layers; ++l) {
     const EncLayerW& w = e->enc[l];
-    if (chain && l > 0) {
+    if (chainB && l > 0) {
       // this layer's q/k/v rows were written by the previous layer's {FFN-out -> QKV} launch
     } else if (fold) {
       gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xraw, dm, w.qkv_f, dm, sl.qkv, 3 * I, T, 3 * I, dm, 0, 0, 1.f, 1, 0, 0, 0, false,
@@ -645,9 +646,19 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
     }
     if (chain) {
       const bool last = l + 1 == d.n_enc_layers;
-      chain_gemm(e, sl, st, PC_ENC_CHAIN_O_FFN, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, sl.ctx, I, w.o, I, I, w.ffn_in_f, dm, sl.ffh, F, Nffn, T, chain_i++);
-      if (!last) chain_gemm(e, sl, st, PC_ENC_CHAIN_FFO_QKV, EPI_STORE_F16, sl.ffh, F, w.ffn_out, F, F, e->enc[l + 1].qkv_f, dm, sl.qkv, 3 * I, 3 * I, T, chain_i++);
-      else gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, sl.ffh, F, w.ffn_out, F, sl.hidden, dm, T, dm, F);   // the final norm reads the fp32 stream itself
+      if (chainA) {
+        chain_gemm(e, sl, st, PC_ENC_CHAIN_O_FFN, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, sl.ctx, I, w.o, I, I, w.ffn_in_f, dm, sl.ffh, F, Nffn, T, chain_i++);
+      } else {
+        gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, I, w.o, I, sl.hidden, dm, T, dm, I, 0, 0, 1.f, 1, 0, 0, 0, false, prod);
+        rowscale(e, st, sl.ssq, sl.rowscale, T);
+        gemm(e, st, PC_ENC_GEMM_FFN_IN, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, sl.xraw, dm, w.ffn_in_f, dm, sl.ffh, F, T, Nffn, dm, 0, 0, 1.f, 1, 0, 0, 0, false, cons);
+      }
+      if (last) gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, sl.ffh, F, w.ffn_out, F, sl.hidden, dm, T, dm, F);   // the final norm reads the fp32 stream itself
+      else if (chainB) chain_gemm(e, sl, st, PC_ENC_CHAIN_FFO_QKV, EPI_STORE_F16, sl.ffh, F, w.ffn_out, F, F, e->enc[l + 1].qkv_f, dm, sl.qkv, 3 * I, 3 * I, T, chain_i++);
+      else {
+        gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, sl.ffh, F, w.ffn_out, F, sl.hidden, dm, T, dm, F, 0, 0, 1.f, 1, 0, 0, 0, false, prod);
+        rowscale(e, st, sl.ssq, sl.rowscale, T);
+      }
       continue;
     }
     if (fold) {
@@ -731,6 +742,8 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
         if (tree) {
           a.tree_keys = tree->keys; a.tree_pos = tree->pos;
           hipLaunchKernelGGL(attn_dec_kernel, dim3(1, d.n_heads, M), dim3(256), smem_self, st, a);
+        } else if (e->opt_dec_attn_seq && attn_dec_seq_lds(Ld) <= 160 * 1024) {   // one workgroup per (head, sequence): K / V staged once (same bits)
+          hipLaunchKernelGGL(attn_dec_seq_kernel, dim3(d.n_heads, B), dim3(256), attn_dec_seq_lds(Ld), st, a);
         } else {
           hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_self, st, a);
         }
@@ -805,7 +818,10 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
       const half_t* kv = sl.cross_kv + (size_t)l * d.max_tokens * 2 * I;
       AttnDecArgs a{sl.dq, I, kv, kv + I, 2 * I, sl.d_seq_off, sl.dctx, I, nullptr, Ld, 0, sl.maxL};
       Bracket br(e, st, PC_DEC_ATTN, 4.0 * Ld * (double)sl.T * I, (double)sl.T * 2 * I * 2.0);
-      hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_cross, st, a);
+      if (e->opt_dec_attn_seq && Ld >= 2 && attn_dec_seq_lds(sl.maxL) <= 160 * 1024)
+        hipLaunchKernelGGL(attn_dec_seq_kernel, dim3(d.n_heads, B), dim3(256), attn_dec_seq_lds(sl.maxL), st, a);
+      else
+        hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_cross, st, a);
     }
     if (dfold) {
       gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dctx, I, w.co, I, sl.dhidden, dm, M, dm, I, 0, 0, 1.f, 1, 0, 0, 0, ws, with_prod(GemmFold()));
@@ -1451,6 +1467,7 @@ int rk_engine_finalize(rk_engine* e) {
   // best effort: only kernels asking for more than the default dynamic-LDS window need the opt-in
   (void)hipFuncSetAttribute((const void*)attn_dec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             std::min(dec_smem_max, 160 * 1024));
+  (void)hipFuncSetAttribute((const void*)attn_dec_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define GEMM_ATTR(EPI)                                                                                              \
   (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES); \
   (void)hipFuncSetAttribute((const void*)gemm_f16_kernel<EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
@@ -2178,6 +2195,8 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
     return RK_OK;
   }
   if (!strcmp(key, "attn_ko")) { e->opt_attn_ko = value; return RK_OK; }   // timing-only knock-outs, see AttnEncArgs
+  if (!strcmp(key, "chain_debug")) { e->opt_chain_debug = value; return RK_OK; }   // knock-outs of the chained launch (ChainArgs::debug)
+  if (!strcmp(key, "chain_only")) { e->opt_chain_only = value; return RK_OK; }      // 1: only {O -> FFN-in} chained, 2: only {FFN-out -> QKV}
   if (!strcmp(key, "chain_trace")) {   // per workgroup and tile wall-clock stamps of the LAST chained launch (gemm_chain.h: ChainArgs::trace)
     const size_t bytes = (size_t)256 * 64 * 4 * sizeof(unsigned long long);
     if (value && !e->chain_trace) { if (hipMalloc(&e->chain_trace, bytes) != hipSuccess) return RK_ERR_HIP; }
@@ -2193,6 +2212,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
   if (!strcmp(key, "dec_fuse_rows")) { e->opt_dec_fuse_rows = value; return RK_OK; }   // rows per workgroup of dec_cross_qk_kernel (0 = auto; A/B)
   if (!strcmp(key, "dec_fuse")) { e->opt_dec_fuse = value; return RK_OK; }   // few-row decoder: projections around the query-side cross-attention fused per (head, row slab): 1 = at one decoder position (default), 2 = always, 0 = separate GEMMs
+  if (!strcmp(key, "dec_attn_seq")) { e->opt_dec_attn_seq = value != 0; ++e->opt_epoch; return RK_OK; }   // decoder attention at several positions: one workgroup per (head, sequence) with K / V staged in LDS (1) or one per query row (0); same bits
   if (!strcmp(key, "chain")) { e->opt_chain = value != 0; return RK_OK; }   // encoder: O -> FFN-in and FFN-out -> next QKV as chained launches (gemm_chain.h) when the batch is large enough (1) or always separate launches (0); same bits
   if (!strcmp(key, "chain_lead")) { if (value < 1 || value > 16) return fail(e, RK_ERR_INVALID, "chain_lead 1..16"); e->opt_chain_lead = value; return RK_OK; }   // producer lead of a chained launch in blocks of four row panels
   if (!strcmp(key, "chain_min_panels")) { if (value < 1) return fail(e, RK_ERR_INVALID, "chain_min_panels >= 1"); e->opt_chain_min_panels = value; return RK_OK; }   // fewest 256-row panels (M / 256) for the chained form

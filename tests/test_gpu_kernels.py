@@ -1147,3 +1147,65 @@ def test_llama_pairwise_reference_cases_on_the_engine(ckpt_dirs):
             n += 1
         rk.llm.engine.close()
     assert n >= 4
+
+
+def test_chained_gemm_launches_bit_identical_to_separate_launches():
+    """csrc/gemm_chain.h: {O -> FFN-in} and {FFN-out -> next QKV} as ONE persistent launch each (row-panel ready flags, dynamic
+    per-XCD queues, write-through hand-off) must give the bits of the separate ping-pong launches + statistics kernel - same tile
+    loop, same K order, same epilogues - on the bench shape, one query, a ragged batch, and (size gate lowered) on shapes with
+    fewer row panels than queues and a partial last panel; for every producer lead; on repeated calls (epoch-tagged flags,
+    self-resetting tickets) and with both slots in flight beside replayed decoder graphs."""
+    from llmrankers import _synth
+    dims = _synth.FLAN_T5_LARGE
+    state = _synth.synth_state_dict(dims, seed=929, threads=16)
+    eng = _engine(dims, state, max_tokens=320 * 184, max_seqs=320, max_dec_len=4)
+    ids = [2163, 465]
+    shapes = [(_synth.synth_token_batch(320, 184, 184, dims.vocab, seed=1), 64), (_synth.synth_token_batch(100, 184, 184, dims.vocab, seed=2), 64),
+              (_synth.synth_token_batch(320, 96, 184, dims.vocab, seed=3), 64), (_synth.synth_token_batch(40, 184, 184, dims.vocab, seed=4), 1),
+              (_synth.synth_token_batch(7, 100, 180, dims.vocab, seed=5), 1), (_synth.synth_token_batch(1, 150, 150, dims.vocab, seed=6), 1),
+              (_synth.synth_token_batch(13, 184, 184, dims.vocab, seed=7), 1)]
+    for seqs, min_panels in shapes:
+        eng.set_option("chain", 0)
+        ref = eng.score(seqs, [0], ids)
+        eng.set_option("chain", 1)
+        eng.set_option("chain_min_panels", min_panels)
+        for lead in (3, 1, 2, 3):
+            eng.set_option("chain_lead", lead)
+            np.testing.assert_array_equal(eng.score(seqs, [0], ids), ref, err_msg=f"{len(seqs)} sequences, lead {lead}")
+    eng.set_option("chain_min_panels", 64)
+    qs = [_synth.synth_token_batch(320, 184, 184, dims.vocab, seed=20 + q) for q in range(2)]
+    eng.set_option("chain", 0)
+    refs = [eng.score(q, [0], ids) for q in qs]
+    eng.set_option("chain", 1)
+    for s_ in range(2):
+        eng.stage(qs[s_], slot=s_)
+    for it in range(3):
+        for s_ in range(2):
+            eng.score_staged([0], ids, slot=s_)
+        for s_ in range(2):
+            np.testing.assert_array_equal(eng.read_scores(s_), refs[s_], err_msg=f"pipelined, iteration {it}, slot {s_}")
+    eng.close()
+
+
+def test_decoder_attention_per_sequence_kernel_bit_identical_to_per_row_kernel():
+    """attn_dec_seq_kernel (one workgroup per (head, sequence), K / V of the head staged in LDS once, a wave per query row) walks
+    the per-row kernel's chains and reduction trees: qlm scores (causal self-attention with the unidirectional bias + cross
+    attention over the materialised K / V, 33 label positions) and greedy tokens / label logits after a multi-token prefix are the
+    SAME BITS with either kernel, at flan-t5-small dims with ragged prompts - also prompts longer than 256 tokens (several keys
+    per lane in the sums)."""
+    from llmrankers import _synth
+    dims = _synth.FLAN_T5_SMALL
+    state = _synth.synth_state_dict(dims, seed=929, threads=8)
+    eng = _engine(dims, state, max_tokens=8192, max_seqs=16, max_dec_len=40)
+    labels = [0] + np.random.RandomState(5).randint(3, dims.vocab, size=32).tolist()
+    prefix = [0] + np.random.RandomState(6).randint(3, dims.vocab, size=19).tolist()
+    for seqs in (_synth.synth_token_batch(6, 40, 150, dims.vocab, seed=31), _synth.synth_token_batch(5, 200, 700, dims.vocab, seed=32),
+                 _synth.synth_token_batch(1, 64, 64, dims.vocab, seed=33)):
+        out = {}
+        for flag in (1, 0):
+            eng.set_option("dec_attn_seq", flag)
+            out[flag] = (eng.qlm(seqs, labels), eng.score(seqs, prefix, [5, 6, 7, 8]))
+        np.testing.assert_array_equal(out[1][0], out[0][0])
+        np.testing.assert_array_equal(out[1][1], out[0][1])
+    eng.set_option("dec_attn_seq", 1)
+    eng.close()
