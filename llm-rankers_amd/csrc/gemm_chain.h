@@ -271,7 +271,10 @@ __global__ __launch_bounds__(512, 2) void gemm_chain_kernel(ChainArgs a) {
     float rsc[4] = {tile_scale, tile_scale, tile_scale, tile_scale};
     if (!is_prod && !CHAIN_DBG(1)) {
       const unsigned roff = (unsigned)(m0 + wm * 128 + l31) * 4u;
-      asm volatile("global_load_dword %0, %1, %2" : "=&v"(rsc[0]) : "v"(roff), "s"(a.rowscale));
+      // (s_nop 4: the base pair may have just been restored from a spill lane by v_readlane - a VALU write of an SGPR needs five
+      // wait states before a VMEM instruction reads it, and the compiler's hazard recognizer does not look inside inline asm;
+      // without it the GEGLU instantiation loaded through a stale pointer half: memory faults on the first launch)
+      asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(rsc[0]) : "v"(roff), "s"(a.rowscale));
       asm volatile("global_load_dword %0, %1, %2 offset:128" : "=&v"(rsc[1]) : "v"(roff), "s"(a.rowscale));
       asm volatile("global_load_dword %0, %1, %2 offset:256" : "=&v"(rsc[2]) : "v"(roff), "s"(a.rowscale));
       asm volatile("global_load_dword %0, %1, %2 offset:384" : "=&v"(rsc[3]) : "v"(roff), "s"(a.rowscale));
@@ -282,12 +285,12 @@ __global__ __launch_bounds__(512, 2) void gemm_chain_kernel(ChainArgs a) {
     if (wave == 0) {
       if (next >= 0 && !chain_is_prod(next) && !CHAIN_DBG(2)) {
         const unsigned foff = (unsigned)chain_tm(next) * 4u;
-        asm volatile("global_load_dword %0, %1, %2 sc1" : "=&v"(flagv) : "v"(foff), "s"(a.flag));
+        asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1" : "=&v"(flagv) : "v"(foff), "s"(a.flag));
       }
       if (claim && lane == 0 && !CHAIN_DBG(32)) {
         const unsigned hoff = (unsigned)qcur * 4u;
         const int one = 1;
-        asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=&v"(idxv) : "v"(hoff), "v"(one), "s"(a.heads) : "memory");
+        asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=&v"(idxv) : "v"(hoff), "v"(one), "s"(a.heads) : "memory");
       }
     }
     __builtin_amdgcn_sched_barrier(0);

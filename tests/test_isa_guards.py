@@ -133,3 +133,60 @@ def test_fused_decoder_kernels_fit_two_workgroups_per_cu(isa, name):
     m = re.search(r"NumVgprs: (\d+)", tail)
     assert m and int(m.group(1)) <= 128, m and m.group(1)
     assert sum("v_mfma_f32_32x32x16_f16" in l for l in body) >= 8
+
+
+def _instructions(body):
+    """(index, text) of the machine instructions of a kernel body (labels, directives and comments dropped)."""
+    out = []
+    for i, l in enumerate(body):
+        code = l.split(";")[0].strip()
+        if code and not code.startswith(".") and not code.endswith(":"):
+            out.append((i, code))
+    return out
+
+
+def test_no_valu_written_sgpr_feeds_an_inline_asm_memory_instruction_without_wait_states(isa):
+    """gfx9 / CDNA hazard: a VALU instruction that writes an SGPR (v_readlane / v_readfirstlane - which is how the compiler brings
+    a spilled SGPR back - , v_cmp with an SGPR destination) needs FIVE wait states before a VMEM instruction reads that SGPR.
+    The compiler's hazard recognizer inserts them for its own instructions but does not look inside inline asm: the chained GEMM
+    launch (gemm_chain.h, round 5) restored the row-factor base from a spill lane right in front of a hand-written load and
+    faulted on its first launch.  Every hand-written VMEM instruction with an SGPR base (loads, LDS-DMA, atomics) in every kernel
+    of the library: no VALU write of its base registers within the five preceding wait states (s_nop N counts N + 1)."""
+    text = isa
+    starts = [i for i, l in enumerate(text) if re.match(r"^_Z\w+:", l)]
+    checked = 0
+    for k, s in enumerate(starts):
+        end = starts[k + 1] if k + 1 < len(starts) else len(text)
+        body = text[s:end]
+        ins = _instructions(body)
+        in_asm = set()
+        inside = False
+        for i, l in enumerate(body):
+            if "ASMSTART" in l:
+                inside = True
+            elif "ASMEND" in l:
+                inside = False
+            elif inside:
+                in_asm.add(i)
+        for pos, (i, code) in enumerate(ins):
+            if i not in in_asm:
+                continue
+            m = re.match(r"(global_load_\w+|global_atomic_\w+|global_store_\w+)\s.*\bs\[(\d+):(\d+)\]", code)
+            if not m:
+                continue
+            base = set(range(int(m.group(2)), int(m.group(3)) + 1))
+            checked += 1
+            waits, back = 0, pos - 1
+            while back >= 0 and waits < 5:
+                prev = ins[back][1]
+                n = re.match(r"s_nop (\d+)", prev)
+                if n:
+                    waits += int(n.group(1)) + 1
+                else:
+                    w = re.match(r"v_(readlane|readfirstlane)_b32 s(\d+)", prev) or re.match(r"v_cmp\w* s\[(\d+):(\d+)\]", prev)
+                    if w:
+                        regs = {int(w.group(2))} if w.re.pattern.startswith("v_(read") else set(range(int(w.group(1)), int(w.group(2)) + 1))
+                        assert not (regs & base), f"{text[s][:60]}: `{prev}` {waits} wait state(s) in front of hand-written `{code}`"
+                    waits += 1
+                back -= 1
+    assert checked > 50        # the ping-pong / chained GEMMs and the DMA attention kernel hold dozens of such instructions each
