@@ -115,7 +115,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 1, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_chain_debug = 0, opt_chain_only = 0;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_chain_debug = 0, opt_chain_only = 0;
   unsigned long long* chain_trace = nullptr;   // measurement builds only (option chain_trace)
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
