@@ -399,13 +399,27 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             if (ok) {
               half4 xr = {f2h_sat(v[0] * p.xs), f2h_sat(v[1] * p.xs), f2h_sat(v[2] * p.xs), f2h_sat(v[3] * p.xs)};
               if constexpr (PUBLISH) {
-                __hip_atomic_store((unsigned long long*)(p.xraw + (size_t)m * p.ldx + n), __builtin_bit_cast(unsigned long long, xr),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (ch == 0) __hip_atomic_store(p.ssq + (size_t)m * p.nb + (ncol0 >> 6), ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               } else {
               if constexpr ((GEMM_EPI_NT & 8) != 0) __builtin_nontemporal_store(xr, (half4*)(p.xraw + (size_t)m * p.ldx + n));
               else *(half4*)(p.xraw + (size_t)m * p.ldx + n) = xr;
               if (ch == 0) p.ssq[(size_t)m * p.nb + (ncol0 >> 6)] = ss;
+              }
+            }
+            if constexpr (PUBLISH) {
+              // write-through (sc1) stores of 8 bytes are one fabric write each (34 us per tile epilogue against 18 contended: the
+              // first form of the chained launch, profiles/r05*_chain_trace*); as 16-byte stores they cost what plain ones do.  The two
+              // lanes that hold neighbouring 4-column pieces of a row pair up: the even one stores both (quad-perm swap, no LDS)
+              half4 xr = {f2h_sat(v[0] * p.xs), f2h_sat(v[1] * p.xs), f2h_sat(v[2] * p.xs), f2h_sat(v[3] * p.xs)};
+              typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+              const u32x2 mine = __builtin_bit_cast(u32x2, xr);
+              const unsigned o0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[0], 0xB1, 0xF, 0xF, true);
+              const unsigned o1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[1], 0xB1, 0xF, 0xF, true);
+              if (ok && (ch & 1) == 0) {
+                const u32x4 both = {mine[0], mine[1], o0, o1};
+                const half_t* dst_x = p.xraw + (size_t)m * p.ldx + n;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst_x), "v"(both) : "memory");
               }
             }
           }

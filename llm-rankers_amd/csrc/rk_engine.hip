@@ -115,7 +115,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_chain_debug = 0, opt_chain_only = 0;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_chain_debug = 0, opt_chain_only = 0, opt_chain_trace_launch = 0;
   unsigned long long* chain_trace = nullptr;   // measurement builds only (option chain_trace)
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
@@ -426,7 +426,7 @@ void chain_gemm(rk_engine* e, Slot& sl, hipStream_t st, int cls, int epi_c, cons
   if (++sl.chain_epoch == 0) ++sl.chain_epoch;
   a.epoch = sl.chain_epoch;
   a.err = sl.chain_err; a.rowscale = sl.rowscale; a.lead_blocks = e->opt_chain_lead;
-  a.trace = e->chain_trace; a.debug = e->opt_chain_debug;
+  a.trace = (e->chain_trace && launch_index == e->opt_chain_trace_launch) ? e->chain_trace : nullptr; a.debug = e->opt_chain_debug;
   const double out_c = EPI_IS_GATED(epi_c) ? (double)T * Nc / 2 : (double)T * Nc;
   Bracket br(e, st, cls, 2.0 * T * (double)dm * Kp + 2.0 * T * (double)Nc * dm,
              2.0 * ((double)T * Kp + (double)dm * Kp) + (double)T * dm * 8.0 + 2.0 * ((double)T * dm + (double)Nc * dm) + out_c * 2.0);
@@ -2197,11 +2197,13 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "attn_ko")) { e->opt_attn_ko = value; return RK_OK; }   // timing-only knock-outs, see AttnEncArgs
   if (!strcmp(key, "chain_debug")) { e->opt_chain_debug = value; return RK_OK; }   // knock-outs of the chained launch (ChainArgs::debug)
   if (!strcmp(key, "chain_only")) { e->opt_chain_only = value; return RK_OK; }      // 1: only {O -> FFN-in} chained, 2: only {FFN-out -> QKV}
-  if (!strcmp(key, "chain_trace")) {   // per workgroup and tile wall-clock stamps of the LAST chained launch (gemm_chain.h: ChainArgs::trace)
+  if (!strcmp(key, "chain_trace")) {   // value = 1 + index of the chained launch of an encoder pass to stamp (gemm_chain.h: ChainArgs::trace); 0 = off
     const size_t bytes = (size_t)256 * 64 * 4 * sizeof(unsigned long long);
+    if (sync_all(e)) return RK_ERR_HIP;
     if (value && !e->chain_trace) { if (hipMalloc(&e->chain_trace, bytes) != hipSuccess) return RK_ERR_HIP; }
     if (e->chain_trace) hipMemset(e->chain_trace, 0, bytes);
     if (!value && e->chain_trace) { hipFree(e->chain_trace); e->chain_trace = nullptr; }
+    e->opt_chain_trace_launch = value - 1;
     return RK_OK;
   }
 #endif

@@ -24,11 +24,18 @@ for only in [int(x) for x in os.environ.get("RK_ONLY", "1,2").split(",")]:
     for dbg in [int(x) for x in os.environ.get("RK_DEBUG", "0").split(",")]:
         for lead in [int(x) for x in os.environ.get("RK_LEAD", "3").split(",")]:
             eng.set_option("chain", 1); eng.set_option("chain_only", only); eng.set_option("chain_debug", dbg); eng.set_option("chain_lead", lead)
-            eng.set_option("chain_trace", 1)
             for _ in range(2):
                 eng.score_staged([0], [bench.YES_ID, bench.NO_ID], slot=0)
             eng.sync()
+            # one launch of the middle of the pass: with both pairs chained launch 2 l is layer l's {O -> FFN-in}, 2 l + 1 its
+            # {FFN-out -> QKV}; with one pair chained launch l is layer l's
+            which = 12 if only else (24 if os.environ.get("RK_PAIR", "A") == "A" else 25)
+            eng.set_option("chain_trace", 1 + which)             # (clears the buffer)
+            eng.score_staged([0], [bench.YES_ID, bench.NO_ID], slot=0)
+            eng.sync()
             raw = eng.debug_read("chain_trace", 256 * 64 * 4 * 2).view(np.uint64).reshape(256, 64, 4)
+            eng.set_option("chain_debug", dbg)
+            eng.set_option("chain_trace", 0)
             eng.profile(True); eng.profile_reset()
             eng.score_staged([0], [bench.YES_ID, bench.NO_ID], slot=0); eng.sync()
             rep = eng.profile_report(); eng.profile(False)
