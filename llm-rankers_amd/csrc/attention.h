@@ -1042,11 +1042,37 @@ __global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
     sQ[lane] = (float)p.q[qrow * p.ldq + h * 64 + lane];
     __builtin_amdgcn_wave_barrier();
     float mx = -1e30f;
-    for (int j = lane; j < nk; j += 64) {
-      float s = dec_qk_dot(sQ, sK + j * ATTS_KSTR);
-      if (p.bias_lut) s += dec_bias(p.bias_lut, h, j, i);
-      sP[j] = s;
-      mx = fmaxf(mx, s);
+    // scores: a lane's keys lane, lane + 64, ... four at a time - the four dot products are independent chains (each the
+    // fma sequence of dec_qk_dot, so the bits are those of the per-row kernel) and share the reads of q
+    for (int j0 = lane; j0 < nk; j0 += 256) {
+      float sc[4] = {0.f, 0.f, 0.f, 0.f};
+      const half_t* kr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int j = j0 + 64 * u; kr[u] = sK + (j < nk ? j : j0) * ATTS_KSTR; }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const f32x4 q0 = *(const f32x4*)(sQ + c * 8), q1 = *(const f32x4*)(sQ + c * 8 + 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const half8 kk = *(const half8*)(kr[u] + c * 8);
+          float s = sc[u];
+          s = __builtin_fmaf(q0[0], (float)kk[0], s); s = __builtin_fmaf(q0[1], (float)kk[1], s);
+          s = __builtin_fmaf(q0[2], (float)kk[2], s); s = __builtin_fmaf(q0[3], (float)kk[3], s);
+          s = __builtin_fmaf(q1[0], (float)kk[4], s); s = __builtin_fmaf(q1[1], (float)kk[5], s);
+          s = __builtin_fmaf(q1[2], (float)kk[6], s); s = __builtin_fmaf(q1[3], (float)kk[7], s);
+          sc[u] = s;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + 64 * u;
+        if (j < nk) {
+          float s = sc[u];
+          if (p.bias_lut) s += dec_bias(p.bias_lut, h, j, i);
+          sP[j] = s;
+          mx = fmaxf(mx, s);
+        }
+      }
     }
     mx = wave_max(mx);
     float ssum[4];
@@ -1062,10 +1088,37 @@ __global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
     }
     const float sum = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
     __builtin_amdgcn_wave_barrier();
+    // P V: the four key shares w = 0 .. 3 of the per-row kernel's waves, each as its four chains (dec_pv_part) - sixteen
+    // independent chains walked together while all of them have their next key, then each share finishes on its own
     const half_t* vb = sV + lane;
+    float a[4][4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a[w][c] = 0.f;
+    int b0 = 0;
+    for (; b0 + 15 < nk; b0 += 16) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int j = b0 + w + 4 * c;
+          a[w][c] = __builtin_fmaf(sP[j], (float)vb[j * 64], a[w][c]);
+        }
+    }
     float part[4];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) part[w] = dec_pv_part(sP, nk, w, [&](int j) { return (float)vb[j * 64]; });
+    for (int w = 0; w < 4; ++w) {
+      int j = b0 + w;
+      for (; j + 12 < nk; j += 16) {
+        a[w][0] = __builtin_fmaf(sP[j], (float)vb[j * 64], a[w][0]);
+        a[w][1] = __builtin_fmaf(sP[j + 4], (float)vb[(j + 4) * 64], a[w][1]);
+        a[w][2] = __builtin_fmaf(sP[j + 8], (float)vb[(j + 8) * 64], a[w][2]);
+        a[w][3] = __builtin_fmaf(sP[j + 12], (float)vb[(j + 12) * 64], a[w][3]);
+      }
+      for (; j < nk; j += 4) a[w][0] = __builtin_fmaf(sP[j], (float)vb[j * 64], a[w][0]);
+      part[w] = (a[w][0] + a[w][1]) + (a[w][2] + a[w][3]);
+    }
     const float acc = (part[0] + part[1]) + (part[2] + part[3]);
     p.ctx[qrow * p.ldctx + h * 64 + lane] = f2h_sat(acc / sum);
     __builtin_amdgcn_wave_barrier();

@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-mkdir -p gpurun_out/c6
-RK_ENGINE_LIB=exp/librk_engine_measure.so RK_ONLY=1,2 RK_DEBUG=0,6,14 RK_LEAD=3 timeout 600 python tools/chain_trace.py > gpurun_out/c6/trace.jsonl 2> gpurun_out/c6/trace.err; echo "trace rc=$?"
-cut -c1-1500 gpurun_out/c6/trace.jsonl; tail -3 gpurun_out/c6/trace.err
-timeout 600 python tools/chain_check.py > gpurun_out/c6/chain_check.jsonl 2> gpurun_out/c6/chain_check.err; echo "chain_check rc=$?"
-grep -v '"shape"' gpurun_out/c6/chain_check.jsonl | cut -c1-1300; grep -c '"lead3_bit_identical": true' gpurun_out/c6/chain_check.jsonl
-tail -3 gpurun_out/c6/chain_check.err
+mkdir -p gpurun_out/c8
+timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -8 > gpurun_out/c8/pytest_gpu.log; cat gpurun_out/c8/pytest_gpu.log
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/c8/qlm_prof -o qlm -- python $GRAFT_REPO_ROOT/tools/bench_qlm_xl.py > $GRAFT_REPO_ROOT/gpurun_out/c8/qlm_prof_stdout.txt 2>&1; cd $GRAFT_REPO_ROOT
+find gpurun_out/c8/qlm_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/c8/qlm_xl_kernel_stats.csv; head -16 gpurun_out/c8/qlm_xl_kernel_stats.csv | cut -c1-200
+find gpurun_out/c8/qlm_prof -name "*kernel_trace.csv" -delete
+RK_L=1560 timeout 300 python tools/profile_compare.py 2>/dev/null | tail -1 > gpurun_out/c8/compare_profile_1560.json; cat gpurun_out/c8/compare_profile_1560.json
