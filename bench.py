@@ -329,7 +329,7 @@ def profile_pass(eng, pipe, G, M_tokens):
     frac_rocprof = None
     try:
         import csv
-        want = "gemm_chain_kernel" if dom.startswith("enc_chain") else {"enc_gemm_ffn_in": "gemm_pp2_kernel<2, 0, true>", "enc_gemm_qkv": "gemm_pp2_kernel<0, 0, true>"}.get(dom, "gemm_pp2_kernel<1, 0, false>")
+        want = "gemm_chain_kernel" if dom.startswith("enc_chain") else {"enc_gemm_ffn_in": "gemm_pp2_kernel<2, 0, true", "enc_gemm_qkv": "gemm_pp2_kernel<0, 0, true"}.get(dom, "gemm_pp2_kernel<1, 0, false")
         with open(os.path.join(REPO, "profiles", "bench_kernel_stats_latest.csv")) as f:
             rows = [r for r in csv.DictReader(f) if want in r["Name"]]
         if rows and pm.get("tokens_per_launch") == M_tokens:

@@ -1036,10 +1036,23 @@ __global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
     *(half8*)(sV + r * 64 + c * 8) = *(const half8*)(p.v + g);
   }
   __syncthreads();
-  for (int i = wave; i < p.Lq; i += 4) {
+  // the wave's query rows i = wave, wave + 4, ...: their q values are requested eight rows ahead (a row's own global round trip in
+  // front of every row was a third of its time)
+  half_t qpre[8];
+  for (int i = wave, n = 0; i < p.Lq; i += 4, ++n) {
+    if ((n & 7) == 0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int iu = i + 4 * u;
+        qpre[u] = p.q[((size_t)b * p.Lq + (iu < p.Lq ? iu : i)) * p.ldq + h * 64 + lane];
+      }
+    }
     const int nk = p.causal ? (i + 1 < Lk ? i + 1 : Lk) : Lk;
     const size_t qrow = (size_t)b * p.Lq + i;
-    sQ[lane] = (float)p.q[qrow * p.ldq + h * 64 + lane];
+    half_t qv = qpre[0];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) if ((n & 7) == u) qv = qpre[u];
+    sQ[lane] = (float)qv;
     __builtin_amdgcn_wave_barrier();
     float mx = -1e30f;
     // scores: a lane's keys lane, lane + 64, ... four at a time - the four dot products are independent chains (each the
@@ -1049,11 +1062,13 @@ __global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
       const half_t* kr[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) { const int j = j0 + 64 * u; kr[u] = sK + (j < nk ? j : j0) * ATTS_KSTR; }
+      const int nu = (nk - (j0 - lane) + 63) >> 6;       // chains of this pass that hold a key for SOME lane (uniform): 1 for a short prefix
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const f32x4 q0 = *(const f32x4*)(sQ + c * 8), q1 = *(const f32x4*)(sQ + c * 8 + 4);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+          if (u >= nu) continue;
           const half8 kk = *(const half8*)(kr[u] + c * 8);
           float s = sc[u];
           s = __builtin_fmaf(q0[0], (float)kk[0], s); s = __builtin_fmaf(q0[1], (float)kk[1], s);
@@ -1079,12 +1094,15 @@ __global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) {                  // the per-row kernel's thread tid = 64 w + lane owns keys tid, tid + 256, ...
       float sum = 0.f;
-      for (int j = w * 64 + lane; j < nk; j += 256) {
-        const float e = __expf(sP[j] - mx);
-        sP[j] = e;
-        sum += e;
+      if (nk > 64 * w) {                           // (a share without keys sums to +0: the reduction tree below is unchanged)
+        for (int j = w * 64 + lane; j < nk; j += 256) {
+          const float e = __expf(sP[j] - mx);
+          sP[j] = e;
+          sum += e;
+        }
+        sum = wave_sum(sum);
       }
-      ssum[w] = wave_sum(sum);
+      ssum[w] = sum;
     }
     const float sum = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
     __builtin_amdgcn_wave_barrier();

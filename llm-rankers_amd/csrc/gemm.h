@@ -52,6 +52,7 @@ struct GemmArgs {
   const int* lse_labels; int lse_npos; float* lse_xlab;
   // ping-pong kernel: width (in tiles) of the column panels of the grouped tile order (gemm_tile_coords); host default GEMM_GROUP_N
   int group_n;
+  int stagger_ticks;   // ping-pong kernel, fp32 residual epilogue: start delay of half of the workgroups (100 MHz ticks), 0 = none
 };
 
 #define GEMM_BM 128
@@ -994,7 +995,12 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 #define GEMM_PP2_RISSUE 0
 #endif
 // RS: consumer side of the folded RMSNorm - the accumulators of row m are multiplied by p.rowscale[m] (gemm_epilogue_staged)
-template <int EPI, int KO = 0, bool RS = false>
+// EDEPTH / p.stagger_ticks (round 5 experiment, fp32 residual epilogue): the lock-step launch runs its read-modify-write epilogues
+// at the chip's memory rate (8.9 TB/s over 256 CUs); alone, a CU's epilogue is bound by the bytes IT keeps in flight (one slab per
+// wave: 26 KB/us, the chained launch's timeline).  Half of the workgroups ((blockIdx.x >> 3) & 1: half of every XCD) may start
+// p.stagger_ticks of the 100 MHz wall clock late, so that one half's epilogues fall into the other half's main loops, with the old
+// rows of EDEPTH slabs requested ahead.
+template <int EPI, int KO = 0, bool RS = false, int EDEPTH = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   constexpr int HALF = 128 * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
@@ -1160,6 +1166,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   using W4 = integral_constant<int, 4>; using W2 = integral_constant<int, 2>; using W0c = integral_constant<int, 0>;
   using WN = integral_constant<int, -1>;
   int tile = blockIdx.x;
+  if constexpr (EPI == EPI_RESID_F32) {
+    if (p.stagger_ticks > 0 && ((blockIdx.x >> 3) & 1)) {
+      const long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   set_tile(tile);
   issue_prologue();
   while (true) {
@@ -1228,7 +1240,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   // fp32 outputs: 16 rows per pass (16 x 272 B per wave); fp16 outputs fit whole 32-row slabs (32 x 144 B)
   constexpr bool F32OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32;
   constexpr int EROWS = F32OUT ? 16 : 32;
-  gemm_epilogue_staged<EPI, 2, 4, false, EROWS>(p, acc, mbase, nbase, lane, gemm_smem + 114688 + wave * 4608, rsc);
+  gemm_epilogue_staged<EPI, 2, 4, false, EROWS, EDEPTH>(p, acc, mbase, nbase, lane, gemm_smem + 114688 + wave * 4608, rsc);
   if (next >= ntiles) break;
   tile = next;
   __syncthreads();   // staging rows are read before the next tile's DMA wraps around to W1 | stage 1

@@ -115,7 +115,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_chain_debug = 0, opt_chain_only = 0, opt_chain_trace_launch = 0;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_gemm_stagger_us = 0, opt_gemm_epi_depth = 0, opt_chain_debug = 0, opt_chain_only = 0, opt_chain_trace_launch = 0;
   unsigned long long* chain_trace = nullptr;   // measurement builds only (option chain_trace)
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
@@ -223,11 +223,11 @@ void launch_v2(hipStream_t st, const GemmArgs& a) {
   hipLaunchKernelGGL((gemm_v2_kernel<EPI, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), smem, st, a);
 }
 
-template <int EPI, int KO = 0, bool RS = false>
+template <int EPI, int KO = 0, bool RS = false, int EDEPTH = 0>
 void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
   constexpr int smem = 2 * 4 * 128 * 64 * 2 + 32768;   // 8 half-tile buffers + 32 KiB epilogue staging = all 160 KiB
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void*)gemm_pp2_kernel<EPI, KO, RS>, smem, attr_done);
+  ensure_dynamic_lds((const void*)gemm_pp2_kernel<EPI, KO, RS, EDEPTH>, smem, attr_done);
   const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
   // persistent: one workgroup per CU walks the tiles (max_wgs = CUs rounded down to a multiple of 8 keeps the tile -> XCD
   // association); max_wgs <= 0: one workgroup per tile
@@ -238,7 +238,7 @@ void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
   // MFMA phases at no cost to the critical path: o 0.496 -> 0.484 ms per step in the serial profile, 7302-7340 against
   // 7338-7376 passages/s in the pipeline - the epilogue's cost is not a shared-HBM burst that de-phasing would spread)
   const int grid = max_wgs > 0 && tiles > max_wgs ? max_wgs : tiles;
-  hipLaunchKernelGGL((gemm_pp2_kernel<EPI, KO, RS>), dim3(grid), dim3(512), smem, st, a);
+  hipLaunchKernelGGL((gemm_pp2_kernel<EPI, KO, RS, EDEPTH>), dim3(grid), dim3(512), smem, st, a);
 }
 
 // Tile-shape choice.  variant: 0 = auto, 1 = 128x128 (v1, two workgroups per CU), 2 = 256x256, 3 = 256x192,
@@ -365,6 +365,17 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a_in, int for
     const int wgs = e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7);
     if constexpr (EPI == EPI_STORE_F16 || EPI_IS_GATED(EPI) || EPI == EPI_RELU_F16) {
       if (a.rowscale) { launch_pp2<EPI, 0, true>(st, a, wgs); return; }   // consumer side of the folded RMSNorm
+    }
+    if constexpr (EPI == EPI_RESID_F32) {
+      // (round-5 experiment, off by default: half of the workgroups start late, old rows of three slabs requested ahead)
+      if (e->opt_gemm_stagger_us > 0 && a.xraw && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 2 * wgs) {
+        GemmArgs b = a;
+        b.stagger_ticks = (int)(100.0 * e->opt_gemm_stagger_us * a.K / 1024.0);
+        if (e->opt_gemm_epi_depth >= 2) launch_pp2<EPI, 0, false, 3>(st, b, wgs);
+        else launch_pp2<EPI>(st, b, wgs);
+        return;
+      }
+      if (e->opt_gemm_epi_depth >= 2) { launch_pp2<EPI, 0, false, 3>(st, a, wgs); return; }
     }
     launch_pp2<EPI>(st, a, wgs);
     return;
@@ -2214,6 +2225,8 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
   if (!strcmp(key, "dec_fuse_rows")) { e->opt_dec_fuse_rows = value; return RK_OK; }   // rows per workgroup of dec_cross_qk_kernel (0 = auto; A/B)
   if (!strcmp(key, "dec_fuse")) { e->opt_dec_fuse = value; return RK_OK; }   // few-row decoder: projections around the query-side cross-attention fused per (head, row slab): 1 = at one decoder position (default), 2 = always, 0 = separate GEMMs
+  if (!strcmp(key, "gemm_stagger_us")) { e->opt_gemm_stagger_us = value; return RK_OK; }   // residual ping-pong GEMMs: half of the workgroups start value x K / 1024 us late (experiment, 0 = off)
+  if (!strcmp(key, "gemm_epi_depth")) { e->opt_gemm_epi_depth = value; return RK_OK; }     // residual ping-pong GEMMs: old fp32 rows of three slabs requested ahead (>= 2) or one slab at a time (0)
   if (!strcmp(key, "dec_attn_seq")) { e->opt_dec_attn_seq = value != 0; ++e->opt_epoch; return RK_OK; }   // decoder attention at several positions: one workgroup per (head, sequence) with K / V staged in LDS (1) or one per query row (0); same bits
   if (!strcmp(key, "chain")) { e->opt_chain = value != 0; return RK_OK; }   // encoder: O -> FFN-in and FFN-out -> next QKV as chained launches (gemm_chain.h) when the batch is large enough (1) or always separate launches (0); same bits
   if (!strcmp(key, "chain_lead")) { if (value < 1 || value > 16) return fail(e, RK_ERR_INVALID, "chain_lead 1..16"); e->opt_chain_lead = value; return RK_OK; }   // producer lead of a chained launch in blocks of four row panels

@@ -97,7 +97,7 @@ def test_dma_attention_keeps_its_dma_queue_and_its_asm_destinations(isa, ng):
 # (epilogue kind, folded-RMSNorm row factors): every product instantiation of the ping-pong kernel
 @pytest.mark.parametrize("epi,rs", [(0, 0), (0, 1), (1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (4, 0)])
 def test_pingpong_gemm_k_loop_keeps_loads_in_flight(isa, epi, rs):
-    body = kernel_body(isa, f"_Z15gemm_pp2_kernelILi{epi}ELi0ELb{rs}EEv8GemmArgs")
+    body = kernel_body(isa, f"_Z15gemm_pp2_kernelILi{epi}ELi0ELb{rs}ELi0EEv8GemmArgs")
     assert not any("scratch_" in l for l in body), "ping-pong GEMM spills"
     # the K loop = the innermost loop that holds MFMAs
     heads = [i for i, l in enumerate(body) if "Inner Loop Header" in l]

@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-mkdir -p gpurun_out/c8
-timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -8 > gpurun_out/c8/pytest_gpu.log; cat gpurun_out/c8/pytest_gpu.log
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/c8/qlm_prof -o qlm -- python $GRAFT_REPO_ROOT/tools/bench_qlm_xl.py > $GRAFT_REPO_ROOT/gpurun_out/c8/qlm_prof_stdout.txt 2>&1; cd $GRAFT_REPO_ROOT
-find gpurun_out/c8/qlm_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/c8/qlm_xl_kernel_stats.csv; head -16 gpurun_out/c8/qlm_xl_kernel_stats.csv | cut -c1-200
-find gpurun_out/c8/qlm_prof -name "*kernel_trace.csv" -delete
-RK_L=1560 timeout 300 python tools/profile_compare.py 2>/dev/null | tail -1 > gpurun_out/c8/compare_profile_1560.json; cat gpurun_out/c8/compare_profile_1560.json
+mkdir -p gpurun_out/c9
+timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -p no:cacheprovider -k "per_sequence or qlm or two_token" 2>&1 | tail -3
+timeout 300 python tools/bench_qlm_xl.py 2>/dev/null | tail -1 > gpurun_out/c9/qlm_xl.json; cut -c1-1500 gpurun_out/c9/qlm_xl.json
+timeout 900 python tools/sweep.py "G=10,steps=40,warmup=10,rep=2" "G=10,steps=40,warmup=10,rep=2,gemm_epi_depth=3" "G=10,steps=40,warmup=10,rep=2,gemm_epi_depth=3,gemm_stagger_us=12" "G=10,steps=40,warmup=10,rep=2,gemm_epi_depth=3,gemm_stagger_us=18" "G=10,steps=40,warmup=10,rep=2,gemm_epi_depth=3,gemm_stagger_us=25" "G=10,steps=40,warmup=10,rep=2,gemm_stagger_us=18" "G=10,steps=40,warmup=10,rep=2" "G=10,steps=40,warmup=10,rep=2,overlap=0" "G=10,steps=40,warmup=10,rep=2,overlap=0,gemm_epi_depth=3,gemm_stagger_us=18" 2>/dev/null > gpurun_out/c9/stagger_sweep.jsonl; cat gpurun_out/c9/stagger_sweep.jsonl
