@@ -935,6 +935,25 @@ __device__ __forceinline__ float dec_qk_dot(const float* sQ, const half_t* kr) {
   }
   return s;
 }
+// Whole-wave sum / max for the decoder attention kernels without LDS round trips (wave_sum / wave_max of common.h go through six
+// ds_bpermute each: ~1 us of a row's ~8 us): the 16 lanes of a DPP row by quad swaps and row rotations (row16_sum_f), then the four
+// rows by v_readlane in a fixed order.  Every lane gets the result; ONE definition for both kernels (same bits).
+__device__ __forceinline__ float dec_wave_sum(float v) {
+  v = row16_sum_f(v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float dec_wave_max(float v) {
+  v = row16_max(v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
 __device__ __forceinline__ float dec_bias(const float* lut, int h, int j, int i) {
   int rel = j - i;
   rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
@@ -981,7 +1000,7 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
     sP[j] = s;
     mx = fmaxf(mx, s);
   }
-  mx = wave_max(mx);
+  mx = dec_wave_max(mx);
   if (lane == 0) sRed[wave] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
@@ -991,7 +1010,7 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
     sP[j] = e;
     sum += e;
   }
-  sum = wave_sum(sum);
+  sum = dec_wave_sum(sum);
   if (lane == 0) sRed[4 + wave] = sum;
   __syncthreads();
   sum = (sRed[4] + sRed[5]) + (sRed[6] + sRed[7]);
@@ -1009,13 +1028,17 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
 // positions, ref: llmrankers/pointwise.py:41-82; greedy prefixes): the per-row kernel above is launched as L_d x H x B
 // workgroups that each re-read the head's K and V rows of their sequence (27 x 36 KB through L2 per (head, sequence) in a
 // flan-t5-xl qlm call: 0.72 ms per launch, 34 of the 83 ms of a hits=100 query).  Here the K rows (144-byte stride: the lanes'
-// 16-byte reads fall on different banks) and V rows of the head are staged in LDS once, and the four waves take the query rows
-// in turn - a wave computes a row with the arithmetic above, walking the four key shares of the per-row kernel's waves one
-// after the other (same chains, same trees: bit-identical).  grid = (H, B); not for the tree form.
+// 16-byte reads fall on different banks), the V rows and the head's bias table are staged in LDS once, and the four waves take the
+// query rows in turn.  A row is computed with the arithmetic above - the four key shares of the per-row kernel's waves walked by
+// one wave, same chains, same trees: BIT-IDENTICAL to the per-row kernel (tests).  Causal rows (self-attention: few keys) go one
+// at a time; rows without a mask (cross-attention: every row sees all keys of the sequence) go FOUR AT A TIME - a K row, a V
+// element and the four rows' probabilities (kept interleaved, one 16-byte broadcast read per key) are read from LDS once for the
+// four rows, which is what the kernel's time is made of (round 5: LDS instructions per row 350 -> ~95).
+// grid = (H, B); not for the tree form.
 #define ATTS_KSTR 72
 __host__ __device__ inline size_t attn_dec_seq_lds(int max_keys) {
   const size_t kp = ((size_t)max_keys + 3) & ~(size_t)3;
-  return kp * ATTS_KSTR * 2 + kp * 64 * 2 + 4 * (64 + kp) * sizeof(float);
+  return kp * ATTS_KSTR * 2 + kp * 64 * 2 + RK_LUT_N * sizeof(float) + 12 + 4 * (64 * 4 + kp * 4) * sizeof(float);
 }
 __global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
   extern __shared__ __attribute__((aligned(16))) float dec_smem[];
@@ -1024,8 +1047,9 @@ __global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
   const int kp = (p.max_keys + 3) & ~3;
   half_t* sK = (half_t*)dec_smem;                  // [kp][ATTS_KSTR]
   half_t* sV = sK + (size_t)kp * ATTS_KSTR;        // [kp][64]
-  float* sQ = (float*)(sV + (size_t)kp * 64) + (size_t)wave * (64 + kp);   // [64]   (wave-private from here on)
-  float* sP = sQ + 64;                             // [kp]
+  float* sLut = (float*)(sV + (size_t)kp * 64);    // [RK_LUT_N (+3)]  this head's bias by clamp(key - query)
+  float* sQ = sLut + RK_LUT_N + 3 + (size_t)wave * (64 * 4 + kp * 4);   // [4][64]   (wave-private from here on)
+  float* sP = sQ + 64 * 4;                         // [kp][4]: the probabilities of the wave's (up to) four rows, interleaved
   int koff, Lk;
   if (p.key_off) { koff = p.key_off[b]; Lk = p.key_off[b + 1] - koff; }
   else { koff = b * p.Lq; Lk = p.Lq; }
@@ -1035,85 +1059,160 @@ __global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
     *(half8*)(sK + r * ATTS_KSTR + c * 8) = *(const half8*)(p.k + g);
     *(half8*)(sV + r * 64 + c * 8) = *(const half8*)(p.v + g);
   }
+  if (p.bias_lut)
+    for (int idx = tid; idx < RK_LUT_N; idx += 256) sLut[idx] = p.bias_lut[h * RK_LUT_N + idx];
   __syncthreads();
-  // the wave's query rows i = wave, wave + 4, ...: their q values are requested eight rows ahead (a row's own global round trip in
-  // front of every row was a third of its time)
-  half_t qpre[8];
-  for (int i = wave, n = 0; i < p.Lq; i += 4, ++n) {
-    if ((n & 7) == 0) {
+  auto bias_at = [&](int j, int i) {
+    int rel = j - i;
+    rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
+    return sLut[rel + RK_LUT_R];
+  };
+  const half_t* vb = sV + lane;
+  if (p.causal || p.bias_lut) {
+    // ---- one row at a time (self-attention: nk = i + 1 keys) ----
+    for (int i = wave; i < p.Lq; i += 4) {
+      const int nk = p.causal ? (i + 1 < Lk ? i + 1 : Lk) : Lk;
+      const size_t qrow = (size_t)b * p.Lq + i;
+      sQ[lane] = (float)p.q[qrow * p.ldq + h * 64 + lane];
+      __builtin_amdgcn_wave_barrier();
+      float mx = -1e30f;
+      for (int j0 = lane; j0 < nk; j0 += 256) {
+        float sc[4] = {0.f, 0.f, 0.f, 0.f};
+        const half_t* kr[4];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int iu = i + 4 * u;
-        qpre[u] = p.q[((size_t)b * p.Lq + (iu < p.Lq ? iu : i)) * p.ldq + h * 64 + lane];
+        for (int u = 0; u < 4; ++u) { const int j = j0 + 64 * u; kr[u] = sK + (j < nk ? j : j0) * ATTS_KSTR; }
+        const int nu = (nk - (j0 - lane) + 63) >> 6;       // chains of this pass that hold a key for SOME lane (uniform)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const f32x4 q0 = *(const f32x4*)(sQ + c * 8), q1 = *(const f32x4*)(sQ + c * 8 + 4);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (u >= nu) continue;
+            const half8 kk = *(const half8*)(kr[u] + c * 8);
+            float s = sc[u];
+            s = __builtin_fmaf(q0[0], (float)kk[0], s); s = __builtin_fmaf(q0[1], (float)kk[1], s);
+            s = __builtin_fmaf(q0[2], (float)kk[2], s); s = __builtin_fmaf(q0[3], (float)kk[3], s);
+            s = __builtin_fmaf(q1[0], (float)kk[4], s); s = __builtin_fmaf(q1[1], (float)kk[5], s);
+            s = __builtin_fmaf(q1[2], (float)kk[6], s); s = __builtin_fmaf(q1[3], (float)kk[7], s);
+            sc[u] = s;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + 64 * u;
+          if (j < nk) {
+            float s = sc[u];
+            if (p.bias_lut) s += bias_at(j, i);
+            sP[j] = s;
+            mx = fmaxf(mx, s);
+          }
+        }
       }
-    }
-    const int nk = p.causal ? (i + 1 < Lk ? i + 1 : Lk) : Lk;
-    const size_t qrow = (size_t)b * p.Lq + i;
-    half_t qv = qpre[0];
+      mx = dec_wave_max(mx);
+      float ssum[4];
 #pragma unroll
-    for (int u = 1; u < 8; ++u) if ((n & 7) == u) qv = qpre[u];
-    sQ[lane] = (float)qv;
+      for (int w = 0; w < 4; ++w) {                  // the per-row kernel's thread tid = 64 w + lane owns keys tid, tid + 256, ...
+        float sum = 0.f;
+        if (nk > 64 * w) {                           // (a share without keys sums to +0: the reduction tree below is unchanged)
+          for (int j = w * 64 + lane; j < nk; j += 256) {
+            const float e = __expf(sP[j] - mx);
+            sP[j] = e;
+            sum += e;
+          }
+          sum = dec_wave_sum(sum);
+        }
+        ssum[w] = sum;
+      }
+      const float sum = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+      __builtin_amdgcn_wave_barrier();
+      float part[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) part[w] = dec_pv_part(sP, nk, w, [&](int j) { return (float)vb[j * 64]; });
+      const float acc = (part[0] + part[1]) + (part[2] + part[3]);
+      p.ctx[qrow * p.ldctx + h * 64 + lane] = f2h_sat(acc / sum);
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+  // ---- four rows at a time (no mask, no bias: every row of the block sees keys 0 .. Lk-1) ----
+  const int nk = Lk;
+  for (int i0 = wave; i0 < p.Lq; i0 += 16) {
+    int rows[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int i = i0 + 4 * r; rows[r] = i < p.Lq ? i : i0; }   // (a missing row repeats the first: computed, not stored)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sQ[r * 64 + lane] = (float)p.q[((size_t)b * p.Lq + rows[r]) * p.ldq + h * 64 + lane];
     __builtin_amdgcn_wave_barrier();
-    float mx = -1e30f;
-    // scores: a lane's keys lane, lane + 64, ... four at a time - the four dot products are independent chains (each the
-    // fma sequence of dec_qk_dot, so the bits are those of the per-row kernel) and share the reads of q
+    float mx[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
     for (int j0 = lane; j0 < nk; j0 += 256) {
-      float sc[4] = {0.f, 0.f, 0.f, 0.f};
+      float sc[4][4];                                   // [row][chain]
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sc[r][u] = 0.f;
       const half_t* kr[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) { const int j = j0 + 64 * u; kr[u] = sK + (j < nk ? j : j0) * ATTS_KSTR; }
-      const int nu = (nk - (j0 - lane) + 63) >> 6;       // chains of this pass that hold a key for SOME lane (uniform): 1 for a short prefix
+      const int nu = (nk - (j0 - lane) + 63) >> 6;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const f32x4 q0 = *(const f32x4*)(sQ + c * 8), q1 = *(const f32x4*)(sQ + c * 8 + 4);
+        half8 kk[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (u >= nu) continue;
-          const half8 kk = *(const half8*)(kr[u] + c * 8);
-          float s = sc[u];
-          s = __builtin_fmaf(q0[0], (float)kk[0], s); s = __builtin_fmaf(q0[1], (float)kk[1], s);
-          s = __builtin_fmaf(q0[2], (float)kk[2], s); s = __builtin_fmaf(q0[3], (float)kk[3], s);
-          s = __builtin_fmaf(q1[0], (float)kk[4], s); s = __builtin_fmaf(q1[1], (float)kk[5], s);
-          s = __builtin_fmaf(q1[2], (float)kk[6], s); s = __builtin_fmaf(q1[3], (float)kk[7], s);
-          sc[u] = s;
+        for (int u = 0; u < 4; ++u) if (u < nu) kk[u] = *(const half8*)(kr[u] + c * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 q0 = *(const f32x4*)(sQ + r * 64 + c * 8), q1 = *(const f32x4*)(sQ + r * 64 + c * 8 + 4);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (u >= nu) continue;
+            float s = sc[r][u];
+            s = __builtin_fmaf(q0[0], (float)kk[u][0], s); s = __builtin_fmaf(q0[1], (float)kk[u][1], s);
+            s = __builtin_fmaf(q0[2], (float)kk[u][2], s); s = __builtin_fmaf(q0[3], (float)kk[u][3], s);
+            s = __builtin_fmaf(q1[0], (float)kk[u][4], s); s = __builtin_fmaf(q1[1], (float)kk[u][5], s);
+            s = __builtin_fmaf(q1[2], (float)kk[u][6], s); s = __builtin_fmaf(q1[3], (float)kk[u][7], s);
+            sc[r][u] = s;
+          }
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = j0 + 64 * u;
         if (j < nk) {
-          float s = sc[u];
-          if (p.bias_lut) s += dec_bias(p.bias_lut, h, j, i);
-          sP[j] = s;
-          mx = fmaxf(mx, s);
+          const f32x4 v4 = {sc[0][u], sc[1][u], sc[2][u], sc[3][u]};
+          *(f32x4*)(sP + j * 4) = v4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx[r] = fmaxf(mx[r], sc[r][u]);
         }
       }
     }
-    mx = wave_max(mx);
-    float ssum[4];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {                  // the per-row kernel's thread tid = 64 w + lane owns keys tid, tid + 256, ...
-      float sum = 0.f;
-      if (nk > 64 * w) {                           // (a share without keys sums to +0: the reduction tree below is unchanged)
+    for (int r = 0; r < 4; ++r) mx[r] = dec_wave_max(mx[r]);
+    float ssum[4][4];                                    // [row][share]
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+      if (nk > 64 * w) {
         for (int j = w * 64 + lane; j < nk; j += 256) {
-          const float e = __expf(sP[j] - mx);
-          sP[j] = e;
-          sum += e;
+          f32x4 v4 = *(const f32x4*)(sP + j * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float e = __expf(v4[r] - mx[r]); v4[r] = e; sum[r] += e; }
+          *(f32x4*)(sP + j * 4) = v4;
         }
-        sum = wave_sum(sum);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] = dec_wave_sum(sum[r]);
       }
-      ssum[w] = sum;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ssum[r][w] = sum[r];
     }
-    const float sum = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
     __builtin_amdgcn_wave_barrier();
-    // P V: the four key shares w = 0 .. 3 of the per-row kernel's waves, each as its four chains (dec_pv_part) - sixteen
-    // independent chains walked together while all of them have their next key, then each share finishes on its own
-    const half_t* vb = sV + lane;
-    float a[4][4];
+    // P V: per row the four key shares x four chains of dec_pv_part; a V element and the four rows' probabilities are read once
+    float a[4][4][4];                                    // [row][share][chain]
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) a[w][c] = 0.f;
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[r][w][c] = 0.f;
     int b0 = 0;
     for (; b0 + 15 < nk; b0 += 16) {
 #pragma unroll
@@ -1121,24 +1220,43 @@ __global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const int j = b0 + w + 4 * c;
-          a[w][c] = __builtin_fmaf(sP[j], (float)vb[j * 64], a[w][c]);
+          const float v = (float)vb[j * 64];
+          const f32x4 p4 = *(const f32x4*)(sP + j * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r][w][c] = __builtin_fmaf(p4[r], v, a[r][w][c]);
         }
     }
-    float part[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       int j = b0 + w;
       for (; j + 12 < nk; j += 16) {
-        a[w][0] = __builtin_fmaf(sP[j], (float)vb[j * 64], a[w][0]);
-        a[w][1] = __builtin_fmaf(sP[j + 4], (float)vb[(j + 4) * 64], a[w][1]);
-        a[w][2] = __builtin_fmaf(sP[j + 8], (float)vb[(j + 8) * 64], a[w][2]);
-        a[w][3] = __builtin_fmaf(sP[j + 12], (float)vb[(j + 12) * 64], a[w][3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float v = (float)vb[(j + 4 * c) * 64];
+          const f32x4 p4 = *(const f32x4*)(sP + (j + 4 * c) * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r][w][c] = __builtin_fmaf(p4[r], v, a[r][w][c]);
+        }
       }
-      for (; j < nk; j += 4) a[w][0] = __builtin_fmaf(sP[j], (float)vb[j * 64], a[w][0]);
-      part[w] = (a[w][0] + a[w][1]) + (a[w][2] + a[w][3]);
+      for (; j < nk; j += 4) {
+        const float v = (float)vb[j * 64];
+        const f32x4 p4 = *(const f32x4*)(sP + j * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r][w][0] = __builtin_fmaf(p4[r], v, a[r][w][0]);
+      }
     }
-    const float acc = (part[0] + part[1]) + (part[2] + part[3]);
-    p.ctx[qrow * p.ldctx + h * 64 + lane] = f2h_sat(acc / sum);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * r;
+      if (i < p.Lq) {
+        const float sum = (ssum[r][0] + ssum[r][1]) + (ssum[r][2] + ssum[r][3]);
+        float part[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) part[w] = (a[r][w][0] + a[r][w][1]) + (a[r][w][2] + a[r][w][3]);
+        const float acc = (part[0] + part[1]) + (part[2] + part[3]);
+        p.ctx[((size_t)b * p.Lq + i) * p.ldctx + h * 64 + lane] = f2h_sat(acc / sum);
+      }
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
