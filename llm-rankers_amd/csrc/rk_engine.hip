@@ -288,6 +288,9 @@ GemmPlan choose_plan(const rk_engine* e, int epi, int M, int N, int K, bool fold
   double rest = 0;
   const int v_rest = choose_variant(e, epi, M - panels * 256, N, K, fold_producer, &rest);
   const double split = (double)((used + wgs - 1) / wgs) * 25.5 + rest + 1.5;   // + a kernel boundary
+  // opt_gemm_split = 2 (experiment): the residual GEMMs always split - their ping-pong round costs twice the model's figure (the
+  // read-modify-write epilogue), so a partial last round is dearer than the model thinks
+  if (e->opt_gemm_split >= 2 && epi == EPI_RESID_F32) { plan.m_pp2 = panels * 256; plan.variant = e->opt_gemm_split == 2 ? 1 : 4; return plan; }   // rest on 128x128 (2) / 256x128 (3) tiles
   if (split < whole - 1e-9) { plan.m_pp2 = panels * 256; plan.variant = v_rest; }
   return plan;
 }
@@ -2231,7 +2234,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "chain")) { e->opt_chain = value != 0; return RK_OK; }   // encoder: O -> FFN-in and FFN-out -> next QKV as chained launches (gemm_chain.h) when the batch is large enough (1) or always separate launches (0); same bits
   if (!strcmp(key, "chain_lead")) { if (value < 1 || value > 16) return fail(e, RK_ERR_INVALID, "chain_lead 1..16"); e->opt_chain_lead = value; return RK_OK; }   // producer lead of a chained launch in blocks of four row panels
   if (!strcmp(key, "chain_min_panels")) { if (value < 1) return fail(e, RK_ERR_INVALID, "chain_min_panels >= 1"); e->opt_chain_min_panels = value; return RK_OK; }   // fewest 256-row panels (M / 256) for the chained form
-  if (!strcmp(key, "gemm_split")) { e->opt_gemm_split = value != 0; return RK_OK; }   // rows beyond the ping-pong kernel's last whole round on a fill-in tile variant (1) or one launch (0)
+  if (!strcmp(key, "gemm_split")) { e->opt_gemm_split = value; return RK_OK; }   // rows beyond the ping-pong kernel's last whole round on a fill-in tile variant (1) or one launch (0)
   if (!strcmp(key, "gemm_group_n")) { e->opt_gemm_group_n = value; return RK_OK; }   // ping-pong GEMM: column-panel width of the tile order in tiles (0 = default 8)
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
     if (set_device(e) || sync_all(e)) return RK_ERR_HIP;
