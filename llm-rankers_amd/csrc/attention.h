@@ -22,6 +22,7 @@ struct AttnEncArgs {
   int ko;                // DMA kernel, measurement builds only: timing knock-outs (ATTD_KO)
   int n_seq;             // DMA kernel only: sequences in the batch
   float* trace;          // DMA kernel, measurement builds only: phase time stamps of one workgroup (ATTD_STAMP), else nullptr
+  int skip_long;         // tiled kernel: sequences longer than ATT_ROW_MAXL are left to attn_enc_long_kernel (round 5)
 };
 
 // Flash-style encoder self-attention.  grid = (ceil(maxL/128), H, B), 256 threads = 4 waves x 32 queries.
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p)
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;
   if (qt * 128 >= L) return;   // uniform for the whole block
+  if (p.skip_long && L > ATT_ROW_MAXL) return;
   const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;
   const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;      // within the group
   half_t (*sK)[64 * ATT_KSTR] = (half_t (*)[64 * ATT_KSTR])sGroup[grp];
@@ -898,6 +900,288 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
       else head(T{}, N1{}, T{}, n);
     }
     cur = nxt; nxt = item_done(raw0, ih0);
+  }
+}
+
+// Long sequences (L > ATT_ROW_MAXL: the setwise prompts, ~1.5k tokens; round 5).  The tiled kernel above stages K / V through
+// registers (V through a 16-bit transpose), runs the online softmax per 64-key tile and reaches 13-15 % of the MFMA peak on
+// eight 1 560-token prompts - a third of a lockstep setwise step.  This kernel brings the short-sequence kernel's recipe to
+// long sequences: a 768-thread workgroup = twelve waves x 32 queries takes 384 queries of one (sequence, head) and walks the
+// keys in chunks of 128: the chunk's K and V rows arrive by LDS-DMA (global_load_lds_dwordx4, swizzle on the source address,
+// the same row-major image as the short kernel: conflict-free ds_read_b128 K fragments, V^T by ds_read_b64_tr_b16) into one
+// of two stages while the previous chunk is computed (one barrier per chunk, behind a wait that has a whole chunk of compute to
+// be satisfied); the 64 scores of a query row per chunk are formed by 16 back-to-back MFMAs, ONE maximum per chunk, the online
+// merge (alpha, rescale of the 32 output accumulators) once per 128 keys instead of once per 64; the relative-position bias
+// comes from a per-chunk table of key - query (built from the head's table in LDS), and a wave whose 32 queries are at least
+// max_distance away from the whole chunk adds the bucket's constant instead (most chunks of a 1.5k prompt).
+// A sequence's result depends on ITS length only: every sequence longer than ATT_ROW_MAXL takes this kernel, in any batch
+// (attn_enc_kernel then only serves the batch's short sequences: AttnEncArgs::skip_long).  grid = (ceil(maxL / 384), H, n_seq).
+#define ATTL_KEYS 128
+// NW waves x 32 queries per workgroup (12 / 6 / 4 / 3): a query row's arithmetic does not depend on NW - the same chunks of 128 keys in
+// the same order, the same table values, the same near / far decision per wave - so the host picks NW from the batch (how many
+// workgroups fill the chip, how much of the last query block is empty, how often a sequence's K / V are re-read) like a GEMM tile shape
+#define ATTL_IMG_HALFS (ATTL_KEYS * 64)
+#define ATTL_TAB_N 512
+#define ATTL_LDS_BYTES (4 * ATTL_IMG_HALFS * 2 + 2 * ATTL_TAB_N * 4 + (RK_LUT_N + 3) * 4)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel(AttnEncArgs p) {
+  constexpr int ATTL_QUERIES = 32 * NW, ATTL_THREADS = 64 * NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char attl_smem[];
+  half_t* const sbuf = (half_t*)attl_smem;                                      // [stage][K image | V image], [128][64] each
+  float* const sTab = (float*)(attl_smem + 4 * ATTL_IMG_HALFS * 2);             // [stage][512]: bias(key - query) * log2(e) of a chunk
+  float* const sLutH = sTab + 2 * ATTL_TAB_N;                                   // this head's table * log2(e)
+  const int b = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
+  const int tok0 = p.seq_off[b];
+  const int L = p.seq_off[b + 1] - tok0;
+  const int Q0 = qb * ATTL_QUERIES;
+  if (L <= ATT_ROW_MAXL || Q0 >= L) return;                                     // uniform for the whole block
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int q0 = Q0 + wave * 32;
+  const bool active = q0 < L;                                                   // wave-uniform
+  const int nch = (L + ATTL_KEYS - 1) / ATTL_KEYS;
+  auto opaque_lane = [&]() {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+  };
+  struct LaneCtx { int hh, l31, qpos, kfo0, vfo0, tab_q; };
+  auto lane_ctx = [&](int lane) {
+    LaneCtx c;
+    c.hh = lane >> 5; c.l31 = lane & 31; c.qpos = q0 + c.l31;
+    c.kfo0 = c.l31 * 64 + ((c.hh ^ ATTD_SWZ(c.l31)) << 3);
+    const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+    c.vfo0 = (4 * c.hh + (i16 >> 2)) * 64 + (((2 * g1 + ((i16 & 3) >> 1)) ^ ((((i16 >> 3) & 1) << 2) | c.hh)) << 3) + 4 * (i16 & 1);
+    c.tab_q = (ATTL_QUERIES - 1) - (c.qpos - Q0) + 4 * c.hh;                    // sTab[tab_q + key - K0 - 4hh ...]: entry t <-> key - K0 - (query - Q0) + 383
+    return c;
+  };
+  // K and V rows of chunk ch -> stage st: 32 pieces of 64 sixteen-byte slots (K image 16, V image 16) over the twelve waves
+  auto issue_chunk = [&](int lane, int ch, int st) {
+#pragma unroll
+    for (int k = 0; k < (32 + NW - 1) / NW; ++k) {
+      const int pid = wave + NW * k;
+      if (pid < 32) {
+        const int which = pid >> 4, sub = pid & 15;
+        const int slot = sub * 64 + lane, r = slot >> 3, c = slot & 7;
+        int key = ch * ATTL_KEYS + r;
+        key = key < L ? key : L - 1;
+        const char* hb = (const char*)(p.qkv + (1 + which) * p.I + h * 64);
+        const unsigned off = ((unsigned)(tok0 + key) * (unsigned)p.ld + ((c ^ ATTD_SWZ(r)) << 3)) * 2u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hb + off),
+                                         (__attribute__((address_space(3))) void*)(sbuf + (2 * st + which) * ATTL_IMG_HALFS + sub * 512),
+                                         16, 0, 0);
+      }
+    }
+  };
+  // is any of the workgroup's queries within max_distance of chunk ch?  (then its table is built; uniform for the block)
+  auto chunk_near_wg = [&](int ch) {
+    const int lo = ch * ATTL_KEYS - (Q0 + ATTL_QUERIES - 1), hi = ch * ATTL_KEYS + ATTL_KEYS - 1 - Q0;     // range of key - query
+    return hi > -RK_LUT_R && lo < RK_LUT_R;
+  };
+  auto build_table = [&](int ch, int st) {
+    if (!chunk_near_wg(ch)) return;
+    for (int t = threadIdx.x; t < ATTL_KEYS + ATTL_QUERIES - 1; t += ATTL_THREADS) {
+      int rel = ch * ATTL_KEYS - Q0 + t - (ATTL_QUERIES - 1);
+      rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
+      sTab[st * ATTL_TAB_N + t] = sLutH[rel + RK_LUT_R];
+    }
+  };
+
+  // ---- prologue: the head's table, this lane's Q fragments, chunk 0 ----
+  for (int i = threadIdx.x; i < RK_LUT_N; i += ATTL_THREADS) sLutH[i] = p.bias_lut[h * RK_LUT_N + i] * ATT_LOG2E;
+  half8 qf[4];
+  {
+    const LaneCtx c = lane_ctx(opaque_lane());
+    const int qrow = c.qpos < L ? c.qpos : L - 1;
+    const half_t* qptr = p.qkv + (size_t)(tok0 + qrow) * p.ld + h * 64 + 8 * c.hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const half8*)(qptr + 16 * s);
+  }
+  issue_chunk(opaque_lane(), 0, 0);
+  __syncthreads();                                          // sLutH written
+  build_table(0, 0);
+  // (the Q fragments are "used" here: the compiler's own wait for these tracked loads then sits in front of the chunk loop, not at
+  // their first MFMA inside it, where - merged over the back edge - it would drain the DMA queue of every chunk)
+  asm volatile("" :: "v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;                        // l_run: this lane's half of the row sum (the halves meet at the end)
+
+  // scores of the chunk: two key tiles x 4 k16 steps, two MFMAs each; the K fragments of step i + 1 requested before the MFMAs of step i
+  auto qk_chunk = [&](const LaneCtx& c, const half_t* kbuf, f32x16 (&s)[2][2]) {
+    const half_t* kb_ = kbuf + c.kfo0;
+    half8 kf[2][2];
+    auto fetch = [&](int i, half8 (&d)[2]) {
+      const half_t* a = kb_ + (i >> 2) * 64 * 64 + ((c.kfo0 ^ ((i & 3) << 4)) - c.kfo0);
+      d[0] = *(const half8*)a;
+      d[1] = *(const half8*)(a + 32 * 64);
+    };
+    fetch(0, kf[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i + 1 < 8) fetch(i + 1, kf[(i + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int kt = i >> 2, ks = i & 3;
+      if (ks == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        s[kt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i & 1][0], qf[ks], z, 0, 0, 0);
+        s[kt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i & 1][1], qf[ks], z, 0, 0, 0);
+      } else {
+        s[kt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i & 1][0], qf[ks], s[kt][0], 0, 0, 0);
+        s[kt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[i & 1][1], qf[ks], s[kt][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // P V of one key tile (the short kernel's pv_tile: asm transposing reads a k16 step ahead of their MFMAs, counted lgkmcnt)
+  auto pv_tile = [&](const LaneCtx& c, const half_t* vbuf, int kt, const unsigned (&pp)[16]) {
+    const unsigned vb0 = (unsigned)(size_t)(const __attribute__((address_space(3))) half_t*)(vbuf + kt * 64 * 64);
+    unsigned va[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) va[i] = vb0 + 2u * (unsigned)(c.vfo0 ^ (16 * i));
+    half4 v[2][4];
+    auto step = [&](auto gc, half4 (&d)[4]) {
+      constexpr int g = decltype(gc)::value, sub = g >> 1, sp = g & 1;
+      const attd_u32x4 pu = {pp[8 * sub + 4 * sp], pp[8 * sub + 4 * sp + 1], pp[8 * sub + 4 * sp + 2], pp[8 * sub + 4 * sp + 3]};
+      const half8 pf = __builtin_bit_cast(half8, pu);
+      if constexpr (g < 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+      __builtin_amdgcn_sched_barrier(0);
+      const half8 vf0 = {d[0][0], d[0][1], d[0][2], d[0][3], d[1][0], d[1][1], d[1][2], d[1][3]};
+      const half8 vf1 = {d[2][0], d[2][1], d[2][2], d[2][3], d[3][0], d[3][1], d[3][2], d[3][3]};
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf0, pf, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf1, pf, o1, 0, 0, 0);
+    };
+    using std::integral_constant;
+    attd_issue_vt<0>(v[0], va);
+    attd_issue_vt<1>(v[1], va);
+    step(integral_constant<int, 0>{}, v[0]);
+    attd_issue_vt<2>(v[0], va);
+    step(integral_constant<int, 1>{}, v[1]);
+    attd_issue_vt<3>(v[1], va);
+    step(integral_constant<int, 2>{}, v[0]);
+    step(integral_constant<int, 3>{}, v[1]);
+  };
+
+  // one chunk of an active wave.  MASK: the chunk holds keys >= L (the last one); NEAR: bias from the chunk's table, else the
+  // constant `far_bias` (every key of the chunk at least max_distance from every query of this wave)
+  auto chunk_body = [&](auto maskc, auto nearc, int ch, int st, float far_bias) {
+    constexpr bool MASK = decltype(maskc)::value, NEAR = decltype(nearc)::value;
+    const half_t* kbuf = sbuf + (2 * st) * ATTL_IMG_HALFS;
+    const half_t* vbuf = sbuf + (2 * st + 1) * ATTL_IMG_HALFS;
+    f32x16 s[2][2];
+    qk_chunk(lane_ctx(opaque_lane()), kbuf, s);
+    __builtin_amdgcn_sched_barrier(0);
+    float tmax = -1e30f;
+    {
+      const LaneCtx c1 = lane_ctx(opaque_lane());
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        const int key_base = ch * ATTL_KEYS + kt * 64 + 4 * c1.hh;
+        if constexpr (NEAR) {
+          int lqi = c1.tab_q + kt * 64;
+          asm volatile("" : "+v"(lqi));
+          const float* lq = sTab + st * ATTL_TAB_N + lqi;
+          auto bias = [&](int r, int sub) { return lq[(r & 3) + 8 * (r >> 2) + 32 * sub]; };
+          attn_tile_bias_max<MASK, decltype(bias), true>(s[kt][0], s[kt][1], tmax, key_base, L, bias);
+        } else {
+          auto bias = [&](int, int) { return far_bias; };
+          attn_tile_bias_max<MASK, decltype(bias), false>(s[kt][0], s[kt][1], tmax, key_base, L, bias);
+        }
+      }
+    }
+    const float m_c = attn_row_max(tmax);
+    const float m_new = attn_max3(m_run, m_c, m_c);
+    float psum = 0.f;
+    unsigned pp[2][16];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      attn_tile_exp(s[kt][0], s[kt][1], m_new, psum);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const half2v a = {(half_t)s[kt][0][2 * i], (half_t)s[kt][0][2 * i + 1]};
+        const half2v b2 = {(half_t)s[kt][1][2 * i], (half_t)s[kt][1][2 * i + 1]};
+        pp[kt][i] = __builtin_bit_cast(unsigned, a);
+        pp[kt][8 + i] = __builtin_bit_cast(unsigned, b2);
+      }
+    }
+    // online merge, once per chunk (m_run starts at -1e30: alpha = 0 and the zero accumulators stay zero on the first chunk)
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    const f32x2 a2 = {alpha, alpha};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 x0 = f32x2{o0[r], o0[r + 1]} * a2, x1 = f32x2{o1[r], o1[r + 1]} * a2;
+      o0[r] = x0[0]; o0[r + 1] = x0[1]; o1[r] = x1[0]; o1[r + 1] = x1[1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const LaneCtx c3 = lane_ctx(opaque_lane());
+    pv_tile(c3, vbuf, 0, pp[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    pv_tile(c3, vbuf, 1, pp[1]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  using T = std::integral_constant<bool, true>; using F = std::integral_constant<bool, false>;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int st = ch & 1;
+    // the next chunk travels while this one is computed: its stage was last read before the barrier that ended chunk ch - 1
+    if (ch + 1 < nch) {
+      issue_chunk(opaque_lane(), ch + 1, st ^ 1);
+      build_table(ch + 1, st ^ 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (active) {
+      const bool mask = (ch + 1) * ATTL_KEYS > L;
+      // this wave's 32 queries against the chunk: range of key - query
+      const int lo = ch * ATTL_KEYS - (q0 + 31), hi = ch * ATTL_KEYS + ATTL_KEYS - 1 - q0;
+      const bool near = hi > -RK_LUT_R && lo < RK_LUT_R;
+      const float far_bias = sLutH[hi <= -RK_LUT_R ? 0 : RK_LUT_N - 1];
+      if (near) { if (mask) chunk_body(T{}, T{}, ch, st, 0.f); else chunk_body(F{}, T{}, ch, st, 0.f); }
+      else { if (mask) chunk_body(T{}, F{}, ch, st, far_bias); else chunk_body(F{}, F{}, ch, st, far_bias); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk ch + 1 has landed (it had this whole chunk to do so)
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the next table is written, every LDS read of this chunk retired
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- context rows: normalise, pack, store (the short kernel's permlane32_swap pairing: two 16-byte stores per 32-column half) ----
+  if (active) {
+    const float l_row = attn_row_sum(l_run);
+    const float inv = 1.0f / l_row;
+    unsigned pk[2][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      half4 a, cc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = f2h_sat(o0[4 * q + j] * inv); cc[j] = f2h_sat(o1[4 * q + j] * inv); }
+      const auto au = __builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, a);
+      const auto cu = __builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, cc);
+      pk[0][2 * q] = au[0]; pk[0][2 * q + 1] = au[1];
+      pk[1][2 * q] = cu[0]; pk[1][2 * q + 1] = cu[1];
+    }
+    const LaneCtx c4 = lane_ctx(opaque_lane());
+    half_t* dst = p.ctx + (size_t)(tok0 + (c4.qpos < L ? c4.qpos : L - 1)) * p.ldctx + h * 64 + 16 * c4.hh;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const auto x0 = __builtin_amdgcn_permlane32_swap(pk[o][0], pk[o][4], false, false);
+      const auto x1 = __builtin_amdgcn_permlane32_swap(pk[o][1], pk[o][5], false, false);
+      const auto y0 = __builtin_amdgcn_permlane32_swap(pk[o][2], pk[o][6], false, false);
+      const auto y1 = __builtin_amdgcn_permlane32_swap(pk[o][3], pk[o][7], false, false);
+      const attd_u32x4 lo = {x0[0], x1[0], x0[1], x1[1]};
+      const attd_u32x4 hi = {y0[0], y1[0], y0[1], y1[1]};
+      if (c4.qpos < L) {
+        *(attd_u32x4*)(dst + 32 * o) = lo;
+        *(attd_u32x4*)(dst + 32 * o + 8) = hi;
+      }
+    }
   }
 }
 

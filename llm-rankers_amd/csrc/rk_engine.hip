@@ -82,7 +82,7 @@ struct Slot {
   int* chain_heads = nullptr; int* chain_cnt = nullptr; unsigned* chain_flag = nullptr; unsigned chain_epoch = 0; int* chain_err = nullptr;
   int chain_heads_cap = 0;
   int* d_tokens = nullptr; int* d_seq_off = nullptr;
-  int n_seq = 0, T = 0, maxL = 0; bool staged = false; int last_n_out = 0;
+  int n_seq = 0, T = 0, maxL = 0, minL = 0; bool staged = false; int last_n_out = 0;
   half_t* cross_kv = nullptr;                                  // [n_dec][max_tokens][2I] encoder -> decoder hand-off
   int *d_dec_ids = nullptr, *d_last_rows = nullptr, *d_out_ids = nullptr, *d_labels = nullptr, *d_argmax = nullptr, *d_row_seq = nullptr, *d_tree_keys = nullptr, *d_tree_pos = nullptr;
   float* dhidden = nullptr; half_t *dxn = nullptr, *dqkv = nullptr, *dctx = nullptr, *dq = nullptr, *dffh = nullptr, *dlast = nullptr;
@@ -115,7 +115,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_gemm_stagger_us = 0, opt_gemm_epi_depth = 0, opt_chain_debug = 0, opt_chain_only = 0, opt_chain_trace_launch = 0;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_attn_long = 1, opt_attn_long_nw = 0, opt_gemm_stagger_us = 0, opt_gemm_epi_depth = 0, opt_chain_debug = 0, opt_chain_only = 0, opt_chain_trace_launch = 0;
   unsigned long long* chain_trace = nullptr;   // measurement builds only (option chain_trace)
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
@@ -649,6 +649,26 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
           hipLaunchKernelGGL(attn_enc_dma_kernel<1>, grid, dim3(384), ATTD_LDS_BYTES, st, a);
         }
       }
+      else if (e->opt_attn_long) {
+        // every sequence longer than ATT_ROW_MAXL keys: the chunked LDS-DMA kernel (round 5); the batch's short sequences (if any):
+        // the tiled kernel, which reproduces the short kernel's bits - a sequence's result depends on ITS length only
+        if (sl.minL <= ATT_ROW_MAXL) {
+          a.skip_long = 1;
+          hipLaunchKernelGGL(attn_enc_kernel<2>, dim3((ATT_ROW_MAXL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
+        }
+        // waves per workgroup (same bits for every choice): option attn_long_nw, or from the batch - enough workgroups for the chip
+        int nw = e->opt_attn_long_nw;
+        // (measured, one to eight 1 560-token prompts: 4 waves = 128 queries per workgroup, two workgroups per CU, wins everywhere -
+        // 36.9 / 49.1 / 157.5 us per layer at 1 / 2 / 8 prompts against 60 / 60 / 180 at twelve waves, 48 / 85 / 212 at six (384-thread
+        // workgroups of this register size run one per CU) and 39.6 / 67.6 / 224.9 for the tiled kernel; profiles/r05_attn_long.jsonl)
+        if (nw != 12 && nw != 6 && nw != 4 && nw != 3) nw = 4;
+        const dim3 grid((sl.maxL + 32 * nw - 1) / (32 * nw), d.n_heads, sl.n_seq);
+        static std::atomic<uint64_t> attr12{0}, attr6{0}, attr4{0}, attr3{0};
+        if (nw == 12) { ensure_dynamic_lds((const void*)attn_enc_long_kernel<12>, ATTL_LDS_BYTES, attr12); hipLaunchKernelGGL(attn_enc_long_kernel<12>, grid, dim3(768), ATTL_LDS_BYTES, st, a); }
+        else if (nw == 6) { ensure_dynamic_lds((const void*)attn_enc_long_kernel<6>, ATTL_LDS_BYTES, attr6); hipLaunchKernelGGL(attn_enc_long_kernel<6>, grid, dim3(384), ATTL_LDS_BYTES, st, a); }
+        else if (nw == 4) { ensure_dynamic_lds((const void*)attn_enc_long_kernel<4>, ATTL_LDS_BYTES, attr4); hipLaunchKernelGGL(attn_enc_long_kernel<4>, grid, dim3(256), ATTL_LDS_BYTES, st, a); }
+        else { ensure_dynamic_lds((const void*)attn_enc_long_kernel<3>, ATTL_LDS_BYTES, attr3); hipLaunchKernelGGL(attn_enc_long_kernel<3>, grid, dim3(192), ATTL_LDS_BYTES, st, a); }
+      }
       else if (e->opt_attn_tiled_occ >= 3)
         hipLaunchKernelGGL(attn_enc_kernel<3>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
       else if (e->opt_attn_tiled_occ == 2 && e->opt_attn_split && sl.maxL > ATT_SPLIT_MIN_L)   // long prompts: two key halves per workgroup
@@ -940,11 +960,12 @@ int check_batch(rk_engine* e, Slot& sl, const int32_t* tokens, const int32_t* of
   if (!tokens || !off || n_seq <= 0) return fail(e, RK_ERR_INVALID, "empty batch (n_seq=%d)", n_seq);
   if (n_seq > e->d.max_seqs) return fail(e, RK_ERR_CAPACITY, "n_seq %d > max_seqs %d", n_seq, e->d.max_seqs);
   if (off[0] != 0) return fail(e, RK_ERR_INVALID, "seq_offsets[0] must be 0");
-  int maxL = 0;
+  int maxL = 0, minL = 1 << 30;
   for (int b = 0; b < n_seq; ++b) {
     const int L = off[b + 1] - off[b];
     if (L <= 0) return fail(e, RK_ERR_INVALID, "sequence %d is empty", b);
     maxL = std::max(maxL, L);
+    minL = std::min(minL, L);
   }
   const int T = off[n_seq];
   if (T > e->d.max_tokens) return fail(e, RK_ERR_CAPACITY, "%d tokens > max_tokens %d", T, e->d.max_tokens);
@@ -952,7 +973,7 @@ int check_batch(rk_engine* e, Slot& sl, const int32_t* tokens, const int32_t* of
     if (tokens[t] < 0 || tokens[t] >= e->d.vocab) return fail(e, RK_ERR_INVALID, "token id %d out of range at %d", tokens[t], t);
   if ((64 + 256 + 8 + (size_t)maxL) * sizeof(float) > 160 * 1024 || maxL > 65536)
     return fail(e, RK_ERR_CAPACITY, "sequence of %d tokens exceeds the cross-attention LDS budget", maxL);
-  sl.maxL = maxL; sl.T = T; sl.n_seq = n_seq;
+  sl.maxL = maxL; sl.minL = minL; sl.T = T; sl.n_seq = n_seq;
   return RK_OK;
 }
 
@@ -2228,6 +2249,8 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
   if (!strcmp(key, "dec_fuse_rows")) { e->opt_dec_fuse_rows = value; return RK_OK; }   // rows per workgroup of dec_cross_qk_kernel (0 = auto; A/B)
   if (!strcmp(key, "dec_fuse")) { e->opt_dec_fuse = value; return RK_OK; }   // few-row decoder: projections around the query-side cross-attention fused per (head, row slab): 1 = at one decoder position (default), 2 = always, 0 = separate GEMMs
+  if (!strcmp(key, "attn_long_nw")) { e->opt_attn_long_nw = value; return RK_OK; }   // waves per workgroup of the long-sequence attention kernel: 12 / 6 / 4 / 3, 0 = from the batch (bit-identical)
+  if (!strcmp(key, "attn_long")) { e->opt_attn_long = value != 0; return RK_OK; }   // encoder attention of sequences longer than 192 keys: the chunked LDS-DMA kernel (1) or the tiled kernel (0)
   if (!strcmp(key, "gemm_stagger_us")) { e->opt_gemm_stagger_us = value; return RK_OK; }   // residual ping-pong GEMMs: half of the workgroups start value x K / 1024 us late (experiment, 0 = off)
   if (!strcmp(key, "gemm_epi_depth")) { e->opt_gemm_epi_depth = value; return RK_OK; }     // residual ping-pong GEMMs: old fp32 rows of three slabs requested ahead (>= 2) or one slab at a time (0)
   if (!strcmp(key, "dec_attn_seq")) { e->opt_dec_attn_seq = value != 0; ++e->opt_epoch; return RK_OK; }   // decoder attention at several positions: one workgroup per (head, sequence) with K / V staged in LDS (1) or one per query row (0); same bits

@@ -1209,3 +1209,43 @@ def test_decoder_attention_per_sequence_kernel_bit_identical_to_per_row_kernel()
         np.testing.assert_array_equal(out[1][1], out[0][1])
     eng.set_option("dec_attn_seq", 1)
     eng.close()
+
+
+def test_long_sequence_attention_kernel_vs_oracle_tiled_kernel_and_batch_independence():
+    """attn_enc_long_kernel (round 5: sequences longer than 192 keys - the setwise prompts - by LDS-DMA in chunks of 128 keys,
+    one online merge per chunk): logits against the fp32 oracle as close as the tiled kernel's, the two kernels within fp16
+    noise of each other; the SAME BITS for every workgroup size (the host's free choice), for a sequence alone / among other
+    long ones / in a batch with short sequences, and the short sequences of such a batch keep the short kernel's bits."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle
+    dims = _synth.FLAN_T5_SMALL
+    state = _synth.synth_state_dict(dims, seed=929, threads=8)
+    eng = _engine(dims, state, max_tokens=16384, max_seqs=32, max_dec_len=4)
+    seqs = _synth.synth_token_batch(3, 200, 900, dims.vocab, seed=41) + _synth.synth_token_batch(1, 385, 385, dims.vocab, seed=42) + \
+        _synth.synth_token_batch(1, 193, 193, dims.vocab, seed=43) + _synth.synth_token_batch(1, 1300, 1300, dims.vocab, seed=45)
+    ids = [5, 6, 7, 8]
+    want = T5Oracle(dims, state).score_last(seqs, [0, 9], ids)
+    eng.set_option("attn_long", 0)
+    tiled = eng.score(seqs, [0, 9], ids)
+    eng.set_option("attn_long", 1)
+    got = {}
+    for nw in (12, 6, 4, 3, 0):
+        eng.set_option("attn_long_nw", nw)
+        got[nw] = eng.score(seqs, [0, 9], ids)
+    for nw in (6, 4, 3, 0):
+        np.testing.assert_array_equal(got[12], got[nw], err_msg=f"{nw} waves per workgroup")
+    scale = np.abs(want).max()
+    assert np.abs(got[0] - want).max() < 2e-3 * max(1.0, scale), (np.abs(got[0] - want).max(), scale)
+    assert np.abs(got[0] - want).max() < 1.5 * np.abs(tiled - want).max() + 1e-4       # no further from fp32 than the tiled kernel
+    assert np.abs(got[0] - tiled).max() < 4e-3 * max(1.0, scale)
+    short = _synth.synth_token_batch(4, 30, 192, dims.vocab, seed=44)
+    mixed = eng.score(short + seqs + short[:2], [0, 9], ids)
+    for i, s_ in enumerate(seqs):
+        np.testing.assert_array_equal(mixed[4 + i], eng.score([s_], [0, 9], ids)[0], err_msg=f"long sequence {i} ({len(s_)} tokens)")
+    np.testing.assert_array_equal(mixed[4:4 + len(seqs)], got[0])
+    eng.set_option("attn_long", 0)
+    short_only = eng.score(short, [0, 9], ids)                      # all-short batch: the DMA kernel
+    np.testing.assert_array_equal(mixed[:4], short_only)
+    np.testing.assert_array_equal(mixed[4 + len(seqs):], short_only[:2])
+    eng.set_option("attn_long", 1)
+    eng.close()

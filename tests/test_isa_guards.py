@@ -190,3 +190,21 @@ def test_no_valu_written_sgpr_feeds_an_inline_asm_memory_instruction_without_wai
                     waits += 1
                 back -= 1
     assert checked > 50        # the ping-pong / chained GEMMs and the DMA attention kernel hold dozens of such instructions each
+
+
+@pytest.mark.parametrize("nw,max_vgprs", [(12, 168), (4, 256)])
+def test_long_sequence_attention_keeps_its_dma_in_flight(isa, nw, max_vgprs):
+    """attn_enc_long_kernel: the next chunk's K / V rows travel by LDS-DMA while the current chunk is computed; the only vmcnt
+    waits inside the chunk loop may be the kernel's own (a compiler-placed one - for a tracked load whose first use slipped
+    into the loop - would drain the DMA queue of every chunk); no spills; three waves per SIMD at twelve waves per workgroup."""
+    body = kernel_body(isa, f"_Z20attn_enc_long_kernelILi{nw}EEv11AttnEncArgs")
+    assert not any("scratch_" in l for l in body), "long-sequence attention kernel spills"
+    m = re.search(r"NumVgprs: (\d+)", "\n".join(isa[isa.index(body[-1]):isa.index(body[-1]) + 400]))
+    assert m and int(m.group(1)) <= max_vgprs, m and m.group(1)
+    assert sum("v_mfma_f32_32x32x16_f16" in l for l in body) == 4 * 32       # four chunk bodies (mask x near / far), 16 + 16 MFMAs each
+    first_mfma = next(i for i, l in enumerate(body) if "v_mfma" in l)
+    last_mfma = max(i for i, l in enumerate(body) if "v_mfma" in l)
+    for i in range(first_mfma, last_mfma):
+        code = body[i].split(";")[0]
+        if "vmcnt" in code:
+            assert "ASMSTART" in body[i - 1], f"compiler-placed vmcnt wait between the chunk bodies: {code.strip()}"

@@ -1,7 +1,8 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-mkdir -p gpurun_out/c14
-for o in "attn_split=1" "attn_split=0" "attn_split=0,attn_tiled_occ=3" "attn_split=1,attn_tiled_occ=1"; do
-for b in 8 1; do
-echo "== B=$b $o"; RK_OPTS=$o RK_L=1560 RK_B=$b timeout 300 python tools/profile_compare.py 2>/dev/null | tail -1 | python -c "
-import sys,json; j=json.loads(sys.stdin.read()); print(j['likelihood_ms'], j['likelihood_classes_ms']['enc_attn'])"
-done; done 2>&1 | tee gpurun_out/c14/attn_split.txt
+mkdir -p gpurun_out/c17
+timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/c17/pytest_gpu.log 2>&1; grep -E "passed|failed|Error|assert " gpurun_out/c17/pytest_gpu.log | head -20
+timeout 900 python tools/bench_setwise_query.py > gpurun_out/c17/setwise.json 2>/dev/null; RK_WORDS=140 RK_QUERY_WORDS=24 RK_MANY=8 timeout 900 python tools/bench_setwise_query.py 2>/dev/null | tail -1 > gpurun_out/c17/setwise_s3.json; python - <<'PY'
+import json
+j=json.loads(open('gpurun_out/c17/setwise_s3.json').read().strip().splitlines()[-1])
+print({k:(v['ms_per_query'], v.get('frac_of_mfma_peak')) for k,v in j.items() if isinstance(v,dict)})
+PY
