@@ -1,1 +1,1 @@
-SKIP_TESTS=1 bash tools/gpu_final.sh
+bash tools/gpu_final.sh
