@@ -23,6 +23,8 @@ struct AttnEncArgs {
   int n_seq;             // DMA kernel only: sequences in the batch
   float* trace;          // DMA kernel, measurement builds only: phase time stamps of one workgroup (ATTD_STAMP), else nullptr
   int skip_long;         // tiled kernel: sequences longer than ATT_ROW_MAXL are left to attn_enc_long_kernel (round 5)
+  int n_heads, nqb;      // attn_enc_long_kernel (1-D grid): heads, query blocks of 32 NW of the longest sequence
+  int xcd_map;           // attn_enc_long_kernel: 1 = the workgroups of a (sequence, head) pair on one XCD, 0 = dealt over all eight
 };
 
 // Flash-style encoder self-attention.  grid = (ceil(maxL/128), H, B), 256 threads = 4 waves x 32 queries.
@@ -915,7 +917,8 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
 // comes from a per-chunk table of key - query (built from the head's table in LDS), and a wave whose 32 queries are at least
 // max_distance away from the whole chunk adds the bucket's constant instead (most chunks of a 1.5k prompt).
 // A sequence's result depends on ITS length only: every sequence longer than ATT_ROW_MAXL takes this kernel, in any batch
-// (attn_enc_kernel then only serves the batch's short sequences: AttnEncArgs::skip_long).  grid = (ceil(maxL / 384), H, n_seq).
+// (attn_enc_kernel then only serves the batch's short sequences: AttnEncArgs::skip_long).  grid = ceil(n_seq H / 8) x 8 x ceil(maxL / (32 NW))
+// workgroups, mapped to (sequence, head, query block) XCD-aware (below).
 #define ATTL_KEYS 128
 // NW waves x 32 queries per workgroup (12 / 6 / 4 / 3): a query row's arithmetic does not depend on NW - the same chunks of 128 keys in
 // the same order, the same table values, the same near / far decision per wave - so the host picks NW from the batch (how many
@@ -930,7 +933,13 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
   half_t* const sbuf = (half_t*)attl_smem;                                      // [stage][K image | V image], [128][64] each
   float* const sTab = (float*)(attl_smem + 4 * ATTL_IMG_HALFS * 2);             // [stage][512]: bias(key - query) * log2(e) of a chunk
   float* const sLutH = sTab + 2 * ATTL_TAB_N;                                   // this head's table * log2(e)
-  const int b = blockIdx.z, h = blockIdx.y, qb = blockIdx.x;
+  // workgroup -> (sequence, head, query block), XCD-aware: consecutive workgroups go to the 8 XCDs in turn, each with its own L2, so
+  // workgroup i takes (sequence, head) pair 8 (i / 8 / nqb) + i % 8: the nqb workgroups that walk one pair's K / V rows (0.4 MB at
+  // 1.5k tokens, read once per query block) meet in ONE L2 instead of every XCD pulling every pair through the fabric
+  const int pair = p.xcd_map ? ((int)blockIdx.x >> 3) / p.nqb * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x / p.nqb;
+  const int qb = p.xcd_map ? ((int)blockIdx.x >> 3) % p.nqb : (int)blockIdx.x % p.nqb;
+  if (pair >= p.n_seq * p.n_heads) return;                                      // uniform for the whole block
+  const int b = pair / p.n_heads, h = pair % p.n_heads;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;
   const int Q0 = qb * ATTL_QUERIES;

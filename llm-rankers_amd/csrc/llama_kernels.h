@@ -42,6 +42,7 @@ struct AttnCausalArgs {
   const int* seq_off;    // [B+1]
   int ld, ldctx, n_heads, n_kv;
   float scale_log2e;     // head_dim**-0.5 * log2(e): the softmax runs in the log2 domain
+  int n_seq, nqb;        // attn_causal128_dma_kernel (1-D grid): sequences, query blocks of 128 of the longest sequence
 };
 
 // Flash-style causal attention, d = 128.  grid = (ceil(maxL / 128), n_heads, B); 256 threads = 4 waves x 32 queries.
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_causal128_kernel(AttnCausalArgs p) {
 // packed-fp32 / v_max3 helpers of attention.h, the two half-rows of a query (lane, lane ^ 32) exchanged by
 // v_permlane32_swap; the 64 accumulator registers are rescaled only when some lane's running maximum moved (alpha == 1 for
 // every lane otherwise: the same bits); context rows leave as 16-byte stores.  64 KiB of LDS, <= 256 VGPRs: two workgroups per
-// CU.  grid = (ceil(maxL / 128), n_heads, B), the query blocks with the most keys first; 256 threads = 4 waves x 32 queries.
+// CU.  grid = ceil(B n_kv / 8) x 8 x (n_heads / n_kv) x ceil(maxL / 128) workgroups (see the mapping below); 256 threads = 4 waves x 32 queries.
 // A row's arithmetic depends on its own sequence only (its position, its keys in chunks of 64 in order): batch-independent.
 #define ATCD_KEYS 64
 #define ATCD_IMG_HALFS (ATCD_KEYS * 64)            // one image: 8 KiB
@@ -201,7 +202,14 @@ __global__ __launch_bounds__(256) void attn_causal128_kernel(AttnCausalArgs p) {
 __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char atcd_smem[];
   half_t* const sbuf = (half_t*)atcd_smem;
-  const int b = blockIdx.z, h = blockIdx.y, qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+  // workgroup -> (sequence, head, query block), XCD-aware: consecutive workgroups go to the 8 XCDs in turn, each with its own
+  // L2, so workgroup i belongs to the (sequence, kv head) group 8 (i / 8 / W) + i % 8 - all W = heads-per-group x query-blocks
+  // workgroups that read one K / V pair (0.8 MB at 1.5k tokens) meet in ONE L2 instead of each XCD pulling every pair through the
+  // fabric - and walks that group's query blocks from the last (most keys) to the first, the heads of a kv head side by side
+  const int hpg = p.n_heads / p.n_kv, W = hpg * p.nqb;
+  const int grp = ((int)blockIdx.x >> 3) / W * 8 + ((int)blockIdx.x & 7), w = ((int)blockIdx.x >> 3) % W;
+  if (grp >= p.n_seq * p.n_kv) return;                       // uniform for the whole block
+  const int b = grp / p.n_kv, kvh = grp % p.n_kv, h = kvh * hpg + w % hpg, qb = p.nqb - 1 - w / hpg;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;
   const int Q0 = qb * 128;
@@ -209,7 +217,6 @@ __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalAr
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int q0 = Q0 + wave * 32;
   const bool active = q0 < L;                                // wave-uniform
-  const int kvh = h / (p.n_heads / p.n_kv);
   const half_t* const kbase = p.qkv + (size_t)(p.n_heads + kvh) * 128;
   const half_t* const vbase = p.qkv + (size_t)(p.n_heads + p.n_kv + kvh) * 128;
   const int last_q = min(Q0 + 127, L - 1);

@@ -115,7 +115,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_attn_long = 1, opt_attn_long_nw = 0, opt_gemm_stagger_us = 0, opt_gemm_epi_depth = 0, opt_chain_debug = 0, opt_chain_only = 0, opt_chain_trace_launch = 0, opt_llama_attn_dma = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_attn_long = 1, opt_attn_long_nw = 0, opt_gemm_stagger_us = 0, opt_gemm_epi_depth = 0, opt_chain_debug = 0, opt_chain_only = 0, opt_chain_trace_launch = 0, opt_llama_attn_dma = 1, opt_attn_long_xcd = 1;
   unsigned long long* chain_trace = nullptr;   // measurement builds only (option chain_trace)
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
@@ -662,7 +662,8 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
         // 36.9 / 49.1 / 157.5 us per layer at 1 / 2 / 8 prompts against 60 / 60 / 180 at twelve waves, 48 / 85 / 212 at six (384-thread
         // workgroups of this register size run one per CU) and 39.6 / 67.6 / 224.9 for the tiled kernel; profiles/r05_attn_long.jsonl)
         if (nw != 12 && nw != 6 && nw != 4 && nw != 3) nw = 4;
-        const dim3 grid((sl.maxL + 32 * nw - 1) / (32 * nw), d.n_heads, sl.n_seq);
+        a.n_seq = sl.n_seq; a.n_heads = d.n_heads; a.nqb = (sl.maxL + 32 * nw - 1) / (32 * nw); a.xcd_map = e->opt_attn_long_xcd;
+        const dim3 grid((unsigned)((sl.n_seq * d.n_heads + 7) / 8 * 8) * a.nqb);
         static std::atomic<uint64_t> attr12{0}, attr6{0}, attr4{0}, attr3{0};
         if (nw == 12) { ensure_dynamic_lds((const void*)attn_enc_long_kernel<12>, ATTL_LDS_BYTES, attr12); hipLaunchKernelGGL(attn_enc_long_kernel<12>, grid, dim3(768), ATTL_LDS_BYTES, st, a); }
         else if (nw == 6) { ensure_dynamic_lds((const void*)attn_enc_long_kernel<6>, ATTL_LDS_BYTES, attr6); hipLaunchKernelGGL(attn_enc_long_kernel<6>, grid, dim3(384), ATTL_LDS_BYTES, st, a); }
@@ -1932,12 +1933,14 @@ static int llama_prefill(rk_engine* e, const int32_t* tokens, const int32_t* off
       hipLaunchKernelGGL(rope128_kernel, dim3(T), dim3(256), 0, st, sl.qkv, e->d_pos, e->rope_cos, e->rope_sin, ldq, l.n_heads + l.n_kv_heads);
     }
     {
-      AttnCausalArgs a{sl.qkv, sl.ctx, sl.d_seq_off, ldq, Q, l.n_heads, l.n_kv_heads, scale_log2e};
+      AttnCausalArgs a{sl.qkv, sl.ctx, sl.d_seq_off, ldq, Q, l.n_heads, l.n_kv_heads, scale_log2e, 0, 0};
       Bracket br(e, st, PC_ENC_ATTN, 2.0 * (double)sl.maxL * T * Q, (double)T * (2 * Q + 2 * KV) * 2.0);   // causal: half of 4 L T Q
       if (e->opt_llama_attn_dma) {     // K / V chunks by LDS-DMA, V^T by transposing reads (round 5); chosen by the option alone: batch-independent
         static std::atomic<uint64_t> attr_done{0};
         ensure_dynamic_lds((const void*)attn_causal128_dma_kernel, ATCD_LDS_BYTES, attr_done);
-        hipLaunchKernelGGL(attn_causal128_dma_kernel, dim3((sl.maxL + 127) / 128, l.n_heads, n_seq), dim3(256), ATCD_LDS_BYTES, st, a);
+        a.n_seq = n_seq; a.nqb = (sl.maxL + 127) / 128;
+        const int groups8 = (n_seq * l.n_kv_heads + 7) / 8 * 8;
+        hipLaunchKernelGGL(attn_causal128_dma_kernel, dim3((unsigned)groups8 * (l.n_heads / l.n_kv_heads) * a.nqb), dim3(256), ATCD_LDS_BYTES, st, a);
       } else {
         hipLaunchKernelGGL(attn_causal128_kernel, dim3((sl.maxL + 127) / 128, l.n_heads, n_seq), dim3(256), 0, st, a);
       }
@@ -2256,6 +2259,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "dec_fuse_rows")) { e->opt_dec_fuse_rows = value; return RK_OK; }   // rows per workgroup of dec_cross_qk_kernel (0 = auto; A/B)
   if (!strcmp(key, "dec_fuse")) { e->opt_dec_fuse = value; return RK_OK; }   // few-row decoder: projections around the query-side cross-attention fused per (head, row slab): 1 = at one decoder position (default), 2 = always, 0 = separate GEMMs
   if (!strcmp(key, "llama_attn_dma")) { e->opt_llama_attn_dma = value != 0; return RK_OK; }   // Llama causal attention: K / V chunks by LDS-DMA with transposing V reads (1) or the register-staged first version (0); differ within fp16 noise
+  if (!strcmp(key, "attn_long_xcd")) { e->opt_attn_long_xcd = value != 0; return RK_OK; }   // long-sequence attention: the workgroups of a (sequence, head) pair on one XCD (1) or dealt over all eight (0); same bits
   if (!strcmp(key, "attn_long_nw")) { e->opt_attn_long_nw = value; return RK_OK; }   // waves per workgroup of the long-sequence attention kernel: 12 / 6 / 4 / 3, 0 = from the batch (bit-identical)
   if (!strcmp(key, "attn_long")) { e->opt_attn_long = value != 0; return RK_OK; }   // encoder attention of sequences longer than 192 keys: the chunked LDS-DMA kernel (1) or the tiled kernel (0)
   if (!strcmp(key, "gemm_stagger_us")) { e->opt_gemm_stagger_us = value; return RK_OK; }   // residual ping-pong GEMMs: half of the workgroups start value x K / 1024 us late (experiment, 0 = off)

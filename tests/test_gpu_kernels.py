@@ -968,6 +968,39 @@ def test_llama_3_8b_widths_one_compare_vs_oracle():
     eng.close()
 
 
+def test_llama_attention_by_lds_dma_vs_oracle_first_kernel_and_batch_independence():
+    """attn_causal128_dma_kernel (round 5: K / V chunks of 64 keys by LDS-DMA, V^T by transposing reads; engine option
+    llama_attn_dma): the last-position logits of MANY PREFIXES of one 700-token sequence - the logits of many positions: every
+    chunk count, the diagonal chunk at both halves, query-block boundaries, a one-token sequence - against the fp32 oracle (as
+    close as the register-staged kernel), the two kernels within fp16 noise of each other, and batch independence: a prefix
+    alone, in the batch and in the reversed batch (other workgroup -> XCD assignment) gives the same bits."""
+    from llmrankers import _synth
+    from llmrankers._engine import RkLlamaEngine
+    from oracle.llama_numpy import LlamaOracle
+    dims = _synth.TOY_LLAMA
+    state = _synth.synth_state_dict(dims, seed=929)
+    base = _synth.synth_token_batch(1, 700, 700, dims.vocab, seed=17)[0]
+    lens = sorted(set([1, 2, 3, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 191, 192, 193, 255, 256, 257, 383, 384,
+                       385, 511, 512, 513, 639, 640, 641, 700] + list(range(7, 700, 37))))
+    seqs = [base[:n] for n in lens]
+    ids = list(range(64))
+    want = LlamaOracle(dims, state).last_logits(seqs)[:, ids]
+    scale = float(np.abs(want).max())
+    eng = RkLlamaEngine(dims, device=0, max_tokens=32768, max_seqs=128).load_state(state.items())
+    eng.set_option("llama_attn_dma", 0)
+    first = eng.last_logits(seqs, ids)
+    eng.set_option("llama_attn_dma", 1)
+    got = eng.last_logits(seqs, ids)
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() < 2e-3 * max(1.0, scale), (np.abs(got - want).max(), scale)
+    assert np.abs(got - want).max() < 1.5 * np.abs(first - want).max() + 1e-4
+    assert np.abs(got - first).max() < 2e-3 * max(1.0, scale)
+    np.testing.assert_array_equal(eng.last_logits(seqs[::-1], ids)[::-1], got)
+    for i in (0, 3, 8, 17, len(seqs) - 1):
+        np.testing.assert_array_equal(eng.last_logits([seqs[i]], ids)[0], got[i], err_msg=f"prefix of {lens[i]} tokens alone")
+    eng.close()
+
+
 def test_llama3_rope_scaling_on_the_engine_vs_hf_golden():
     """rope type "llama3" (Llama-3.1 / 3.2 checkpoints; rk_llama_set_rope_scaling before finalize): last-position logits of
     ragged prompts vs HF LlamaForCausalLM (tests/golden/model_llama3rope.npz) and vs the oracle; the default rope type on
@@ -1234,6 +1267,9 @@ def test_long_sequence_attention_kernel_vs_oracle_tiled_kernel_and_batch_indepen
         got[nw] = eng.score(seqs, [0, 9], ids)
     for nw in (6, 4, 3, 0):
         np.testing.assert_array_equal(got[12], got[nw], err_msg=f"{nw} waves per workgroup")
+    eng.set_option("attn_long_xcd", 0)                              # workgroup -> XCD mapping: the same bits either way
+    np.testing.assert_array_equal(eng.score(seqs, [0, 9], ids), got[0])
+    eng.set_option("attn_long_xcd", 1)
     scale = np.abs(want).max()
     assert np.abs(got[0] - want).max() < 2e-3 * max(1.0, scale), (np.abs(got[0] - want).max(), scale)
     assert np.abs(got[0] - want).max() < 1.5 * np.abs(tiled - want).max() + 1e-4       # no further from fp32 than the tiled kernel

@@ -1,5 +1,5 @@
-mkdir -p gpurun_out/c20
-RK_LAYERS=8 timeout 420 python tools/llama_attn_check.py > gpurun_out/c20/llama_attn.jsonl 2> gpurun_out/c20/err.log
+mkdir -p gpurun_out/c24
+timeout 400 python tools/llama_gemm_variants.py > gpurun_out/c24/variants.jsonl 2> gpurun_out/c24/err.log
 echo "rc=$?"
-cat gpurun_out/c20/llama_attn.jsonl
-tail -5 gpurun_out/c20/err.log
+cat gpurun_out/c24/variants.jsonl
+tail -5 gpurun_out/c24/err.log
