@@ -42,7 +42,8 @@ struct AttnCausalArgs {
   const int* seq_off;    // [B+1]
   int ld, ldctx, n_heads, n_kv;
   float scale_log2e;     // head_dim**-0.5 * log2(e): the softmax runs in the log2 domain
-  int n_seq, nqb;        // attn_causal128_dma_kernel (1-D grid): sequences, query blocks of 128 of the longest sequence
+  int n_seq, nqb;        // attn_causal128_dma_kernel (1-D grid): sequences, query blocks of 32 NW of the longest sequence
+  int ko;                // attn_causal128_dma_kernel, measurement builds only (-DRK_MEASURE): timing knock-outs, see ATCD_KO
 };
 
 // Flash-style causal attention, d = 128.  grid = (ceil(maxL / 128), n_heads, B); 256 threads = 4 waves x 32 queries.
@@ -195,11 +196,24 @@ __global__ __launch_bounds__(256) void attn_causal128_kernel(AttnCausalArgs p) {
 // every lane otherwise: the same bits); context rows leave as 16-byte stores.  64 KiB of LDS, <= 256 VGPRs: two workgroups per
 // CU.  grid = ceil(B n_kv / 8) x 8 x (n_heads / n_kv) x ceil(maxL / 128) workgroups (see the mapping below); 256 threads = 4 waves x 32 queries.
 // A row's arithmetic depends on its own sequence only (its position, its keys in chunks of 64 in order): batch-independent.
+// timing-only knock-outs (measurement builds: hipcc ... -DRK_MEASURE, loaded through RK_ENGINE_LIB; results are garbage):
+// AttnCausalArgs::ko bit 0 no K / V DMA inside the chunk loop, 1 no score MFMAs, 2 no softmax (scale, maximum, exp, merge),
+// 3 no P V, 4 no workgroup barrier per chunk, 5 no context stores, 6 return at once, 7 return after the prologue.  tools/llama_attn_ko.py
+#ifdef RK_MEASURE
+#define ATCD_KO(bit) ((p.ko >> (bit)) & 1)
+#else
+#define ATCD_KO(bit) 0
+#endif
 #define ATCD_KEYS 64
 #define ATCD_IMG_HALFS (ATCD_KEYS * 64)            // one image: 8 KiB
 #define ATCD_STAGE_HALFS (4 * ATCD_IMG_HALFS)      // K columns 0-63 | K columns 64-127 | V columns 0-63 | V columns 64-127
 #define ATCD_LDS_BYTES (2 * ATCD_STAGE_HALFS * 2)
-__global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalArgs p) {
+// NW waves x 32 queries per workgroup (4 or 8): a query row's arithmetic does not depend on NW - the same chunks of 64 keys in the
+// same order, the same per-wave decisions - so the host may pick it freely (8: two waves per SIMD inside ONE workgroup, each
+// K / V chunk fetched once for 256 queries; 4: twice the workgroups, shorter critical path of the last query block)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_causal128_dma_kernel(AttnCausalArgs p) {
+  constexpr int ATCD_QUERIES = 32 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char atcd_smem[];
   half_t* const sbuf = (half_t*)atcd_smem;
   // workgroup -> (sequence, head, query block), XCD-aware: consecutive workgroups go to the 8 XCDs in turn, each with its own
@@ -212,14 +226,15 @@ __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalAr
   const int b = grp / p.n_kv, kvh = grp % p.n_kv, h = kvh * hpg + w % hpg, qb = p.nqb - 1 - w / hpg;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;
-  const int Q0 = qb * 128;
+  const int Q0 = qb * ATCD_QUERIES;
   if (Q0 >= L) return;                                       // uniform for the whole block
+  if (ATCD_KO(6)) return;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int q0 = Q0 + wave * 32;
   const bool active = q0 < L;                                // wave-uniform
   const half_t* const kbase = p.qkv + (size_t)(p.n_heads + kvh) * 128;
   const half_t* const vbase = p.qkv + (size_t)(p.n_heads + p.n_kv + kvh) * 128;
-  const int last_q = min(Q0 + 127, L - 1);
+  const int last_q = min(Q0 + ATCD_QUERIES - 1, L - 1);
   const int nch = (last_q >> 6) + 1;                         // chunks this block of queries can see (causal)
   auto opaque_lane = [&]() {
     int lane;
@@ -235,12 +250,12 @@ __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalAr
     c.vfo0 = (4 * c.hh + (i16 >> 2)) * 64 + (((2 * g1 + ((i16 & 3) >> 1)) ^ ((((i16 >> 3) & 1) << 2) | c.hh)) << 3) + 4 * (i16 & 1);
     return c;
   };
-  // chunk ch -> stage st: 32 pieces of 64 sixteen-byte slots (8 per image), eight per wave; keys beyond the sequence are
+  // chunk ch -> stage st: 32 pieces of 64 sixteen-byte slots (8 per image), 32 / NW per wave; keys beyond the sequence are
   // clamped copies of its last row (never visible to a valid query: causal)
   auto issue_chunk = [&](int lane, int ch, int st) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int img = k >> 1, sub = wave + 4 * (k & 1);
+    for (int k = 0; k < 32 / NW; ++k) {
+      const int pid = wave + NW * k, img = pid >> 3, sub = pid & 7;
       const int slot = sub * 64 + lane, r = slot >> 3, c = slot & 7;
       int key = ch * ATCD_KEYS + r;
       key = key < L ? key : L - 1;
@@ -267,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalAr
   asm volatile("" :: "v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]), "v"(qf[4]), "v"(qf[5]), "v"(qf[6]), "v"(qf[7]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (ATCD_KO(7)) return;
 
   f32x16 o[4];
 #pragma unroll
@@ -338,10 +354,15 @@ __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalAr
     constexpr bool MASK = decltype(maskc)::value;
     const half_t* kst = sbuf + st * ATCD_STAGE_HALFS;
     f32x16 s0, s1;
-    qk_chunk(lane_ctx(opaque_lane()), kst, s0, s1);
+    if (!ATCD_KO(1)) qk_chunk(lane_ctx(opaque_lane()), kst, s0, s1);
+    else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      asm volatile("" : "+v"(s0), "+v"(s1));
+    }
     __builtin_amdgcn_sched_barrier(0);
     float tmax = -1e30f;
-    {
+    if (!ATCD_KO(2)) {
       const LaneCtx c1 = lane_ctx(opaque_lane());
       const int key_base = ch * ATCD_KEYS + 4 * c1.hh;       // register r <-> key key_base + (r & 3) + 8 (r >> 2) (+ 32 for s1)
       const f32x2 sc = {p.scale_log2e, p.scale_log2e};
@@ -365,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalAr
     const float m_c = attn_row_max(tmax);
     const float m_new = attn_max3(m_run, m_c, m_c);
     float psum = 0.f;
-    attn_tile_exp(s0, s1, m_new, psum);
+    if (!ATCD_KO(2)) attn_tile_exp(s0, s1, m_new, psum);
     unsigned pp[16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -379,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalAr
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     l_run = l_run * alpha + psum;
     m_run = m_new;
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
+    if (!ATCD_KO(2) && __builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
       const f32x2 a2 = {alpha, alpha};
 #pragma unroll
       for (int f = 0; f < 4; ++f)
@@ -391,9 +412,9 @@ __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalAr
     }
     __builtin_amdgcn_sched_barrier(0);
     const LaneCtx c3 = lane_ctx(opaque_lane());
-    pv_image(c3, kst + 2 * ATCD_IMG_HALFS, pp, o[0], o[1]);
+    if (!ATCD_KO(3)) pv_image(c3, kst + 2 * ATCD_IMG_HALFS, pp, o[0], o[1]);
     __builtin_amdgcn_sched_barrier(0);
-    pv_image(c3, kst + 3 * ATCD_IMG_HALFS, pp, o[2], o[3]);
+    if (!ATCD_KO(3)) pv_image(c3, kst + 3 * ATCD_IMG_HALFS, pp, o[2], o[3]);
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -401,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalAr
   for (int ch = 0; ch < nch; ++ch) {
     const int st = ch & 1;
     // the next chunk travels while this one is computed: its stage was last read before the barrier that ended chunk ch - 1
-    if (ch + 1 < nch) issue_chunk(opaque_lane(), ch + 1, st ^ 1);
+    if (ch + 1 < nch && !ATCD_KO(0)) issue_chunk(opaque_lane(), ch + 1, st ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     if (active && ch * ATCD_KEYS <= q0 + 31) {               // else: every key of the chunk lies after every query of this wave
       if (ch * ATCD_KEYS + ATCD_KEYS - 1 > q0) chunk_body(T{}, ch, st); else chunk_body(F{}, ch, st);
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalAr
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk ch + 1 has landed (it had this whole chunk to do so)
     __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): every LDS read of this chunk retired
-    __builtin_amdgcn_s_barrier();
+    if (!ATCD_KO(4)) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
   // ---- context rows: normalise, pack, 16-byte stores (v_permlane32_swap pairs the half-waves' quads into whole octets) ----
@@ -435,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void attn_causal128_dma_kernel(AttnCausalAr
       const auto y1 = __builtin_amdgcn_permlane32_swap(pk[3], pk[7], false, false);
       const attd_u32x4 lo = {x0[0], x1[0], x0[1], x1[1]};
       const attd_u32x4 hi = {y0[0], y1[0], y0[1], y1[1]};
-      if (c4.qpos < L) {
+      if (c4.qpos < L && !ATCD_KO(5)) {
         *(attd_u32x4*)(dst + 32 * f) = lo;
         *(attd_u32x4*)(dst + 32 * f + 8) = hi;
       }

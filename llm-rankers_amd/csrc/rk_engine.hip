@@ -115,7 +115,7 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_attn_long = 1, opt_attn_long_nw = 0, opt_gemm_stagger_us = 0, opt_gemm_epi_depth = 0, opt_chain_debug = 0, opt_chain_only = 0, opt_chain_trace_launch = 0, opt_llama_attn_dma = 1, opt_attn_long_xcd = 1;
+  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_attn_long = 1, opt_attn_long_nw = 0, opt_gemm_stagger_us = 0, opt_gemm_epi_depth = 0, opt_chain_debug = 0, opt_chain_only = 0, opt_chain_trace_launch = 0, opt_llama_attn_dma = 1, opt_attn_long_xcd = 1, opt_llama_attn_nw = 0;
   unsigned long long* chain_trace = nullptr;   // measurement builds only (option chain_trace)
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
@@ -1933,14 +1933,22 @@ static int llama_prefill(rk_engine* e, const int32_t* tokens, const int32_t* off
       hipLaunchKernelGGL(rope128_kernel, dim3(T), dim3(256), 0, st, sl.qkv, e->d_pos, e->rope_cos, e->rope_sin, ldq, l.n_heads + l.n_kv_heads);
     }
     {
-      AttnCausalArgs a{sl.qkv, sl.ctx, sl.d_seq_off, ldq, Q, l.n_heads, l.n_kv_heads, scale_log2e, 0, 0};
+      AttnCausalArgs a{sl.qkv, sl.ctx, sl.d_seq_off, ldq, Q, l.n_heads, l.n_kv_heads, scale_log2e, 0, 0, e->opt_attn_ko};
       Bracket br(e, st, PC_ENC_ATTN, 2.0 * (double)sl.maxL * T * Q, (double)T * (2 * Q + 2 * KV) * 2.0);   // causal: half of 4 L T Q
       if (e->opt_llama_attn_dma) {     // K / V chunks by LDS-DMA, V^T by transposing reads (round 5); chosen by the option alone: batch-independent
         static std::atomic<uint64_t> attr_done{0};
-        ensure_dynamic_lds((const void*)attn_causal128_dma_kernel, ATCD_LDS_BYTES, attr_done);
-        a.n_seq = n_seq; a.nqb = (sl.maxL + 127) / 128;
+        static std::atomic<uint64_t> attr_done8{0};
+        int lds = ATCD_LDS_BYTES, lds_max = ATCD_LDS_BYTES;
+#ifdef RK_MEASURE
+        lds_max += 49152;
+        if (e->opt_attn_ko & 256) lds += 49152;          // residency probe: 112 KiB per workgroup = ONE per CU for certain
+#endif
+        const int nw = e->opt_llama_attn_nw == 8 ? 8 : 4;   // same bits either way
+        a.n_seq = n_seq; a.nqb = (sl.maxL + 32 * nw - 1) / (32 * nw);
         const int groups8 = (n_seq * l.n_kv_heads + 7) / 8 * 8;
-        hipLaunchKernelGGL(attn_causal128_dma_kernel, dim3((unsigned)groups8 * (l.n_heads / l.n_kv_heads) * a.nqb), dim3(256), ATCD_LDS_BYTES, st, a);
+        const dim3 grid((unsigned)groups8 * (l.n_heads / l.n_kv_heads) * a.nqb);
+        if (nw == 8) { ensure_dynamic_lds((const void*)attn_causal128_dma_kernel<8>, lds_max, attr_done8); hipLaunchKernelGGL(attn_causal128_dma_kernel<8>, grid, dim3(512), lds, st, a); }
+        else { ensure_dynamic_lds((const void*)attn_causal128_dma_kernel<4>, lds_max, attr_done); hipLaunchKernelGGL(attn_causal128_dma_kernel<4>, grid, dim3(256), lds, st, a); }
       } else {
         hipLaunchKernelGGL(attn_causal128_kernel, dim3((sl.maxL + 127) / 128, l.n_heads, n_seq), dim3(256), 0, st, a);
       }
@@ -2258,6 +2266,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
   if (!strcmp(key, "dec_fuse_rows")) { e->opt_dec_fuse_rows = value; return RK_OK; }   // rows per workgroup of dec_cross_qk_kernel (0 = auto; A/B)
   if (!strcmp(key, "dec_fuse")) { e->opt_dec_fuse = value; return RK_OK; }   // few-row decoder: projections around the query-side cross-attention fused per (head, row slab): 1 = at one decoder position (default), 2 = always, 0 = separate GEMMs
+  if (!strcmp(key, "llama_attn_nw")) { e->opt_llama_attn_nw = value; return RK_OK; }   // waves per workgroup of the Llama LDS-DMA attention kernel: 8, or 4 (0 = default); same bits
   if (!strcmp(key, "llama_attn_dma")) { e->opt_llama_attn_dma = value != 0; return RK_OK; }   // Llama causal attention: K / V chunks by LDS-DMA with transposing V reads (1) or the register-staged first version (0); differ within fp16 noise
   if (!strcmp(key, "attn_long_xcd")) { e->opt_attn_long_xcd = value != 0; return RK_OK; }   // long-sequence attention: the workgroups of a (sequence, head) pair on one XCD (1) or dealt over all eight (0); same bits
   if (!strcmp(key, "attn_long_nw")) { e->opt_attn_long_nw = value; return RK_OK; }   // waves per workgroup of the long-sequence attention kernel: 12 / 6 / 4 / 3, 0 = from the batch (bit-identical)

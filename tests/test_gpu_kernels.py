@@ -996,6 +996,9 @@ def test_llama_attention_by_lds_dma_vs_oracle_first_kernel_and_batch_independenc
     assert np.abs(got - want).max() < 1.5 * np.abs(first - want).max() + 1e-4
     assert np.abs(got - first).max() < 2e-3 * max(1.0, scale)
     np.testing.assert_array_equal(eng.last_logits(seqs[::-1], ids)[::-1], got)
+    eng.set_option("llama_attn_nw", 8)                              # eight waves per workgroup: the same bits
+    np.testing.assert_array_equal(eng.last_logits(seqs, ids), got)
+    eng.set_option("llama_attn_nw", 0)
     for i in (0, 3, 8, 17, len(seqs) - 1):
         np.testing.assert_array_equal(eng.last_logits([seqs[i]], ids)[0], got[i], err_msg=f"prefix of {lens[i]} tokens alone")
     eng.close()

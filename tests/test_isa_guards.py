@@ -210,14 +210,15 @@ def test_long_sequence_attention_keeps_its_dma_in_flight(isa, nw, max_vgprs):
             assert "ASMSTART" in body[i - 1], f"compiler-placed vmcnt wait between the chunk bodies: {code.strip()}"
 
 
-def test_llama_dma_attention_keeps_its_dma_in_flight(isa):
+@pytest.mark.parametrize("nw", [4, 8])
+def test_llama_dma_attention_keeps_its_dma_in_flight(isa, nw):
     """attn_causal128_dma_kernel: the next 64-key chunk (K and V, two 64-column images each) travels by LDS-DMA while the current one
     is computed; no compiler-placed vmcnt wait between the chunk bodies, no spills, two workgroups per CU (<= 256 VGPRs, 64 KiB)."""
-    body = kernel_body(isa, "_Z25attn_causal128_dma_kernel14AttnCausalArgs")
+    body = kernel_body(isa, f"_Z25attn_causal128_dma_kernelILi{nw}EEv14AttnCausalArgs")
     assert not any("scratch_" in l for l in body), "Llama DMA attention kernel spills"
     m = re.search(r"NumVgprs: (\d+)", "\n".join(isa[isa.index(body[-1]):isa.index(body[-1]) + 400]))
     assert m and int(m.group(1)) <= 256, m and m.group(1)
-    assert sum("global_load_lds_dwordx4" in l for l in body) == 2 * 8                # chunk 0 + the loop's next chunk, eight 1-KiB pieces per wave
+    assert sum("global_load_lds_dwordx4" in l for l in body) == 2 * 32 // nw         # chunk 0 + the loop's next chunk, 32 / NW 1-KiB pieces per wave
     assert sum("v_mfma_f32_32x32x16_f16" in l for l in body) == 2 * 32            # two chunk bodies (diagonal / below), 16 + 16 MFMAs each
     assert sum("ds_read_b64_tr_b16" in l for l in body) == 2 * 2 * 16
     first_mfma = next(i for i, l in enumerate(body) if "v_mfma" in l)

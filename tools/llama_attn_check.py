@@ -35,6 +35,9 @@ def main():
                           "worst_prefix_len": int(lens[int(err.argmax())]), "logit_scale": scale, "finite": bool(np.isfinite(res[flag]).all())}), flush=True)
     print(json.dumps({"toy_max_abs_diff_between_kernels": float(np.abs(res[0] - res[1]).max())}), flush=True)
     eng.set_option("llama_attn_dma", 1)
+    eng.set_option("llama_attn_nw", 8)
+    print(json.dumps({"eight_waves_per_workgroup_same_bits": bool(np.array_equal(eng.last_logits(seqs, ids), res[1]))}), flush=True)
+    eng.set_option("llama_attn_nw", 0)
     alone_ok = all(np.array_equal(eng.last_logits([s], ids)[0], res[1][i]) for i, s in enumerate(seqs))
     rev = eng.last_logits(seqs[::-1], ids)[::-1]
     print(json.dumps({"bit_identical_alone_vs_batch": bool(alone_ok), "bit_identical_in_reversed_batch": bool(np.array_equal(rev, res[1]))}), flush=True)
@@ -48,8 +51,8 @@ def main():
     for B in (1, 4):
         seqs = _synth.synth_token_batch(B, L, L, dims.vocab, seed=3)
         toks = {}
-        for flag in (0, 1, 0, 1):
-            eng.set_option("llama_attn_dma", flag)
+        for flag, nw in ((0, 0), (1, 4), (1, 8), (1, 4), (1, 8)):
+            eng.set_option("llama_attn_dma", flag); eng.set_option("llama_attn_nw", nw)
             for _ in range(2):
                 toks[flag] = eng.greedy1(seqs)
             t = time.perf_counter()
@@ -62,8 +65,9 @@ def main():
             eng.profile(False)
             flop = layers * 2.0 * L * L * dims.n_heads * 128 * B
             us = rep["enc_attn"]["ms"] / layers * 1e3
-            print(json.dumps({"B": B, "L": L, "layers": layers, "llama_attn_dma": flag, "ms_per_call": round(ms, 2),
+            print(json.dumps({"B": B, "L": L, "layers": layers, "llama_attn_dma": flag, "nw": nw, "ms_per_call": round(ms, 2),
                               "attn_us_per_layer": round(us, 1), "attn_tflops": round(flop / layers / us / 1e6, 1)}), flush=True)
+        eng.set_option("llama_attn_nw", 0)
         print(json.dumps({"B": B, "same_greedy_tokens": bool(np.array_equal(toks[0], toks[1]))}), flush=True)
     eng.close()
 
