@@ -8,6 +8,7 @@
 #pragma once
 #include "common.h"
 #include <type_traits>
+#include "xcd_map.h"
 
 #ifndef ATTD_Q_EARLY
 #define ATTD_Q_EARLY 1   // the next item's Q loads: 1 = right behind the score tiles (a whole softmax in front of the counted V wait), 0 = behind the V barrier
@@ -936,9 +937,9 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
   // workgroup -> (sequence, head, query block), XCD-aware: consecutive workgroups go to the 8 XCDs in turn, each with its own L2, so
   // workgroup i takes (sequence, head) pair 8 (i / 8 / nqb) + i % 8: the nqb workgroups that walk one pair's K / V rows (0.4 MB at
   // 1.5k tokens, read once per query block) meet in ONE L2 instead of every XCD pulling every pair through the fabric
-  const int pair = p.xcd_map ? ((int)blockIdx.x >> 3) / p.nqb * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x / p.nqb;
-  const int qb = p.xcd_map ? ((int)blockIdx.x >> 3) % p.nqb : (int)blockIdx.x % p.nqb;
-  if (pair >= p.n_seq * p.n_heads) return;                                      // uniform for the whole block
+  int pair, qb;
+  if (p.xcd_map) { if (!xcd_decode((int)blockIdx.x, p.n_seq * p.n_heads, p.nqb, pair, qb)) return; }   // (xcd_map.h; uniform for the whole block)
+  else { pair = (int)blockIdx.x / p.nqb; qb = (int)blockIdx.x % p.nqb; if (pair >= p.n_seq * p.n_heads) return; }
   const int b = pair / p.n_heads, h = pair % p.n_heads;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;

@@ -7,6 +7,7 @@
 // repeat_kv :180-189 (query head h reads kv head h / (n_heads / n_kv_heads)).
 #pragma once
 #include "common.h"
+#include "xcd_map.h"
 
 // In place on the fused QKV buffer [T, ld]: the first n_rot heads of a row (all query heads, then all key heads) are
 // rotated by the row's position.  cos / sin: [max_pos, 64] fp32 (the two halves of HF's table are equal).
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_causal128_dma_kernel(AttnCaus
   // workgroups that read one K / V pair (0.8 MB at 1.5k tokens) meet in ONE L2 instead of each XCD pulling every pair through the
   // fabric - and walks that group's query blocks from the last (most keys) to the first, the heads of a kv head side by side
   const int hpg = p.n_heads / p.n_kv, W = hpg * p.nqb;
-  const int grp = ((int)blockIdx.x >> 3) / W * 8 + ((int)blockIdx.x & 7), w = ((int)blockIdx.x >> 3) % W;
-  if (grp >= p.n_seq * p.n_kv) return;                       // uniform for the whole block
+  int grp, w;
+  if (!xcd_decode((int)blockIdx.x, p.n_seq * p.n_kv, W, grp, w)) return;   // uniform for the whole block (xcd_map.h)
   const int b = grp / p.n_kv, kvh = grp % p.n_kv, h = kvh * hpg + w % hpg, qb = p.nqb - 1 - w / hpg;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;

@@ -663,7 +663,7 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
         // workgroups of this register size run one per CU) and 39.6 / 67.6 / 224.9 for the tiled kernel; profiles/r05_attn_long.jsonl)
         if (nw != 12 && nw != 6 && nw != 4 && nw != 3) nw = 4;
         a.n_seq = sl.n_seq; a.n_heads = d.n_heads; a.nqb = (sl.maxL + 32 * nw - 1) / (32 * nw); a.xcd_map = e->opt_attn_long_xcd;
-        const dim3 grid((unsigned)((sl.n_seq * d.n_heads + 7) / 8 * 8) * a.nqb);
+        const dim3 grid(xcd_grid(sl.n_seq * d.n_heads, a.nqb));
         static std::atomic<uint64_t> attr12{0}, attr6{0}, attr4{0}, attr3{0};
         if (nw == 12) { ensure_dynamic_lds((const void*)attn_enc_long_kernel<12>, ATTL_LDS_BYTES, attr12); hipLaunchKernelGGL(attn_enc_long_kernel<12>, grid, dim3(768), ATTL_LDS_BYTES, st, a); }
         else if (nw == 6) { ensure_dynamic_lds((const void*)attn_enc_long_kernel<6>, ATTL_LDS_BYTES, attr6); hipLaunchKernelGGL(attn_enc_long_kernel<6>, grid, dim3(384), ATTL_LDS_BYTES, st, a); }
@@ -1945,8 +1945,7 @@ static int llama_prefill(rk_engine* e, const int32_t* tokens, const int32_t* off
 #endif
         const int nw = e->opt_llama_attn_nw == 8 ? 8 : 4;   // same bits either way
         a.n_seq = n_seq; a.nqb = (sl.maxL + 32 * nw - 1) / (32 * nw);
-        const int groups8 = (n_seq * l.n_kv_heads + 7) / 8 * 8;
-        const dim3 grid((unsigned)groups8 * (l.n_heads / l.n_kv_heads) * a.nqb);
+        const dim3 grid(xcd_grid(n_seq * l.n_kv_heads, (l.n_heads / l.n_kv_heads) * a.nqb));
         if (nw == 8) { ensure_dynamic_lds((const void*)attn_causal128_dma_kernel<8>, lds_max, attr_done8); hipLaunchKernelGGL(attn_causal128_dma_kernel<8>, grid, dim3(512), lds, st, a); }
         else { ensure_dynamic_lds((const void*)attn_causal128_dma_kernel<4>, lds_max, attr_done); hipLaunchKernelGGL(attn_causal128_dma_kernel<4>, grid, dim3(256), lds, st, a); }
       } else {
