@@ -540,8 +540,9 @@ def test_pointwise_rerank_many_streams_and_equals_one_query_at_a_time():
     assert counters == [o[1] for o in one]
 
 
-@pytest.mark.parametrize("method", ["heapsort", "bubblesort"])
-def test_setwise_lockstep_alternates_two_groups_over_the_slots(method):
+@pytest.mark.parametrize("method,sizes", [("heapsort", (14, 9, 14, 12, 13, 5, 14)), ("bubblesort", (14, 9, 14, 12, 13, 5, 14)),
+                                          ("heapsort", (14, 9, 14, 12, 13, 5, 14, 11, 14, 7, 10, 14, 13, 6, 12, 14))])   # 16 = run.py's default
+def test_setwise_lockstep_alternates_two_groups_over_the_slots(method, sizes):
     """SetwiseLlmRanker.rerank_many, likelihood scoring on a runtime with batch slots: the chains run as two groups that
     alternate over slots 0 and 1 (a launch on one slot happens while the other is still uncollected), rankings and counters
     are those of rerank() one query at a time; a call that does not fit the engine sends the rest down the blocking loop."""
@@ -555,7 +556,7 @@ def test_setwise_lockstep_alternates_two_groups_over_the_slots(method):
         r = random.Random(7)
         return [(" ".join(r.choice(words) for _ in range(4)),
                  [SearchResult(docid=f"q{q}d{i}", score=float(50 - i), text=" ".join(r.choice(words) for _ in range(r.randrange(3, 12))))
-                  for i in range(n)]) for q, n in enumerate((14, 9, 14, 12, 13, 5, 14))]
+                  for i in range(n)]) for q, n in enumerate(sizes)]
 
     def run(max_tokens, alternate=True):
         events = []
