@@ -25,6 +25,7 @@
 #include "decoder_kernels.h"
 #include "gemm.h"
 #include "gemm_chain.h"
+#include "gemm_sk.h"
 #include "llama_kernels.h"
 #include "misc_kernels.h"
 
@@ -119,6 +120,9 @@ struct rk_engine {
   unsigned long long* chain_trace = nullptr;   // measurement builds only (option chain_trace)
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
+  // stream-K GEMM (gemm_sk.h): partial-tile slabs and arrival tickets, one set per stream (launches on different streams overlap)
+  struct SkWs { hipStream_t st = nullptr; float* slabs = nullptr; int* cnt = nullptr; };
+  SkWs sk_ws[2 * RK_SLOTS]; int opt_gemm_sk = 1;
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
@@ -241,14 +245,37 @@ void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
   hipLaunchKernelGGL((gemm_pp2_kernel<EPI, KO, RS, EDEPTH>), dim3(grid), dim3(512), smem, st, a);
 }
 
+// Stream-K launch (gemm_sk.h): one persistent workgroup per CU, equal runs of (tile, K step) units; needs the stream's workspace.
+#define SK_MAX_TILES 65536
+const rk_engine::SkWs* sk_workspace(const rk_engine* e, hipStream_t st) {
+  for (const auto& w : e->sk_ws) if (w.st == st && w.slabs) return &w;
+  return nullptr;
+}
+bool sk_ok(const rk_engine* e, hipStream_t st, const GemmArgs& a) {
+  const long tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+  return a.K >= 64 && a.K % 64 == 0 && tiles <= SK_MAX_TILES && sk_workspace(e, st) != nullptr &&
+         (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldw * 2 < (1ull << 32);   // (32-bit byte offsets of the DMA)
+}
+template <int EPI, int KO = 0>
+void launch_sk(rk_engine* e, hipStream_t st, const GemmArgs& a) {
+  constexpr int smem = SK_LDS_BYTES;
+  static std::atomic<uint64_t> attr_done{0};
+  ensure_dynamic_lds((const void*)gemm_sk_kernel<EPI, KO>, smem, attr_done);
+  const rk_engine::SkWs* w = sk_workspace(e, st);
+  const long units = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.K / 64);
+  const int grid = (int)std::min<long>(e->n_cu, units);           // never more workgroups than units: every run is non-empty
+  SkArgs s{w->slabs, w->cnt};
+  hipLaunchKernelGGL((gemm_sk_kernel<EPI, KO>), dim3(grid), dim3(512), smem, st, a, s);
+}
+
 // Tile-shape choice.  variant: 0 = auto, 1 = 128x128 (v1, two workgroups per CU), 2 = 256x256, 3 = 256x192,
 // 4 = 256x128 (v2 kernels, one workgroup per CU), 5 = 256x256 ping-pong (v3).  auto = cheapest under a measured model:
 // time ~ rounds over the resident slots x the variant's time for one round of K = 1024 (us, MI355X, tools/gemm_bench.py
 // at M = 736 .. 23552, profiles/r01c_gemm_bench.txt, r01e_gemm_pingpong.txt).  All variants sum K in the same order, so
 // the choice never changes a result bit.  GEGLU pairs gate/up inside 64-row wave tiles: no 192-wide tile for it.
-int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_producer = false, double* cost_out = nullptr) {
+int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_producer = false, double* cost_out = nullptr, bool no_sk = false) {
   if (cost_out) *cost_out = 0;
-  if (e->opt_gemm_variant) return (e->opt_gemm_variant == 3 && (EPI_IS_GATED(epi) || fold_producer)) ? 2 : e->opt_gemm_variant;
+  if (e->opt_gemm_variant && !(no_sk && e->opt_gemm_variant == 7)) return (e->opt_gemm_variant == 3 && (EPI_IS_GATED(epi) || fold_producer)) ? 2 : e->opt_gemm_variant;
   struct V { int id, bm, bn, slots; double round_us; };
   static const V vs[5] = {{5, 256, 256, 256, 25.5}, {2, 256, 256, 256, 29.8}, {3, 256, 192, 256, 24.7}, {4, 256, 128, 256, 19.0}, {1, 128, 128, 512, 17.3}};
   // 64x64 tiles (variant 6) win only while the larger tiles leave most of the chip idle (tools/gemm_bench.py, r02: O / FFN-out
@@ -327,6 +354,19 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a_in, int for
     }
   }
 #ifdef RK_MEASURE
+  if constexpr (EPI == EPI_STORE_F16) {                              // stream-K knock-outs (gemm_variant 100 + mask)
+    if (variant > 100 && variant < 116 && sk_ok(e, st, a)) {
+      switch (variant - 100) {
+        case 1: launch_sk<EPI, 1>(e, st, a); return;
+        case 2: launch_sk<EPI, 2>(e, st, a); return;
+        case 3: launch_sk<EPI, 3>(e, st, a); return;
+        case 4: launch_sk<EPI, 4>(e, st, a); return;
+        case 5: launch_sk<EPI, 5>(e, st, a); return;
+        case 6: launch_sk<EPI, 6>(e, st, a); return;
+        default: launch_sk<EPI, 0>(e, st, a); return;
+      }
+    }
+  }
   if constexpr (EPI == EPI_STORE_F16) {                              // timing-only knock-outs (gemm_variant 80 + mask)
     if (variant > 80 && variant <= 96 && a.K >= 128) {
       switch (variant - 80) {
@@ -342,6 +382,10 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a_in, int for
     }
   }
 #endif
+  if (variant == 7) {
+    if (sk_ok(e, st, a)) { launch_sk<EPI>(e, st, a); return; }
+    variant = choose_variant(e, EPI, a.M, a.N, a.K, a.xraw != nullptr, nullptr, /*no_sk=*/true);
+  }
   if (variant == 6) {
     const int tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
     // stages: as many as keep every tile resident at once (4 -> 2 workgroups per CU, 3 -> 3, 2 -> 4)
@@ -1229,9 +1273,17 @@ int rk_engine_create(const rk_model_desc* desc, int device_ordinal, rk_engine** 
   for (int i = 0; ok && i < RK_SLOTS; ++i)
     ok = hipEventCreateWithFlags(&e->slots[i].ev_enc, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&e->slots[i].ev_dec, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < 2 * RK_SLOTS; ++i) {
+    rk_engine::SkWs& w = e->sk_ws[i];
+    w.st = (i & 1) ? e->slots[i >> 1].sd : e->slots[i >> 1].se;
+    ok = hipMalloc((void**)&w.slabs, (size_t)2 * e->n_cu * SK_SLAB_FLOATS * sizeof(float)) == hipSuccess &&
+         hipMalloc((void**)&w.cnt, SK_MAX_TILES * sizeof(int)) == hipSuccess &&
+         hipMemset(w.cnt, 0, SK_MAX_TILES * sizeof(int)) == hipSuccess;
+  }
   if (!ok) {
+    for (auto& w : e->sk_ws) { if (w.slabs) hipFree(w.slabs); if (w.cnt) hipFree(w.cnt); }
     delete e;
-    return fail(nullptr, RK_ERR_HIP, "stream/event creation failed");
+    return fail(nullptr, RK_ERR_HIP, "stream/event/workspace creation failed");
   }
   *out = e;
   return RK_OK;
@@ -1251,6 +1303,7 @@ void rk_engine_destroy(rk_engine* e) {
   if (e->logits) hipFree(e->logits);
   if (e->amax_val) hipFree(e->amax_val);
   if (e->amax_idx) hipFree(e->amax_idx);
+  for (auto& w : e->sk_ws) { if (w.slabs) hipFree(w.slabs); if (w.cnt) hipFree(w.cnt); }
   for (auto& sl : e->slots) {
     if (sl.h_scores) hipHostFree(sl.h_scores);
     if (sl.h_small) hipHostFree(sl.h_small);
@@ -2276,6 +2329,7 @@ int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!strcmp(key, "chain")) { e->opt_chain = value != 0; return RK_OK; }   // encoder: O -> FFN-in and FFN-out -> next QKV as chained launches (gemm_chain.h) when the batch is large enough (1) or always separate launches (0); same bits
   if (!strcmp(key, "chain_lead")) { if (value < 1 || value > 16) return fail(e, RK_ERR_INVALID, "chain_lead 1..16"); e->opt_chain_lead = value; return RK_OK; }   // producer lead of a chained launch in blocks of four row panels
   if (!strcmp(key, "chain_min_panels")) { if (value < 1) return fail(e, RK_ERR_INVALID, "chain_min_panels >= 1"); e->opt_chain_min_panels = value; return RK_OK; }   // fewest 256-row panels (M / 256) for the chained form
+  if (!strcmp(key, "gemm_sk")) { if (value < 0 || value > 1) return fail(e, RK_ERR_INVALID, "gemm_sk 0..1"); e->opt_gemm_sk = value; return RK_OK; }   // small-M projections on the stream-K kernel (1) or the tile variants only (0)
   if (!strcmp(key, "gemm_split")) { e->opt_gemm_split = value; return RK_OK; }   // rows beyond the ping-pong kernel's last whole round on a fill-in tile variant (1) or one launch (0)
   if (!strcmp(key, "gemm_group_n")) { e->opt_gemm_group_n = value; return RK_OK; }   // ping-pong GEMM: column-panel width of the tile order in tiles (0 = default 8)
   if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
@@ -2315,7 +2369,11 @@ int rk_debug_gemm_bench(rk_engine* e, int M, int N, int K, int epi, int iters, f
   int rc = set_device(e);
   if (rc) return rc;
   if (K % 64 || N % 4) return fail(e, RK_ERR_INVALID, "gemm bench needs K%%64==0 and N%%4==0");
-  const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N;
+  // (RK_BENCH_PAD: extra halfs per operand row - a leading dimension that is not a power of two; measurement of the L2 channel spread)
+  const char* pad_env = getenv("RK_BENCH_PAD");
+  const int pad = pad_env ? atoi(pad_env) : 0;
+  const int ldk = K + pad;
+  const size_t na = (size_t)M * ldk, nw = (size_t)N * ldk, nc = (size_t)M * N;
   half_t *dA = nullptr, *dW = nullptr; void* dC = nullptr;
   HIPCHK(e, hipMalloc((void**)&dA, na * 2)); HIPCHK(e, hipMalloc((void**)&dW, nw * 2));
   HIPCHK(e, hipMalloc(&dC, nc * 4));
@@ -2328,9 +2386,9 @@ int rk_debug_gemm_bench(rk_engine* e, int M, int N, int K, int epi, int iters, f
     HIPCHK(e, hipMemset(dC, 0, nc * 4));
   }
   const int ldc = EPI_IS_GATED(epi) ? N / 2 : N;
-  for (int i = 0; i < 2; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, K, dW, K, dC, ldc, M, N, K);
+  for (int i = 0; i < 2; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, ldk, dW, ldk, dC, ldc, M, N, K);
   HIPCHK(e, hipEventRecord(e->t0, e->slots[0].se));
-  for (int i = 0; i < iters; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, K, dW, K, dC, ldc, M, N, K);
+  for (int i = 0; i < iters; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, ldk, dW, ldk, dC, ldc, M, N, K);
   HIPCHK(e, hipEventRecord(e->t1, e->slots[0].se));
   HIPCHK(e, hipEventSynchronize(e->t1));
   float ms = 0;

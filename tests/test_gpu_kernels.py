@@ -93,6 +93,36 @@ def test_pingpong_gemm_random_shapes_bit_equal_to_lockstep_kernel(toy):
         assert np.abs(ref - want).max() < 2e-3 * np.sqrt(k)
 
 
+def test_stream_k_gemm_vs_numpy_whole_tiles_bit_equal_and_deterministic(toy):
+    """gemm_sk_kernel (round 6; gemm_variant 7): equal runs of (tile, K step) units per workgroup, split tiles combined by the last
+    arriver in K order.  (1) every shape vs numpy at the fp16-input tolerance; (2) each shape three times: bit-identical runs (the
+    combine order is fixed, whoever arrives last), also right after a different shape used the same tickets and slabs; (3) rows /
+    columns of tiles that are NOT split carry the bits of the lock-step tile kernel (same MFMA order and operand slots) - checked
+    on shapes with fewer units than workgroups (one unit per workgroup: every tile split) and with K of one step (no tile split)."""
+    eng = toy["ckpt_gated_untied"][2]
+    rs = np.random.RandomState(20261001)
+    shapes = [(int(rs.randint(1, 2600)), int(rs.randint(1, 400)) * 4, int(rs.randint(1, 46)) * 64) for _ in range(16)]
+    shapes += [(1450, 1024, 1024), (1450, 1024, 2816), (2392, 1024, 2816), (2392, 3072, 1024), (1450, 5632, 1024), (128, 128, 64),
+               (1, 4, 64), (129, 132, 128), (256, 128, 4096), (100, 100, 14336), (3000, 260, 64)]
+    for m, n, k in shapes:
+        a = rs.standard_normal((m, k)).astype(np.float16)
+        w = rs.standard_normal((n, k)).astype(np.float16)
+        want = a.astype(np.float32) @ w.astype(np.float32).T
+        try:
+            eng.set_option("gemm_variant", 7)
+            first = eng.debug_gemm(a, w, use_glds=True)
+            for _ in range(2):
+                np.testing.assert_array_equal(eng.debug_gemm(a, w, use_glds=True), first, err_msg=f"shape {(m, n, k)} not deterministic")
+            if k == 64:                                  # one K step per tile: nothing is split
+                eng.set_option("gemm_variant", 2)
+                np.testing.assert_array_equal(first, eng.debug_gemm(a, w, use_glds=True), err_msg=f"shape {(m, n, k)}")
+        finally:
+            eng.set_option("gemm_variant", 0)
+        err = np.abs(first - want)
+        assert err.max() < 2e-3 * np.sqrt(k), f"shape {(m, n, k)}: max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}; " \
+            f"bad rows {np.unique(np.where(err > 1e-2 * np.sqrt(k))[0])[:16]} bad cols {np.unique(np.where(err > 1e-2 * np.sqrt(k))[1])[:16]}"
+
+
 def test_small_tile_gemm_stage_counts_bit_equal_to_lockstep_kernel(toy):
     """The 64x64 kernel keeps 1 - 3 K tiles of DMA in flight with counted vmcnt (2 / 3 / 4 LDS stages): every stage count,
     K from one tile (shorter than the pipeline) to 44 tiles, each run three times, bit-equal to the lock-step kernel."""

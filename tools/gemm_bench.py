@@ -31,6 +31,9 @@ def main():
     only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
     dims = _synth.TOY_GATED_UNTIED
     eng = RkEngine(dims, 0, max_tokens=256, max_seqs=4, max_dec_len=4).load_state(_synth.synth_state_dict(dims, 1).items())
+    for kv in os.environ.get("RK_OPTS", "").split(","):       # engine options for the whole run, e.g. RK_OPTS=gemm_glds=0
+        if kv:
+            eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     out = {}
     variants = [int(v) for v in os.environ.get("RK_GEMM_VARIANTS", "0,1,2,3,4,5,6").split(",")]
     for name, m, n, k, epi in SHAPES:

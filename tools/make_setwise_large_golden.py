@@ -13,6 +13,10 @@ recipe is stored.  The sort driver's parity with the REFERENCE is pinned separat
 this fixture pins the engine's arithmetic at the real problem size.
 
 usage: python tools/make_setwise_large_golden.py [doc_seed ...]   (tries seeds until min margin > FLOOR)
+       python tools/make_setwise_large_golden.py --generation-only [doc_seed ...]
+           keeps the committed likelihood run and searches a corpus of its own for the `generation` run (its margins are top-2
+           gaps over the FULL vocabulary at both greedy steps, so a corpus that is decisive for likelihood need not be for
+           generation); the run then carries its own doc_seed / query / docs.
 """
 import contextlib
 import io
@@ -88,7 +92,8 @@ def main():
     label_ids = [tok.encode(f"<pad> Passage {c}", add_special_tokens=False)[-1] for c in SetwiseLlmRanker.CHARACTERS]
     state = boosted_state(dims, label_ids)
     rt = MarginRuntime(dims, state)
-    seeds = [int(a) for a in sys.argv[1:]] or [2, 3, 4, 5]
+    gen_only = "--generation-only" in sys.argv[1:]
+    seeds = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [2, 3, 4, 5]
 
     def corpus(seed):
         rs = np.random.RandomState(seed)
@@ -123,6 +128,28 @@ def main():
                 "caller_list_after": [r.docid for r in ranking], "min_margin": mm,
                 "counters": [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens]}
 
+    if gen_only:
+        path = os.path.join(GOLD, "setwise_large.json")
+        with open(path) as f:
+            out = json.load(f)
+        best = None
+        for seed in seeds:
+            r = run(seed, "generation")
+            if best is None or r["min_margin"] > best[1]["min_margin"]:
+                best = (seed, r)
+            if r["min_margin"] > FLOOR:
+                break
+        seed, gen = best
+        if gen["min_margin"] <= out["runs"]["generation"]["min_margin"]:
+            print("no better corpus found; fixture unchanged")
+            return
+        query, docs = corpus(seed)
+        gen.update({"doc_seed": seed, "query": query, "docs": docs})
+        out["runs"]["generation"] = gen
+        with open(path, "w") as f:
+            json.dump(out, f)
+        print("written tests/golden/setwise_large.json (generation corpus seed %d, min margin %.3f)" % (seed, gen["min_margin"]))
+        return
     best = None
     for seed in seeds:                                   # likelihood first: keep the corpus with the largest minimum margin
         r = run(seed, "likelihood")

@@ -10,7 +10,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, int MFMA>   // MODE 0: LDS-DMA, 1: register loads
+template <int MODE, int MFMA>   // MODE 0: LDS-DMA, 1: register loads, 2: LDS-DMA with GEMM-tile addressing (8 rows x 128 B at a 2 KiB stride, XOR-swizzled chunks)
 __global__ __launch_bounds__(512) void pull(const char* src, int iters, float* sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -36,7 +36,14 @@ __global__ __launch_bounds__(512) void pull(const char* src, int iters, float* s
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const unsigned off = (unsigned)(((it * 8 + u) * nload + wave) & 63) * 1024u + lane * 16u;   // walks the 64-KiB region
-      if (MODE == 0) {
+      if (MODE == 2) {
+        // one instruction = tile rows 8j .. 8j+7 of a [512 rows][1024 halfs] operand slice (row stride 2 KiB), k-step from the round
+        const int j = ((it * 8 + u) * nload + wave) & 63, ktile = (it >> 3) & 15;
+        const int row = j * 8 + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const unsigned o2 = (unsigned)row * 2048u + (unsigned)ktile * 128u + (unsigned)chunk * 16u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)(blockIdx.x & 31) * (512 * 2048) + o2),
+                                         (__attribute__((address_space(3))) void*)(lds + (wave * 8 + u) * 1024), 16, 0, 0);
+      } else if (MODE == 0) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
                                          (__attribute__((address_space(3))) void*)(lds + (wave * 8 + u) * 1024), 16, 0, 0);
       } else {
@@ -49,7 +56,7 @@ __global__ __launch_bounds__(512) void pull(const char* src, int iters, float* s
       for (int u = 0; u < 8; ++u) { asm volatile("" : "+v"(r[u])); keep ^= r[u][0]; }
     }
   }
-  if (MODE == 0) keep = ((unsigned*)lds)[threadIdx.x];
+  if (MODE != 1) keep = ((unsigned*)lds)[threadIdx.x];
   if (keep == 0x12345678u) sink[1] = 1.f;
   if (lane == 0) sink[16 + blockIdx.x * 8 + wave] = (float)(wall_clock64() - t_begin) * 0.01f;
 }
@@ -81,9 +88,11 @@ void run(const char* name, const char* src, float* sink, int grid) {
 
 int main() {
   char* src; float* sink;
-  hipMalloc(&src, 256 * 65536); hipMemset(src, 1, 256 * 65536); hipMalloc(&sink, (16 + 256 * 8) * 4);
+  hipMalloc(&src, 64 << 20); hipMemset(src, 1, 64 << 20); hipMalloc(&sink, (16 + 256 * 8) * 4);
   for (int grid : {256, 128, 64}) {
     run<0, 0>("LDS-DMA, 8 loader waves", src, sink, grid);
+    run<2, 0>("tile-addressed DMA, 8 waves", src, sink, grid);
+    run<2, 1>("tile-addressed DMA 4 + MFMA 4", src, sink, grid);
     run<1, 0>("register loads, 8 waves", src, sink, grid);
     run<0, 1>("LDS-DMA 4 waves + MFMA 4", src, sink, grid);
     run<1, 1>("register loads 4 + MFMA 4", src, sink, grid);
