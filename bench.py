@@ -45,14 +45,9 @@ sys.path.insert(0, REPO)
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md chip table
 YES_ID, NO_ID = 2163, 465     # flan-t5 "Yes"/"No" ids quoted from memory; any two rows cost the same
-GEMM_CLASSES = ["enc_gemm_qkv", "enc_gemm_o", "enc_gemm_ffn_in", "enc_gemm_ffn_out", "gemm_cross_kv",
-                "enc_chain_o_ffn_in", "enc_chain_ffn_out_qkv"]     # the last two: chained launches (csrc/gemm_chain.h), two GEMMs each
+GEMM_CLASSES = ["enc_gemm_qkv", "enc_gemm_o", "enc_gemm_ffn_in", "enc_gemm_ffn_out", "gemm_cross_kv"]
 KERNEL_OF_CLASS = {
     "enc_gemm_ffn_in": "gemm_pp2_kernel (256x256x64 ping-pong fp16 MFMA GEMM, fused GEGLU epilogue), M={M} N={N2F} K={D}",
-    "enc_chain_o_ffn_in": "gemm_chain_kernel<GEGLU> (ONE persistent launch: attention output projection + fp32 residual [M={M} N={D} K={I}] chained by "
-                          "row-panel flags into FFN-in + GEGLU [M={M} N={N2F} K={D}]; 256x256x64 ping-pong fp16 MFMA tiles)",
-    "enc_chain_ffn_out_qkv": "gemm_chain_kernel<STORE> (ONE persistent launch: FFN-out + fp32 residual [M={M} N={D} K={F}] chained by row-panel flags "
-                             "into the next layer's QKV projection [M={M} N={N3I} K={D}]; 256x256x64 ping-pong fp16 MFMA tiles)",
 }
 
 
@@ -309,11 +304,22 @@ def profile_pass(eng, pipe, G, M_tokens):
     # when that summary was taken at this run's GEMM M (= tokens per launch sequence); otherwise null.
     traffic, traffic_src = None, "no PMC summary for M=%d tokens per launch" % M_tokens
     pm = {}
+    # The committed summaries are quoted only when they were taken from THESE kernel sources (tools/gpu_prof.sh stamps them with
+    # __graft_entry__._source_hash(), the hash the in-tree library is built from): after a kernel change without a new profiling
+    # lease the rocprofv3-derived fields are null instead of stale (round-5 advisor finding).
+    try:
+        import __graft_entry__ as _ge
+        src_hash = _ge._source_hash()
+    except Exception:
+        src_hash = None
     try:
         with open(os.path.join(REPO, "profiles", "pmc_summary_latest.json")) as f:
             pm = json.load(f)
+        if pm.get("source_hash") != src_hash or src_hash is None:
+            traffic_src = "profiles/pmc_summary_latest.json was taken from other kernel sources (source_hash differs): not quoted"
+            pm = {}
         if pm.get("tokens_per_launch") == M_tokens:
-            want = "gemm_chain" if dom.startswith("enc_chain") else "gemm_pp2"
+            want = "gemm_pp2"
             gk = [(v["stats"]["pct"], k, v) for k, v in pm["kernels"].items()
                   if want in k and v.get("stats") and "FETCH_SIZE" in v["pmc"] and "WRITE_SIZE" in v["pmc"]]
             if gk:
@@ -329,7 +335,7 @@ def profile_pass(eng, pipe, G, M_tokens):
     frac_rocprof = None
     try:
         import csv
-        want = "gemm_chain_kernel" if dom.startswith("enc_chain") else {"enc_gemm_ffn_in": "gemm_pp2_kernel<2, 0, true", "enc_gemm_qkv": "gemm_pp2_kernel<0, 0, true"}.get(dom, "gemm_pp2_kernel<1, 0, false")
+        want = {"enc_gemm_ffn_in": "gemm_pp2_kernel<2, 0, true", "enc_gemm_qkv": "gemm_pp2_kernel<0, 0, true"}.get(dom, "gemm_pp2_kernel<1, 0, false")
         with open(os.path.join(REPO, "profiles", "bench_kernel_stats_latest.csv")) as f:
             rows = [r for r in csv.DictReader(f) if want in r["Name"]]
         if rows and pm.get("tokens_per_launch") == M_tokens:
@@ -337,8 +343,8 @@ def profile_pass(eng, pipe, G, M_tokens):
             avg_us = float(r["AverageNs"]) / 1e3
             fl = d["flops"] / max(d["launches"], 1)
             frac_rocprof = {"frac": round(fl / (avg_us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS, 4), "avg_launch_us": round(avg_us, 1), "calls": int(r["Calls"]),
-                            "kernel": r["Name"], "source": "profiles/bench_kernel_stats_latest.csv: rocprofv3 --kernel-trace --stats of this command at the same M, "
-                                                           "taken in the builder's evidence lease beside profiles/r05_bench_driver.json (not on the box of a driver-run line)"}
+                            "kernel": r["Name"], "source": "profiles/bench_kernel_stats_latest.csv: rocprofv3 --kernel-trace --stats of this command at the same M and from the same "
+                                                           "kernel sources (source_hash " + str(src_hash)[:12] + "), taken in the builder's evidence lease (not on the box of a driver-run line)"}
     except Exception:
         pass
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

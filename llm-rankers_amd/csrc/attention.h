@@ -174,30 +174,24 @@ __device__ __forceinline__ void attn_tile_softmax(f32x16& s0, f32x16& s1, f32x16
 // walks the key tiles of such a sequence twice - maximum first, then probabilities - and reproduces the same operations.
 #define ATT_ROW_MAXL 192
 
-// MINW: minimum waves per SIMD the register allocation must allow (1: up to 512 registers, one workgroup per CU;
-// 2: 256 registers, two workgroups per CU overlap each other's load / softmax / MFMA phases)
-// KS = 2 (launched when the batch holds a sequence longer than ATT_SPLIT_MIN_L): 8 waves; waves 4-7 take the same 128 queries
-// over the SECOND half of the key tiles of such a sequence, with their own LDS stages, and the two running softmax states
-// are merged through LDS at the end - a single long prompt (one setwise compare) is 12 x 16 workgroups walking 23 key tiles
-// each, and only the length of that walk matters.  Whether a sequence is split depends on ITS length alone, so its result
-// does not depend on the batch it is scored in; sequences up to ATT_SPLIT_MIN_L are computed exactly as by KS = 1.
-#define ATT_SPLIT_MIN_L 512
+// Compiled for two workgroups per CU (256-register budget): they overlap each other's load / softmax / MFMA phases.  (Rounds 2-4
+// also shipped a key-split form for single long prompts and 1- / 3-per-CU builds; attn_enc_long_kernel superseded them in round
+// 5 and they were removed in round 6 - git history and profiles/r05_attn_split_B1_B8.txt keep the measurements.)
 #define ATT_GROUP_BYTES (2 * 64 * ATT_KSTR * 2 + 2 * 64 * ATT_VSTR * 2)
-template <int MINW, int KS = 1>
-__global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char sGroup[KS][ATT_GROUP_BYTES];
+__global__ __launch_bounds__(256, 2) void attn_enc_kernel(AttnEncArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char sGroup[1][ATT_GROUP_BYTES];
   __shared__ float sLut[RK_LUT_N + 3];
   const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
   const int tok0 = p.seq_off[b];
   const int L = p.seq_off[b + 1] - tok0;
   if (qt * 128 >= L) return;   // uniform for the whole block
   if (p.skip_long && L > ATT_ROW_MAXL) return;
-  const int grp = KS == 2 ? (int)(threadIdx.x >> 8) : 0;
-  const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;      // within the group
+  constexpr int grp = 0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;      // within the group
   half_t (*sK)[64 * ATT_KSTR] = (half_t (*)[64 * ATT_KSTR])sGroup[grp];
   half_t (*sVt)[64 * ATT_VSTR] = (half_t (*)[64 * ATT_VSTR])(sGroup[grp] + 2 * 64 * ATT_KSTR * 2);
   const int hh = lane >> 5, l31 = lane & 31;
-  for (int i = threadIdx.x; i < RK_LUT_N; i += 256 * KS) sLut[i] = p.bias_lut[h * RK_LUT_N + i] * ATT_LOG2E;
+  for (int i = threadIdx.x; i < RK_LUT_N; i += 256) sLut[i] = p.bias_lut[h * RK_LUT_N + i] * ATT_LOG2E;
   const int q0 = qt * 128 + wave * 32;
   const bool wave_active = q0 < L;
   const int qpos = q0 + l31;
@@ -213,9 +207,7 @@ __global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p)
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
   const int nkt = (L + 63) >> 6;
-  const bool split = KS == 2 && L > ATT_SPLIT_MIN_L;
-  const int n_iter = split ? (nkt + 1) >> 1 : nkt;                 // group 0's tile count (>= group 1's)
-  const int kt_begin = grp ? n_iter : 0, kt_end = grp ? (split ? nkt : n_iter) : n_iter;   // group 1 of an unsplit sequence: empty
+  const int n_iter = nkt, kt_begin = 0, kt_end = nkt;
   // staging roles: K: thread takes rows (tid>>3) and 32+(tid>>3), chunk tid&7; V: key pair tid>>3, chunk tid&7
   const int srow = tid >> 3, scc = tid & 7;
   half8 rk0, rk1, rv0, rv1;
@@ -240,7 +232,7 @@ __global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p)
   // Whole-row softmax (ATT_ROW_MAXL above) for a short sequence that shares its batch with a longer one: the key tiles are
   // walked TWICE - first pass: scores, bias and the row maximum only; second pass: the same scores again (same MFMA inputs,
   // same bits), probabilities against that maximum, P V without rescaling - which reproduces the DMA kernel's operations
-  // and their order exactly.  (Never split: ATT_ROW_MAXL < ATT_SPLIT_MIN_L, so group 1 idles through the same barriers.)
+  // and their order exactly.
   const bool row_form = L <= ATT_ROW_MAXL;
   const int n_total = row_form ? 2 * nkt : n_iter;
   auto tile_of = [&](int it) { return row_form ? (it >= nkt ? it - nkt : it) : kt_begin + it; };
@@ -332,29 +324,6 @@ __global__ __launch_bounds__(256 * KS, MINW) void attn_enc_kernel(AttnEncArgs p)
     __syncthreads();
   }
   if (row_form) l_run = attn_row_sum(row_psum);
-  if (KS == 2) {
-    // merge the two halves of a split sequence: group 1 hands (m, l, O) of its keys to the wave of group 0 that holds
-    // the same queries - through its own, now idle, LDS stages ([value][lane]: conflict-free)
-    float* sx = (float*)sGroup[1];
-    if (split && grp == 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sx[r * 256 + tid] = o0[r]; sx[(16 + r) * 256 + tid] = o1[r]; }
-      sx[32 * 256 + tid] = m_run; sx[33 * 256 + tid] = l_run;
-    }
-    __syncthreads();
-    if (grp == 1) return;
-    if (split && wave_active) {
-      const float m1 = sx[32 * 256 + tid], l1 = sx[33 * 256 + tid];
-      const float m = fmaxf(m_run, m1);
-      const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
-      l_run = l_run * a0 + l1 * a1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        o0[r] = o0[r] * a0 + sx[r * 256 + tid] * a1;
-        o1[r] = o1[r] * a0 + sx[(16 + r) * 256 + tid] * a1;
-      }
-    }
-  }
   // all waves are past the last barrier: reuse sK[0] to turn per-lane 8-byte pieces into whole context rows
   if (wave_active) {
     const float inv = 1.0f / l_run;

@@ -52,7 +52,10 @@ struct GemmArgs {
   const int* lse_labels; int lse_npos; float* lse_xlab;
   // ping-pong kernel: width (in tiles) of the column panels of the grouped tile order (gemm_tile_coords); host default GEMM_GROUP_N
   int group_n;
-  int stagger_ticks;   // ping-pong kernel, fp32 residual epilogue: start delay of half of the workgroups (100 MHz ticks), 0 = none
+  // ping-pong kernel, K split over workgroups (SPLIT instantiations; gemm_pp2_kernel): ksplit >= 2 workgroups share an output tile,
+  // each sums a contiguous K range; fp32 partial tiles in ks_slabs [ksplit * tiles][256 * 256], arrival tickets ks_cnt [tiles]
+  // (zero between launches: the last arriver of a tile resets its ticket)
+  int ksplit; float* ks_slabs; int* ks_cnt;
 };
 
 #define GEMM_BM 128
@@ -276,9 +279,7 @@ __device__ __forceinline__ void gemm_epilogue_lse(const GemmArgs& p, f32x16 (&ac
 #ifndef GEMM_EPI_NT
 #define GEMM_EPI_NT 7
 #endif
-// PUBLISH (gemm_chain.h): the fp16 copy of the stream and the block sums are read by OTHER workgroups of the same launch -
-// they leave as write-through stores (agent-scope relaxed atomic stores = `global_store ... sc1`), see the hand-off there.
-template <int EPI, int NI, int MI, bool RESID_IN_ACC = false, int ROWS = 32, int DEPTH = 0, bool PUBLISH = false>
+template <int EPI, int NI, int MI, bool RESID_IN_ACC = false, int ROWS = 32, int DEPTH = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase,
                                                      int lane, unsigned char* stage, const float (&rsc)[MI]) {
   if constexpr (EPI == EPI_LSE_F32) {
@@ -399,29 +400,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             ss = row16_sum_f(ss);                                // the 16 lanes of one row
             if (ok) {
               half4 xr = {f2h_sat(v[0] * p.xs), f2h_sat(v[1] * p.xs), f2h_sat(v[2] * p.xs), f2h_sat(v[3] * p.xs)};
-              if constexpr (PUBLISH) {
-                if (ch == 0) __hip_atomic_store(p.ssq + (size_t)m * p.nb + (ncol0 >> 6), ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              } else {
               if constexpr ((GEMM_EPI_NT & 8) != 0) __builtin_nontemporal_store(xr, (half4*)(p.xraw + (size_t)m * p.ldx + n));
               else *(half4*)(p.xraw + (size_t)m * p.ldx + n) = xr;
               if (ch == 0) p.ssq[(size_t)m * p.nb + (ncol0 >> 6)] = ss;
-              }
-            }
-            if constexpr (PUBLISH) {
-              // write-through (sc1) stores of 8 bytes are one fabric write each (34 us per tile epilogue against 18 contended: the
-              // first form of the chained launch, profiles/r05*_chain_trace*); as 16-byte stores they cost what plain ones do.  The two
-              // lanes that hold neighbouring 4-column pieces of a row pair up: the even one stores both (quad-perm swap, no LDS)
-              half4 xr = {f2h_sat(v[0] * p.xs), f2h_sat(v[1] * p.xs), f2h_sat(v[2] * p.xs), f2h_sat(v[3] * p.xs)};
-              typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-              const u32x2 mine = __builtin_bit_cast(u32x2, xr);
-              const unsigned o0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[0], 0xB1, 0xF, 0xF, true);
-              const unsigned o1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[1], 0xB1, 0xF, 0xF, true);
-              if (ok && (ch & 1) == 0) {
-                const u32x4 both = {mine[0], mine[1], o0, o1};
-                const half_t* dst_x = p.xraw + (size_t)m * p.ldx + n;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst_x), "v"(both) : "memory");
-              }
             }
           }
         }
@@ -963,6 +944,9 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 #ifndef GEMM_W_AUX
 #define GEMM_W_AUX 0
 #endif
+#ifndef GEMM_KSPLIT_SKEW
+#define GEMM_KSPLIT_SKEW 4      // K tiles split 0 of a two-way split takes more than split 1 (gemm_pp2_kernel<.., SPLIT>)
+#endif
 #ifndef GEMM_PP2_ISSUE_Q
 #define GEMM_PP2_ISSUE_Q 1      // the DMA instruction of a k16 step goes out after its MFMA number ISSUE_Q (0..3)
 #endif
@@ -995,12 +979,16 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 #define GEMM_PP2_RISSUE 0
 #endif
 // RS: consumer side of the folded RMSNorm - the accumulators of row m are multiplied by p.rowscale[m] (gemm_epilogue_staged)
-// EDEPTH / p.stagger_ticks (round 5 experiment, fp32 residual epilogue): the lock-step launch runs its read-modify-write epilogues
-// at the chip's memory rate (8.9 TB/s over 256 CUs); alone, a CU's epilogue is bound by the bytes IT keeps in flight (one slab per
-// wave: 26 KB/us, the chained launch's timeline).  Half of the workgroups ((blockIdx.x >> 3) & 1: half of every XCD) may start
-// p.stagger_ticks of the 100 MHz wall clock late, so that one half's epilogues fall into the other half's main loops, with the old
-// rows of EDEPTH slabs requested ahead.
-template <int EPI, int KO = 0, bool RS = false, int EDEPTH = 0>
+// SPLIT (round 6; p.ksplit = 1 or 2): K split over TWO workgroups for the launches that have far fewer tiles than the chip has CUs and a long K (Llama-3-8B
+// O / down projections of ONE setwise prompt: 96 tiles, K = 4 096 / 14 336; flan-t5-xl FFN-out at a few thousand rows).  The tile
+// walk runs over 2 * tiles virtual tiles (split s of tile t = virtual tile s * tiles + t, K tiles [kt0, kt0 + nk); split 0 takes a
+// few K tiles more).  The first arriver of a tile leaves its fp32 partial tile in a slab as WRITE-THROUGH 16-byte stores, every
+// storing wave drains, one lane takes the tile's arrival ticket (guide G16 R1); the LAST arriver - it looks at the ticket first
+// and, if the other is already there, publishes nothing - adds the other slab to its registers (a + b == b + a: the same bits
+// whoever arrives last) and runs the epilogue.  Nobody spins.  (Three / four ways measured slower: every slab re-read.)  A split
+// sums K in another association than one workgroup would: results differ from the unsplit launch in the last fp32 bits; whether a
+// launch is split follows from (M, N, K) alone (host: choose_ksplit), so a call shape always gives the same bits.
+template <int EPI, int KO = 0, bool RS = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   constexpr int HALF = 128 * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
@@ -1010,14 +998,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   const int l31 = lane & 31, hh = lane >> 5;
   const int grp = wave >> 2, wm = wave & 1, wn = (wave >> 1) & 3;
   const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
-  const int ntiles = tiles_m * tiles_n;
-  int m0 = 0, n0 = 0;
+  const int nsplit = SPLIT ? p.ksplit : 1;
+  const int ntiles_out = tiles_m * tiles_n, ntiles = ntiles_out * nsplit;   // output tiles | (virtual) tiles of the walk
+  int m0 = 0, n0 = 0, kt0 = 0, nk = p.K >> 6;                                // current tile: origin, first K tile, K tiles
   unsigned off[4][2];   // kind 0 = A0, 1 = A1, 2 = W0, 3 = W1; byte offsets of this wave's two DMA instructions
   // PERSISTENT: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8 or the whole grid, so
   // the tile -> XCD association of gemm_tile_coords holds) and issues the NEXT tile's first six half-tiles before it
   // runs the epilogue of the current one: pipeline fill and workgroup launch no longer sit between two tiles.
   auto set_tile = [&](int tile) {
     int tm, tn;
+    if constexpr (SPLIT) {
+      const int sp = tile / ntiles_out, nk_all = p.K >> 6, base_n = nk_all / nsplit, rem = nk_all - base_n * nsplit;
+      tile -= sp * ntiles_out;
+      kt0 = sp * base_n + (sp < rem ? sp : rem);
+      nk = base_n + (sp < rem ? 1 : 0);
+      // two splits: split 0 takes GEMM_KSPLIT_SKEW more K tiles than split 1, so that split 1 publishes its slab while split 0
+      // still computes and split 0 - arriving last - finds the ticket taken and need not publish at all (below)
+      if (base_n > 4 * GEMM_KSPLIT_SKEW) { if (sp == 0) nk += GEMM_KSPLIT_SKEW; else { kt0 += GEMM_KSPLIT_SKEW; nk -= GEMM_KSPLIT_SKEW; } }
+    }
     gemm_tile_coords(tile, tiles_m, tiles_n, tm, tn, p.group_n);
     m0 = tm * 256; n0 = tn * 256;
 #pragma unroll
@@ -1036,16 +1034,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
     }
   };
   // buffer of (kind, stage) at (kind * 2 + stage) * 16 KiB
-  const int nk = p.K >> 6;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)gemm_smem);
   auto issue1 = [&](auto kindc, int stage, int tile, auto jc) {
     constexpr int kind = decltype(kindc)::value, j = decltype(jc)::value;
-    const char* base = (const char*)((kind < 2 ? p.A : p.W) + tile * 64);
+    const char* base = (const char*)((kind < 2 ? p.A : p.W) + (kt0 + tile) * 64);
 #if GEMM_PP2_ASMDMA
     const unsigned dst = lds0 + (unsigned)(((kind * 2 + stage) * HALF + (wave * 2 + j) * 512) * 2);
     const unsigned o = off[kind][j];                      // (asm operands cannot name a captured array element)
     // (M0 is written here: it is on the clobber list so that the compiler never keeps a value of its own in it across the statement)
+    // (the clobber draws the note "reserved register M0 on the clobber list" per instantiation: silenced for THIS statement only - the
+    // rest of the build keeps its inline-asm diagnostics; tests/test_isa_guards.py is the check that no compiler-owned M0 value lives
+    // across the statement)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(o), "s"(base) : "memory", "m0");
+#pragma clang diagnostic pop
 #else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off[kind][j]),
                                      (__attribute__((address_space(3))) void*)(smem + (kind * 2 + stage) * HALF + (wave * 2 + j) * 512),
@@ -1166,12 +1169,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   using W4 = integral_constant<int, 4>; using W2 = integral_constant<int, 2>; using W0c = integral_constant<int, 0>;
   using WN = integral_constant<int, -1>;
   int tile = blockIdx.x;
-  if constexpr (EPI == EPI_RESID_F32) {
-    if (p.stagger_ticks > 0 && ((blockIdx.x >> 3) & 1)) {
-      const long long t0 = wall_clock64();
-      while (wall_clock64() - t0 < (long long)p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
-    }
-  }
   set_tile(tile);
   issue_prologue();
   while (true) {
@@ -1236,11 +1233,72 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) rsc[i] *= p.scale;
   }
+  const int cur_tile = tile;
   if (next < ntiles) { set_tile(next); issue_prologue(); }
+  bool finish = true;
+  if constexpr (SPLIT) {
+    if (nsplit > 1) {
+      // publish this workgroup's partial tile (layout [wave][fragment][quarter][lane] x 16 B: every store instruction is 1 KiB
+      // of consecutive bytes), take the ticket; the last arriver combines
+      const int spl = cur_tile / ntiles_out, t_out = cur_tile - spl * ntiles_out;
+      float* mine = p.ks_slabs + (size_t)cur_tile * 65536;
+      int* flag = (int*)(gemm_smem + 163840 - 16);
+      // the other split already there?  Then this workgroup is the last arriver whatever happens and its partial stays in registers
+      if (tid == 0) *flag = __hip_atomic_load(p.ks_cnt + t_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
+      __syncthreads();
+      const bool skip_publish = *flag != 0;
+      __syncthreads();                                      // (the flag word is written again below)
+      if (!skip_publish) {
+        // saddr form (uniform slab base + ONE 32-bit lane offset per fragment + immediate offsets): 64-bit store addresses per
+        // (fragment, quarter) would be hoisted out of the tile walk and spilled - the kernel has no registers to spare
+        unsigned voff = (unsigned)(wave * 32768 + lane * 16);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          const f32x16& a = acc[f >> 2][f & 3];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 x = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+            asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3 sc1\n\ts_nop 1" :: "v"(voff), "v"(x), "s"(mine), "n"(q * 1024) : "memory");
+          }
+          voff += 4096;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains (and the next tile's first loads land)
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(p.ks_cnt + t_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == 1;
+        if (last) {
+          __hip_atomic_store(p.ks_cnt + t_out, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody touches this ticket again
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        *flag = last;
+      }
+      __syncthreads();
+      finish = *flag != 0;
+      if (finish) {
+        // own registers + the other split's slab (a + b == b + a: the same bits whichever of the two arrives last); one fragment
+        // at a time - 16 registers of loads in flight, not 128
+        const float* src = p.ks_slabs + (size_t)((1 - spl) * ntiles_out + t_out) * 65536 + (size_t)(wave * 32 * 64 + lane) * 4;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          f32x4 x[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x[q] = *(const f32x4*)(src + (size_t)((f * 4 + q) * 64) * 4);
+          f32x16& a = acc[f >> 2][f & 3];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[4 * q + j] += x[q][j];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
   // fp32 outputs: 16 rows per pass (16 x 272 B per wave); fp16 outputs fit whole 32-row slabs (32 x 144 B)
   constexpr bool F32OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32;
   constexpr int EROWS = F32OUT ? 16 : 32;
-  gemm_epilogue_staged<EPI, 2, 4, false, EROWS, EDEPTH>(p, acc, mbase, nbase, lane, gemm_smem + 114688 + wave * 4608, rsc);
+  if (finish) gemm_epilogue_staged<EPI, 2, 4, false, EROWS>(p, acc, mbase, nbase, lane, gemm_smem + 114688 + wave * 4608, rsc);
   if (next >= ntiles) break;
   tile = next;
   __syncthreads();   // staging rows are read before the next tile's DMA wraps around to W1 | stage 1

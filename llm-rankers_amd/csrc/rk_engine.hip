@@ -24,8 +24,6 @@
 #include "attention.h"
 #include "decoder_kernels.h"
 #include "gemm.h"
-#include "gemm_chain.h"
-#include "gemm_sk.h"
 #include "llama_kernels.h"
 #include "misc_kernels.h"
 
@@ -36,12 +34,10 @@ thread_local std::string g_create_error;
 enum ProfClass {
   PC_ENC_GEMM_QKV = 0, PC_ENC_GEMM_O, PC_ENC_GEMM_FFN_IN, PC_ENC_GEMM_FFN_OUT, PC_ENC_ATTN, PC_GEMM_CROSS_KV,
   PC_NORM, PC_EMBED, PC_DEC_GEMM, PC_DEC_ATTN, PC_HEAD, PC_OTHER,
-  PC_ENC_CHAIN_O_FFN, PC_ENC_CHAIN_FFO_QKV,      // chained launches (gemm_chain.h): O -> FFN-in, FFN-out -> next layer's QKV
   PC_COUNT
 };
 const char* kProfNames[PC_COUNT] = {"enc_gemm_qkv", "enc_gemm_o", "enc_gemm_ffn_in", "enc_gemm_ffn_out", "enc_attn",
-                                    "gemm_cross_kv", "norm", "embed", "dec_gemm", "dec_attn", "head", "other",
-                                    "enc_chain_o_ffn_in", "enc_chain_ffn_out_qkv"};
+                                    "gemm_cross_kv", "norm", "embed", "dec_gemm", "dec_attn", "head", "other"};
 
 struct HostTensor {
   std::vector<half_t> h;   // 2-D matrices (fp16, the reference's accelerator dtype)
@@ -78,10 +74,6 @@ struct Slot {
   hipStream_t se = nullptr, sd = nullptr;   // this slot's encoder chain (MFMA-bound) | decoder chain (latency-bound)
   float* hidden = nullptr; half_t *xn = nullptr, *qkv = nullptr, *ctx = nullptr, *ffh = nullptr, *enc_out = nullptr;
   half_t* xraw = nullptr; float *ssq = nullptr, *rowscale = nullptr;   // folded RMSNorm: fp16 stream x RK_XRAW_SCALE, block sums of squares, row factors
-  // chained GEMM launches (gemm_chain.h): queue heads of every launch of an encoder pass (zeroed once per pass), arrival tickets
-  // and ready flags per row panel (epoch-tagged: never zeroed), the host-visible error word of a timed-out hand-off
-  int* chain_heads = nullptr; int* chain_cnt = nullptr; unsigned* chain_flag = nullptr; unsigned chain_epoch = 0; int* chain_err = nullptr;
-  int chain_heads_cap = 0;
   int* d_tokens = nullptr; int* d_seq_off = nullptr;
   int n_seq = 0, T = 0, maxL = 0, minL = 0; bool staged = false; int last_n_out = 0;
   half_t* cross_kv = nullptr;                                  // [n_dec][max_tokens][2I] encoder -> decoder hand-off
@@ -116,13 +108,21 @@ struct rk_engine {
   size_t scores_cap = 0;
   Slot slots[RK_SLOTS];
   // options / measurement
-  int opt_glds = 1, opt_skinny = 0x3F, opt_overlap = 1, opt_gemm_variant = 0, opt_attn_short = 5, opt_xattn_direct = 1, opt_attn_heads_per_wg = 0, opt_attn_ko = 0, opt_gemm_persistent = 1, opt_fold_norm = 1, opt_attn_tiled_occ = 2, opt_s64_stages = 0, opt_dec_fold_norm = 1, opt_greedy_spec = 160, opt_attn_split = 1, opt_consumer_stats = 1, opt_xattn_mfma = 1, opt_dec_ffn_tiled = 1, opt_gemm_group_n = 0, opt_gemm_split = 1, opt_dec_fuse = 1, opt_dec_fuse_rows = 0, opt_chain = 0, opt_chain_lead = 3, opt_chain_min_panels = 64, opt_dec_attn_seq = 1, opt_attn_long = 1, opt_attn_long_nw = 0, opt_gemm_stagger_us = 0, opt_gemm_epi_depth = 0, opt_chain_debug = 0, opt_chain_only = 0, opt_chain_trace_launch = 0, opt_llama_attn_dma = 1, opt_attn_long_xcd = 1, opt_llama_attn_nw = 0;
-  unsigned long long* chain_trace = nullptr;   // measurement builds only (option chain_trace)
+  // Engine options (rk_engine_set_option; table kOptions below: key, range, meaning).  Every option selects between TESTED
+  // implementations of the same arithmetic - the on-device cross-check of a default path (tests/test_gpu_kernels.py compares them
+  // bit for bit or within the stated tolerance) - or is a measurement knob of tools/; none is an unfinished experiment.
+  struct Options {
+    int glds = 1, skinny = 0x3F, overlap = 1, gemm_variant = 0, attn_short = 5, xattn_direct = 1, attn_heads_per_wg = 0, attn_ko = 0,
+        gemm_persistent = 1, fold_norm = 1, s64_stages = 0, dec_fold_norm = 1, greedy_spec = 160, consumer_stats = 1, xattn_mfma = 1,
+        dec_ffn_tiled = 1, gemm_split = 1, dec_fuse = 1, dec_fuse_rows = 0, dec_attn_seq = 1, attn_long = 1, attn_long_nw = 0,
+        llama_attn_dma = 1, attn_long_xcd = 1, llama_attn_nw = 0, dec_graph = 1, gemm_sk = 1;
+  } opt;
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
-  // stream-K GEMM (gemm_sk.h): partial-tile slabs and arrival tickets, one set per stream (launches on different streams overlap)
+  // K-split ping-pong GEMM (gemm.h: SPLIT): partial-tile slabs and arrival tickets, one set per stream (launches on different
+  // streams overlap)
   struct SkWs { hipStream_t st = nullptr; float* slabs = nullptr; int* cnt = nullptr; };
-  SkWs sk_ws[2 * RK_SLOTS]; int opt_gemm_sk = 1;
+  SkWs sk_ws[2 * RK_SLOTS];
   hipEvent_t t0 = nullptr, t1 = nullptr, t_tmp = nullptr;
   bool prof_on = false;
   std::vector<ProfRec> prof_recs; size_t prof_used = 0;
@@ -134,7 +134,7 @@ struct rk_engine {
   std::vector<LlamaLayerW> ll; float *l_final_ln = nullptr, *rope_cos = nullptr, *rope_sin = nullptr; int* d_pos = nullptr;
   // decoder chains as HIP graphs: key = everything the launch parameters of a chain depend on
   struct GraphEntry { int seen = 0; bool failed = false; hipGraphExec_t exec = nullptr; };
-  std::map<std::vector<int>, GraphEntry> graphs; int opt_dec_graph = 1, opt_epoch = 0;
+  std::map<std::vector<int>, GraphEntry> graphs; int opt_epoch = 0;
   // score collection across GPUs (K9): one RCCL communicator per engine = per process = per GPU
   ncclComm_t comm = nullptr; int comm_rank = 0, comm_world = 1;
   float* d_gather[RK_SLOTS] = {nullptr}; float* h_gather[RK_SLOTS] = {nullptr}; size_t gather_cap = 0;
@@ -200,8 +200,8 @@ struct Bracket {
 // overlap = 0 puts every launch of every slot on ONE stream (serial timeline, used for per-kernel event timing)
 // encoders alternate between TWO streams however many slots there are (more concurrent GEMM chains only thrash);
 // the extra slots exist to lengthen the distance between a decoder and the next encoder that reuses its buffers
-hipStream_t enc_stream(rk_engine* e, Slot& sl) { return e->opt_overlap ? e->slots[(&sl - e->slots) & 1].se : e->slots[0].se; }
-hipStream_t dec_stream(rk_engine* e, Slot& sl) { return e->opt_overlap ? sl.sd : e->slots[0].se; }
+hipStream_t enc_stream(rk_engine* e, Slot& sl) { return e->opt.overlap ? e->slots[(&sl - e->slots) & 1].se : e->slots[0].se; }
+hipStream_t dec_stream(rk_engine* e, Slot& sl) { return e->opt.overlap ? sl.sd : e->slots[0].se; }
 
 // ---- kernel launch helpers ------------------------------------------------------------------------------
 // More than 64 KiB of dynamic LDS needs hipFuncSetAttribute, which applies per DEVICE: done once per (kernel, device),
@@ -227,12 +227,14 @@ void launch_v2(hipStream_t st, const GemmArgs& a) {
   hipLaunchKernelGGL((gemm_v2_kernel<EPI, WM, WN, MI, NI>), dim3(tiles), dim3(WM * WN * 64), smem, st, a);
 }
 
-template <int EPI, int KO = 0, bool RS = false, int EDEPTH = 0>
+#define KSPLIT_MAX_SLABS 256      // partial tiles (256 x 256 fp32 = 256 KiB each) per stream: 64 MiB
+
+template <int EPI, int KO = 0, bool RS = false, bool SPLIT = false>
 void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
   constexpr int smem = 2 * 4 * 128 * 64 * 2 + 32768;   // 8 half-tile buffers + 32 KiB epilogue staging = all 160 KiB
   static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void*)gemm_pp2_kernel<EPI, KO, RS, EDEPTH>, smem, attr_done);
-  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+  ensure_dynamic_lds((const void*)gemm_pp2_kernel<EPI, KO, RS, SPLIT>, smem, attr_done);
+  const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256) * (SPLIT ? a.ksplit : 1);
   // persistent: one workgroup per CU walks the tiles (max_wgs = CUs rounded down to a multiple of 8 keeps the tile -> XCD
   // association); max_wgs <= 0: one workgroup per tile
   // (measured, r03: trimming the grid to the fewest workgroups with the same number of rounds - 232 instead of 256 for the
@@ -242,30 +244,7 @@ void launch_pp2(hipStream_t st, const GemmArgs& a, int max_wgs) {
   // MFMA phases at no cost to the critical path: o 0.496 -> 0.484 ms per step in the serial profile, 7302-7340 against
   // 7338-7376 passages/s in the pipeline - the epilogue's cost is not a shared-HBM burst that de-phasing would spread)
   const int grid = max_wgs > 0 && tiles > max_wgs ? max_wgs : tiles;
-  hipLaunchKernelGGL((gemm_pp2_kernel<EPI, KO, RS, EDEPTH>), dim3(grid), dim3(512), smem, st, a);
-}
-
-// Stream-K launch (gemm_sk.h): one persistent workgroup per CU, equal runs of (tile, K step) units; needs the stream's workspace.
-#define SK_MAX_TILES 65536
-const rk_engine::SkWs* sk_workspace(const rk_engine* e, hipStream_t st) {
-  for (const auto& w : e->sk_ws) if (w.st == st && w.slabs) return &w;
-  return nullptr;
-}
-bool sk_ok(const rk_engine* e, hipStream_t st, const GemmArgs& a) {
-  const long tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-  return a.K >= 64 && a.K % 64 == 0 && tiles <= SK_MAX_TILES && sk_workspace(e, st) != nullptr &&
-         (size_t)a.M * a.lda * 2 < (1ull << 32) && (size_t)a.N * a.ldw * 2 < (1ull << 32);   // (32-bit byte offsets of the DMA)
-}
-template <int EPI, int KO = 0>
-void launch_sk(rk_engine* e, hipStream_t st, const GemmArgs& a) {
-  constexpr int smem = SK_LDS_BYTES;
-  static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void*)gemm_sk_kernel<EPI, KO>, smem, attr_done);
-  const rk_engine::SkWs* w = sk_workspace(e, st);
-  const long units = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.K / 64);
-  const int grid = (int)std::min<long>(e->n_cu, units);           // never more workgroups than units: every run is non-empty
-  SkArgs s{w->slabs, w->cnt};
-  hipLaunchKernelGGL((gemm_sk_kernel<EPI, KO>), dim3(grid), dim3(512), smem, st, a, s);
+  hipLaunchKernelGGL((gemm_pp2_kernel<EPI, KO, RS, SPLIT>), dim3(grid), dim3(512), smem, st, a);
 }
 
 // Tile-shape choice.  variant: 0 = auto, 1 = 128x128 (v1, two workgroups per CU), 2 = 256x256, 3 = 256x192,
@@ -273,9 +252,28 @@ void launch_sk(rk_engine* e, hipStream_t st, const GemmArgs& a) {
 // time ~ rounds over the resident slots x the variant's time for one round of K = 1024 (us, MI355X, tools/gemm_bench.py
 // at M = 736 .. 23552, profiles/r01c_gemm_bench.txt, r01e_gemm_pingpong.txt).  All variants sum K in the same order, so
 // the choice never changes a result bit.  GEGLU pairs gate/up inside 64-row wave tiles: no 192-wide tile for it.
-int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_producer = false, double* cost_out = nullptr, bool no_sk = false) {
+// K split of the ping-pong kernel (gemm.h: SPLIT): only the fp32 residual projections (O / FFN-out, Llama o / down), only TWO ways,
+// only when the launch has at most half as many 256 x 256 tiles as the chip has CUs and K >= 6 144 (96 K tiles).  Measured
+// (profiles/r06_gemm_ksplit.txt, M = 1 536, N = 4 096): K = 14 336 281.6 -> 212.0 us, K = 8 192 155.9 -> 123.6 us, K = 4 096
+// 76.9 -> 75.1 us (not worth a different rounding); three / four ways lose (every slab is published and re-read).  A function of
+// (M, N, K) alone.  flan-t5-large / -xl never qualify (K <= 5 120).
+const rk_engine::SkWs* ksplit_workspace(const rk_engine* e, hipStream_t st) {
+  for (const auto& w : e->sk_ws) if (w.st == st && w.slabs) return &w;
+  return nullptr;
+}
+int choose_ksplit(const rk_engine* e, int epi, int M, int N, int K) {
+  if (!e->opt.gemm_sk || !(epi == EPI_RESID_F32 || epi == EPI_STORE_F32) || K % 64) return 1;
+  const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+  const int wgs = e->n_cu & ~7, nk = K / 64;
+  if (e->opt.gemm_sk == 2)                                             // tests / measurement: two ways wherever they fit
+    return (nk >= 4 && tiles * 2 <= KSPLIT_MAX_SLABS) ? 2 : 1;
+  if (epi != EPI_RESID_F32 || tiles < 1 || tiles * 2 > wgs || nk < 96) return 1;
+  return 2;
+}
+
+int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_producer = false, double* cost_out = nullptr) {
   if (cost_out) *cost_out = 0;
-  if (e->opt_gemm_variant && !(no_sk && e->opt_gemm_variant == 7)) return (e->opt_gemm_variant == 3 && (EPI_IS_GATED(epi) || fold_producer)) ? 2 : e->opt_gemm_variant;
+  if (e->opt.gemm_variant) return (e->opt.gemm_variant == 3 && (EPI_IS_GATED(epi) || fold_producer)) ? 2 : e->opt.gemm_variant;
   struct V { int id, bm, bn, slots; double round_us; };
   static const V vs[5] = {{5, 256, 256, 256, 25.5}, {2, 256, 256, 256, 29.8}, {3, 256, 192, 256, 24.7}, {4, 256, 128, 256, 19.0}, {1, 128, 128, 512, 17.3}};
   // 64x64 tiles (variant 6) win only while the larger tiles leave most of the chip idle (tools/gemm_bench.py, r02: O / FFN-out
@@ -287,7 +285,8 @@ int choose_variant(const rk_engine* e, int epi, int M, int N, int K, bool fold_p
     if (v.id == 3 && (EPI_IS_GATED(epi) || fold_producer)) continue;   // (the folded-norm producer needs 64-column wave tiles)
     if (v.id == 5 && K < 128) continue;
     const long tiles = (long)((M + v.bm - 1) / v.bm) * ((N + v.bn - 1) / v.bn);
-    const double cost = (double)((tiles + v.slots - 1) / v.slots) * v.round_us;
+    double cost = (double)((tiles + v.slots - 1) / v.slots) * v.round_us;
+    if (v.id == 5 && e->opt.gemm_sk == 1 && choose_ksplit(e, epi, M, N, K) > 1) cost = 0.0;   // the K-split launch wins wherever it is eligible (measured)
     if (cost < best - 1e-9) { best = cost; bv = v.id; }
   }
   if (cost_out) *cost_out = best;
@@ -304,7 +303,7 @@ struct GemmPlan { int m_pp2; int variant; };
 GemmPlan choose_plan(const rk_engine* e, int epi, int M, int N, int K, bool fold_producer) {
   double whole = 0;
   GemmPlan plan{0, choose_variant(e, epi, M, N, K, fold_producer, &whole)};
-  if (!e->opt_gemm_split || e->opt_gemm_variant || K < 128 || e->opt_gemm_persistent != 1) return plan;
+  if (!e->opt.gemm_split || e->opt.gemm_variant || K < 128 || e->opt.gemm_persistent != 1) return plan;
   if (!(epi == EPI_STORE_F16 || epi == EPI_RESID_F32 || EPI_IS_GATED(epi) || epi == EPI_RELU_F16)) return plan;   // (the heads index rows from 0)
   const int wgs = e->n_cu & ~7, tiles_n = (N + 255) / 256, tiles_m = (M + 255) / 256;
   const long rounds = (long)tiles_m * tiles_n / wgs;
@@ -315,9 +314,6 @@ GemmPlan choose_plan(const rk_engine* e, int epi, int M, int N, int K, bool fold
   double rest = 0;
   const int v_rest = choose_variant(e, epi, M - panels * 256, N, K, fold_producer, &rest);
   const double split = (double)((used + wgs - 1) / wgs) * 25.5 + rest + 1.5;   // + a kernel boundary
-  // opt_gemm_split = 2 (experiment): the residual GEMMs always split - their ping-pong round costs twice the model's figure (the
-  // read-modify-write epilogue), so a partial last round is dearer than the model thinks
-  if (e->opt_gemm_split >= 2 && epi == EPI_RESID_F32) { plan.m_pp2 = panels * 256; plan.variant = e->opt_gemm_split == 2 ? 1 : 4; return plan; }   // rest on 128x128 (2) / 256x128 (3) tiles
   if (split < whole - 1e-9) { plan.m_pp2 = panels * 256; plan.variant = v_rest; }
   return plan;
 }
@@ -354,42 +350,25 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a_in, int for
     }
   }
 #ifdef RK_MEASURE
-  if constexpr (EPI == EPI_STORE_F16) {                              // stream-K knock-outs (gemm_variant 100 + mask)
-    if (variant > 100 && variant < 116 && sk_ok(e, st, a)) {
-      switch (variant - 100) {
-        case 1: launch_sk<EPI, 1>(e, st, a); return;
-        case 2: launch_sk<EPI, 2>(e, st, a); return;
-        case 3: launch_sk<EPI, 3>(e, st, a); return;
-        case 4: launch_sk<EPI, 4>(e, st, a); return;
-        case 5: launch_sk<EPI, 5>(e, st, a); return;
-        case 6: launch_sk<EPI, 6>(e, st, a); return;
-        default: launch_sk<EPI, 0>(e, st, a); return;
-      }
-    }
-  }
   if constexpr (EPI == EPI_STORE_F16) {                              // timing-only knock-outs (gemm_variant 80 + mask)
     if (variant > 80 && variant <= 96 && a.K >= 128) {
       switch (variant - 80) {
-        case 8: launch_pp2<EPI, 8>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;    // no W-panel DMA
-        case 16: launch_pp2<EPI, 16>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;  // no A-panel DMA
-        case 1: launch_pp2<EPI, 1>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
-        case 2: launch_pp2<EPI, 2>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
-        case 3: launch_pp2<EPI, 3>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
-        case 4: launch_pp2<EPI, 4>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
-        case 5: launch_pp2<EPI, 5>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
-        default: launch_pp2<EPI, 6>(st, a, (e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7))); return;
+        case 8: launch_pp2<EPI, 8>(st, a, (e->opt.gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt.gemm_persistent & ~7))); return;    // no W-panel DMA
+        case 16: launch_pp2<EPI, 16>(st, a, (e->opt.gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt.gemm_persistent & ~7))); return;  // no A-panel DMA
+        case 1: launch_pp2<EPI, 1>(st, a, (e->opt.gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt.gemm_persistent & ~7))); return;
+        case 2: launch_pp2<EPI, 2>(st, a, (e->opt.gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt.gemm_persistent & ~7))); return;
+        case 3: launch_pp2<EPI, 3>(st, a, (e->opt.gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt.gemm_persistent & ~7))); return;
+        case 4: launch_pp2<EPI, 4>(st, a, (e->opt.gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt.gemm_persistent & ~7))); return;
+        case 5: launch_pp2<EPI, 5>(st, a, (e->opt.gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt.gemm_persistent & ~7))); return;
+        default: launch_pp2<EPI, 6>(st, a, (e->opt.gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt.gemm_persistent & ~7))); return;
       }
     }
   }
 #endif
-  if (variant == 7) {
-    if (sk_ok(e, st, a)) { launch_sk<EPI>(e, st, a); return; }
-    variant = choose_variant(e, EPI, a.M, a.N, a.K, a.xraw != nullptr, nullptr, /*no_sk=*/true);
-  }
   if (variant == 6) {
     const int tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
     // stages: as many as keep every tile resident at once (4 -> 2 workgroups per CU, 3 -> 3, 2 -> 4)
-    int nst = e->opt_s64_stages;
+    int nst = e->opt.s64_stages;
     if (nst < 2 || nst > 4) nst = tiles <= 2 * e->n_cu ? 4 : (tiles <= 3 * e->n_cu ? 3 : 2);
     if (nst == 4) {
       static std::atomic<uint64_t> attr_done{0};
@@ -409,20 +388,19 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a_in, int for
   if (variant > 6) variant = 5;
   if (variant == 5 && a.K < 128) variant = 2;                       // the ping-pong kernel needs two K tiles
   if (variant == 5) {
-    const int wgs = e->opt_gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt_gemm_persistent & ~7);
+    const int wgs = e->opt.gemm_persistent == 1 ? (e->n_cu & ~7) : (e->opt.gemm_persistent & ~7);
     if constexpr (EPI == EPI_STORE_F16 || EPI_IS_GATED(EPI) || EPI == EPI_RELU_F16) {
       if (a.rowscale) { launch_pp2<EPI, 0, true>(st, a, wgs); return; }   // consumer side of the folded RMSNorm
     }
-    if constexpr (EPI == EPI_RESID_F32) {
-      // (round-5 experiment, off by default: half of the workgroups start late, old rows of three slabs requested ahead)
-      if (e->opt_gemm_stagger_us > 0 && a.xraw && (long)((a.M + 255) / 256) * ((a.N + 255) / 256) >= 2 * wgs) {
+    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
+      const int ks = e->opt.gemm_persistent == 1 ? choose_ksplit(e, EPI, a.M, a.N, a.K) : 1;
+      const rk_engine::SkWs* w = ks > 1 ? ksplit_workspace(e, st) : nullptr;
+      if (w) {
         GemmArgs b = a;
-        b.stagger_ticks = (int)(100.0 * e->opt_gemm_stagger_us * a.K / 1024.0);
-        if (e->opt_gemm_epi_depth >= 2) launch_pp2<EPI, 0, false, 3>(st, b, wgs);
-        else launch_pp2<EPI>(st, b, wgs);
+        b.ksplit = ks; b.ks_slabs = w->slabs; b.ks_cnt = w->cnt;
+        launch_pp2<EPI, 0, false, true>(st, b, wgs);
         return;
       }
-      if (e->opt_gemm_epi_depth >= 2) { launch_pp2<EPI, 0, false, 3>(st, a, wgs); return; }
     }
     launch_pp2<EPI>(st, a, wgs);
     return;
@@ -432,7 +410,7 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a_in, int for
   if (variant == 4) { launch_v2<EPI, 4, 2, 2, 2>(st, a); return; }
   // (a 16-wave 256x256 form, launch_v2<EPI, 4, 4, 2, 2>, measured 3-9 % slower than the 8-wave one: not instantiated)
   const int tiles = ((a.M + GEMM_BM - 1) / GEMM_BM) * ((a.N + GEMM_BN - 1) / GEMM_BN);
-  if (e->opt_glds)
+  if (e->opt.glds)
     hipLaunchKernelGGL((gemm_f16_kernel<EPI, true>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);
   else
     hipLaunchKernelGGL((gemm_f16_kernel<EPI, false>), dim3(tiles), dim3(256), GEMM_LDS_BYTES, st, a);
@@ -448,51 +426,8 @@ GemmArgs make_gemm_args(const rk_engine* e, const half_t* A, int lda, const half
   GemmArgs a{A, W, C, lda, ldw, ldc, M, N, K, n_split, split_stride, scale, bsA, bsW, bsC};
   a.rowscale = fold.rowscale; a.xraw = fold.xraw; a.ssq = fold.ssq; a.ldx = N; a.nb = (N + 63) / 64; a.xs = RK_XRAW_SCALE;
   a.ssq_in = fold.ssq_in; a.nb_in = fold.nb_in ? fold.nb_in : (K + 63) / 64; a.eps_in = e->d.eps;       // (tiled producers: 64-column blocks)
-  a.group_n = e->opt_gemm_group_n > 0 ? e->opt_gemm_group_n : GEMM_GROUP_N;
+  a.group_n = GEMM_GROUP_N;
   return a;
-}
-
-// ---- chained launch (gemm_chain.h): producer = an fp32 residual GEMM that writes the folded-norm stream, consumer = the GEMM
-// behind the norm.  Same tile loop and epilogues as the separate ping-pong launches: same bits. ----
-bool chain_ok(const rk_engine* e, int M, int Np, int Kp, int Nc, int Kc) {
-  return e->opt_chain && e->opt_fold_norm && e->opt_gemm_persistent == 1 && !e->opt_gemm_variant &&
-         (M + 255) / 256 >= e->opt_chain_min_panels && Kp >= 128 && Kc >= 128 && Kp % 64 == 0 && Kc % 64 == 0 && Np % 64 == 0 && Np == Kc &&
-         (long)M * std::max(std::max(Np, Nc), std::max(Kp, Kc)) * 2 < (1l << 32);      // (32-bit byte offsets of the DMA)
-}
-
-template <int EPI_C>
-void launch_chain(rk_engine* e, hipStream_t st, const ChainArgs& a) {
-  constexpr int smem = 163840;            // the ping-pong kernel's eight half-tile buffers + epilogue staging; scheduler words at the top
-  static std::atomic<uint64_t> attr_done{0};
-  ensure_dynamic_lds((const void*)gemm_chain_kernel<EPI_C>, smem, attr_done);
-  const long tiles = (long)((a.prod.M + 255) / 256) * (((a.prod.N + 255) / 256) + ((a.cons.N + 255) / 256));
-  const int wgs = e->n_cu & ~7;
-  hipLaunchKernelGGL((gemm_chain_kernel<EPI_C>), dim3((unsigned)(tiles < wgs ? tiles : wgs)), dim3(512), smem, st, a);
-}
-
-// prod: C (fp32 stream) += A W^T with xraw / ssq written; cons: Cc = epi_c(rowfactor x (xraw Wc^T))
-void chain_gemm(rk_engine* e, Slot& sl, hipStream_t st, int cls, int epi_c, const half_t* A, int lda, const half_t* W, int ldw, int Kp,
-                const half_t* Wc, int ldwc, void* Cc, int ldcc, int Nc, int T, int launch_index) {
-  const int dm = e->d.d_model;
-  GemmFold pf; pf.xraw = sl.xraw; pf.ssq = sl.ssq;
-  GemmFold cf; cf.rowscale = sl.rowscale;
-  ChainArgs a{};
-  a.prod = make_gemm_args(e, A, lda, W, ldw, sl.hidden, dm, T, dm, Kp, 0, 0, 1.f, 0, 0, 0, pf);
-  a.cons = make_gemm_args(e, sl.xraw, dm, Wc, ldwc, Cc, ldcc, T, Nc, dm, 0, 0, 1.f, 0, 0, 0, cf);
-  a.heads = sl.chain_heads + (size_t)launch_index * CHAIN_QUEUES;
-  a.cnt = sl.chain_cnt; a.flag = sl.chain_flag;
-  if (++sl.chain_epoch == 0) ++sl.chain_epoch;
-  a.epoch = sl.chain_epoch;
-  a.err = sl.chain_err; a.rowscale = sl.rowscale; a.lead_blocks = e->opt_chain_lead;
-  a.trace = (e->chain_trace && launch_index == e->opt_chain_trace_launch) ? e->chain_trace : nullptr; a.debug = e->opt_chain_debug;
-  const double out_c = EPI_IS_GATED(epi_c) ? (double)T * Nc / 2 : (double)T * Nc;
-  Bracket br(e, st, cls, 2.0 * T * (double)dm * Kp + 2.0 * T * (double)Nc * dm,
-             2.0 * ((double)T * Kp + (double)dm * Kp) + (double)T * dm * 8.0 + 2.0 * ((double)T * dm + (double)Nc * dm) + out_c * 2.0);
-  switch (epi_c) {
-    case EPI_GEGLU_F16: launch_chain<EPI_GEGLU_F16>(e, st, a); break;
-    case EPI_RELU_F16: launch_chain<EPI_RELU_F16>(e, st, a); break;
-    default: launch_chain<EPI_STORE_F16>(e, st, a); break;
-  }
 }
 
 void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int lda, const half_t* W, int ldw, void* C,
@@ -507,7 +442,7 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
   Bracket br(e, st, cls, flops, bytes);
   // Kernel family is chosen by the CALLER's regime, never by M: a row's result must not depend on how many other rows
   // share the launch (the split-K weight-streaming kernel and the tiled kernels sum K in different orders).
-  if ((weight_streaming || batch > 1) && n_split == 0 && (((e->opt_skinny >> epi) & 1) || batch > 1 || epi == EPI_ARGMAX_F32)) {
+  if ((weight_streaming || batch > 1) && n_split == 0 && (((e->opt.skinny >> epi) & 1) || batch > 1 || epi == EPI_ARGMAX_F32)) {
     // (a form where one workgroup takes up to 8 row slabs - 8x fewer, fatter workgroups - was bit-identical but made
     // the step 6 % slower: what the decoder costs the concurrent encoder GEMMs is the serial LENGTH of its chain, every
     // kernel delaying some tile of the GEMM in flight, not its CU-time; so: many short workgroups)
@@ -627,7 +562,7 @@ int upload_small(rk_engine* e, Slot& sl, hipStream_t st, std::vector<int>* cache
 // L x 2I x d for the projections: cheaper up to L_d ~ 64, and far fewer bytes below 16).  More rows than the workspace
 // holds are taken in passes (run_decoder).
 bool use_xattn_direct(const rk_engine* e, const Slot&, int max_ld) {
-  return e->opt_xattn_direct && max_ld <= XA_MAX_LD;
+  return e->opt.xattn_direct && max_ld <= XA_MAX_LD;
 }
 
 int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
@@ -637,27 +572,18 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
   // Folded RMSNorm (default): the GEMMs that follow a norm read the un-normalised stream as fp16 (written by the
   // producer of the stream: embedding / residual epilogue), their weights carry the norm weight, and their epilogue
   // applies the row factor - the two norm kernels per layer (re-reading the fp32 stream) are gone.
-  const bool fold = e->opt_fold_norm != 0;
+  const bool fold = e->opt.fold_norm != 0;
   GemmFold cons, cons_ssq, prod;
   if (fold) { cons.rowscale = sl.rowscale; cons_ssq.ssq_in = sl.ssq; prod.xraw = sl.xraw; prod.ssq = sl.ssq; }
   // The persistent ping-pong GEMM takes its row factors ready-made (loaded under its last MFMAs): a rowscale_kernel runs in
   // front of it.  The fill-in tile variants of small launches (one setwise prompt) add the block sums themselves in their
   // epilogue (gemm_row_factors, same rk_row_factor -> same bits): two 5-us launches per layer less where launches are what costs.
-  const bool qkv_pp2 = !e->opt_consumer_stats || consumer_uses_pp2(e, EPI_STORE_F16, T, 3 * I, dm);
-  const bool ffn_pp2 = !e->opt_consumer_stats || consumer_uses_pp2(e, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, T, d.gated_gelu ? 2 * F : F, dm);
+  const bool qkv_pp2 = !e->opt.consumer_stats || consumer_uses_pp2(e, EPI_STORE_F16, T, 3 * I, dm);
+  const bool ffn_pp2 = !e->opt.consumer_stats || consumer_uses_pp2(e, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, T, d.gated_gelu ? 2 * F : F, dm);
   embed(e, st, sl.d_tokens, sl.hidden, T, fold ? sl.xraw : nullptr, fold ? sl.rowscale : nullptr);
-  // Chained form (gemm_chain.h; large batches): per layer {O -> FFN-in} and {FFN-out -> next layer's QKV} are ONE persistent launch
-  // each - 3 launches per layer instead of 7, same bits.  The queue heads of all the launches of this pass are zeroed here once.
-  const int Nffn = d.gated_gelu ? 2 * F : F;
-  const bool chain = fold && chain_ok(e, T, dm, I, Nffn, dm) && chain_ok(e, T, dm, F, 3 * I, dm) && 2 * d.n_enc_layers * CHAIN_QUEUES <= sl.chain_heads_cap;
-  const bool chainA = chain && e->opt_chain_only != 2, chainB = chain && e->opt_chain_only != 1;   // (chain_only: measurement switch, 0 = both)
-  int chain_i = 0;
-  if (chain) HIPCHK(e, hipMemsetAsync(sl.chain_heads, 0, (size_t)sl.chain_heads_cap * sizeof(int), st));
   for (int l = 0; l < d.n_enc_layers; ++l) {
     const EncLayerW& w = e->enc[l];
-    if (chainB && l > 0) {
-      // this layer's q/k/v rows were written by the previous layer's {FFN-out -> QKV} launch
-    } else if (fold) {
+    if (fold) {
       gemm(e, st, PC_ENC_GEMM_QKV, EPI_STORE_F16, sl.xraw, dm, w.qkv_f, dm, sl.qkv, 3 * I, T, 3 * I, dm, 0, 0, 1.f, 1, 0, 0, 0, false,
            (l == 0 || qkv_pp2) ? cons : cons_ssq);            // layer 0: the embedding kernel wrote the row factors
     } else {
@@ -668,18 +594,18 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
       // Every sequence of the batch at most ATT_ROW_MAXL keys: the DMA kernel (attn_short = 5, the default: two six-wave groups
       // per 768-thread workgroup; 6: one group per workgroup); otherwise, or with attn_short = 0, the tiled kernel.  The two
       // compute a sequence bit-identically (attention.h: ATT_ROW_MAXL).
-      AttnEncArgs a{sl.qkv, sl.ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I, 1, e->opt_attn_ko};
+      AttnEncArgs a{sl.qkv, sl.ctx, sl.d_seq_off, e->lut_enc, 3 * I, I, I, 1, e->opt.attn_ko};
 #ifdef RK_MEASURE
       a.trace = e->attn_trace;
 #endif
       const double att_flops = 4.0 * (double)sl.maxL * T * I;   // exact for uniform lengths, upper bound if ragged
       Bracket br(e, st, PC_ENC_ATTN, att_flops, (double)T * 4 * I * 2.0);
-      if (sl.maxL <= ATT_ROW_MAXL && e->opt_attn_short) {
-        const int ng = e->opt_attn_short == 6 ? 1 : 2;
+      if (sl.maxL <= ATT_ROW_MAXL && e->opt.attn_short) {
+        const int ng = e->opt.attn_short == 6 ? 1 : 2;
         // persistent launch: at most one workgroup per CU, the (sequence, head) items dealt out evenly in contiguous runs per
         // wave group (320 sequences x 16 heads on 256 CUs x 2 groups: 10 items each)
         const long total = (long)sl.n_seq * d.n_heads, groups = (long)e->n_cu * ng;
-        const int per = e->opt_attn_heads_per_wg > 0 ? e->opt_attn_heads_per_wg : (int)((total + groups - 1) / groups);
+        const int per = e->opt.attn_heads_per_wg > 0 ? e->opt.attn_heads_per_wg : (int)((total + groups - 1) / groups);
         a.heads_per_wg = per;
         a.n_seq = sl.n_seq;
         const dim3 grid((unsigned)((total + (long)ng * per - 1) / ((long)ng * per)));
@@ -693,20 +619,20 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
           hipLaunchKernelGGL(attn_enc_dma_kernel<1>, grid, dim3(384), ATTD_LDS_BYTES, st, a);
         }
       }
-      else if (e->opt_attn_long) {
+      else if (e->opt.attn_long) {
         // every sequence longer than ATT_ROW_MAXL keys: the chunked LDS-DMA kernel (round 5); the batch's short sequences (if any):
         // the tiled kernel, which reproduces the short kernel's bits - a sequence's result depends on ITS length only
         if (sl.minL <= ATT_ROW_MAXL) {
           a.skip_long = 1;
-          hipLaunchKernelGGL(attn_enc_kernel<2>, dim3((ATT_ROW_MAXL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
+          hipLaunchKernelGGL(attn_enc_kernel, dim3((ATT_ROW_MAXL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
         }
         // waves per workgroup (same bits for every choice): option attn_long_nw, or from the batch - enough workgroups for the chip
-        int nw = e->opt_attn_long_nw;
+        int nw = e->opt.attn_long_nw;
         // (measured, one to eight 1 560-token prompts: 4 waves = 128 queries per workgroup, two workgroups per CU, wins everywhere -
         // 36.9 / 49.1 / 157.5 us per layer at 1 / 2 / 8 prompts against 60 / 60 / 180 at twelve waves, 48 / 85 / 212 at six (384-thread
         // workgroups of this register size run one per CU) and 39.6 / 67.6 / 224.9 for the tiled kernel; profiles/r05_attn_long.jsonl)
         if (nw != 12 && nw != 6 && nw != 4 && nw != 3) nw = 4;
-        a.n_seq = sl.n_seq; a.n_heads = d.n_heads; a.nqb = (sl.maxL + 32 * nw - 1) / (32 * nw); a.xcd_map = e->opt_attn_long_xcd;
+        a.n_seq = sl.n_seq; a.n_heads = d.n_heads; a.nqb = (sl.maxL + 32 * nw - 1) / (32 * nw); a.xcd_map = e->opt.attn_long_xcd;
         const dim3 grid(xcd_grid(sl.n_seq * d.n_heads, a.nqb));
         static std::atomic<uint64_t> attr12{0}, attr6{0}, attr4{0}, attr3{0};
         if (nw == 12) { ensure_dynamic_lds((const void*)attn_enc_long_kernel<12>, ATTL_LDS_BYTES, attr12); hipLaunchKernelGGL(attn_enc_long_kernel<12>, grid, dim3(768), ATTL_LDS_BYTES, st, a); }
@@ -714,31 +640,8 @@ int run_encoder(rk_engine* e, Slot& sl, bool need_cross_kv) {
         else if (nw == 4) { ensure_dynamic_lds((const void*)attn_enc_long_kernel<4>, ATTL_LDS_BYTES, attr4); hipLaunchKernelGGL(attn_enc_long_kernel<4>, grid, dim3(256), ATTL_LDS_BYTES, st, a); }
         else { ensure_dynamic_lds((const void*)attn_enc_long_kernel<3>, ATTL_LDS_BYTES, attr3); hipLaunchKernelGGL(attn_enc_long_kernel<3>, grid, dim3(192), ATTL_LDS_BYTES, st, a); }
       }
-      else if (e->opt_attn_tiled_occ >= 3)
-        hipLaunchKernelGGL(attn_enc_kernel<3>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
-      else if (e->opt_attn_tiled_occ == 2 && e->opt_attn_split && sl.maxL > ATT_SPLIT_MIN_L)   // long prompts: two key halves per workgroup
-        hipLaunchKernelGGL((attn_enc_kernel<2, 2>), dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(512), 0, st, a);
-      else if (e->opt_attn_tiled_occ == 2)
-        hipLaunchKernelGGL(attn_enc_kernel<2>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
-      else
-        hipLaunchKernelGGL(attn_enc_kernel<1>, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
-    }
-    if (chain) {
-      const bool last = l + 1 == d.n_enc_layers;
-      if (chainA) {
-        chain_gemm(e, sl, st, PC_ENC_CHAIN_O_FFN, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, sl.ctx, I, w.o, I, I, w.ffn_in_f, dm, sl.ffh, F, Nffn, T, chain_i++);
-      } else {
-        gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, I, w.o, I, sl.hidden, dm, T, dm, I, 0, 0, 1.f, 1, 0, 0, 0, false, prod);
-        rowscale(e, st, sl.ssq, sl.rowscale, T);
-        gemm(e, st, PC_ENC_GEMM_FFN_IN, d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, sl.xraw, dm, w.ffn_in_f, dm, sl.ffh, F, T, Nffn, dm, 0, 0, 1.f, 1, 0, 0, 0, false, cons);
-      }
-      if (last) gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, sl.ffh, F, w.ffn_out, F, sl.hidden, dm, T, dm, F);   // the final norm reads the fp32 stream itself
-      else if (chainB) chain_gemm(e, sl, st, PC_ENC_CHAIN_FFO_QKV, EPI_STORE_F16, sl.ffh, F, w.ffn_out, F, F, e->enc[l + 1].qkv_f, dm, sl.qkv, 3 * I, 3 * I, T, chain_i++);
-      else {
-        gemm(e, st, PC_ENC_GEMM_FFN_OUT, EPI_RESID_F32, sl.ffh, F, w.ffn_out, F, sl.hidden, dm, T, dm, F, 0, 0, 1.f, 1, 0, 0, 0, false, prod);
-        rowscale(e, st, sl.ssq, sl.rowscale, T);
-      }
-      continue;
+      else   // option attn_long = 0: the tiled kernel for every length (the on-device cross-check of the two DMA kernels)
+        hipLaunchKernelGGL(attn_enc_kernel, dim3((sl.maxL + 127) / 128, d.n_heads, sl.n_seq), dim3(256), 0, st, a);
     }
     if (fold) {
       gemm(e, st, PC_ENC_GEMM_O, EPI_RESID_F32, sl.ctx, I, w.o, I, sl.hidden, dm, T, dm, I, 0, 0, 1.f, 1, 0, 0, 0, false, prod);
@@ -790,7 +693,7 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
   // the new rows as fp16 (dxraw) with their sums of squares per 32-column block (dssq), the GEMM behind the norm reads
   // those with the norm weight folded into its matrix and forms the row factor itself (gemm.h: GemmArgs::ssq_in) - three
   // launches per layer less.  A producer never writes the buffer a workgroup of the same launch may still read: two of each.
-  const bool dfold = ws && e->opt_dec_fold_norm && (e->opt_skinny & 0x3F) == 0x3F;
+  const bool dfold = ws && e->opt.dec_fold_norm && (e->opt.skinny & 0x3F) == 0x3F;
   int cur = 0; bool from_embed = true;
   // (the producers of dssq are weight-streaming GEMMs: 32-column blocks, whichever kernel family consumes them)
   auto cons = [&]() { GemmFold f; if (from_embed) f.rowscale = sl.drowscale; else { f.ssq_in = sl.dssq[cur]; f.nb_in = (dm + 31) / 32; } return f; };
@@ -821,7 +724,7 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
         if (tree) {
           a.tree_keys = tree->keys; a.tree_pos = tree->pos;
           hipLaunchKernelGGL(attn_dec_kernel, dim3(1, d.n_heads, M), dim3(256), smem_self, st, a);
-        } else if (e->opt_dec_attn_seq && attn_dec_seq_lds(Ld) <= 160 * 1024) {   // one workgroup per (head, sequence): K / V staged once (same bits)
+        } else if (e->opt.dec_attn_seq && attn_dec_seq_lds(Ld) <= 160 * 1024) {   // one workgroup per (head, sequence): K / V staged once (same bits)
           hipLaunchKernelGGL(attn_dec_seq_kernel, dim3(d.n_heads, B), dim3(256), attn_dec_seq_lds(Ld), st, a);
         } else {
           hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_self, st, a);
@@ -836,7 +739,7 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
     // pipeline gains 1.2 %; at the 13 rows x 23 chunks of a setwise compare it is 4 us per layer SLOWER (the separate GEMMs spread
     // the cold weights of a layer over 512 + 5120 workgroups).  The family follows from the CALL SHAPE, never from the batch
     // (the two round differently): fused for one decoder position, separate beyond (dec_fuse = 2 forces the fused form: tests)
-    const bool fuse = (e->opt_dec_fuse == 2 || (e->opt_dec_fuse == 1 && Ld == 1)) && !sl.have_cross_kv && dm % 128 == 0;   // (eight K ranges of whole k16 steps per workgroup)
+    const bool fuse = (e->opt.dec_fuse == 2 || (e->opt.dec_fuse == 1 && Ld == 1)) && !sl.have_cross_kv && dm % 128 == 0;   // (eight K ranges of whole k16 steps per workgroup)
     if (!dfold) rmsnorm(e, st, sl.dhidden, w.ln1, sl.dxn, nullptr, M);
     if (!fuse) {
       if (dfold) gemm(e, st, PC_DEC_GEMM, EPI_STORE_F16, sl.dxraw[cur], dm, w.cq_f, dm, sl.dq, I, M, I, dm, 0, 0, 1.f, 1, 0, 0, 0, ws, cons());
@@ -854,7 +757,7 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
           const GemmFold cf = dfold ? cons() : GemmFold();
           DecQKArgs qa{(dfold ? sl.dxraw[cur] : sl.dxn) + (size_t)r0 * dm, dm, dfold ? w.cq_f : w.cq, w.ckT, sl.xqk, nr, dm, H,
                        cf.rowscale ? cf.rowscale + r0 : nullptr, cf.ssq_in ? cf.ssq_in + (size_t)r0 * cf.nb_in : nullptr, cf.nb_in, d.eps, RK_XRAW_SCALE, 32, 1};
-          if (e->opt_dec_fuse_rows > 0) qa.R = std::min(32, e->opt_dec_fuse_rows);
+          if (e->opt.dec_fuse_rows > 0) qa.R = std::min(32, e->opt.dec_fuse_rows);
           else if (nr <= 16) qa.R = 16;   // (a setwise pass: 13 rows - half the MFMA columns, half the x rows; measured at 320 rows: 32 > 16 > 8)
           // few rows: several workgroups per (head, slab) share the output columns, each streaming 1 / CS of W_k^T (and all of W_q,h)
           while (qa.CS < 8 && (dm / 64) % (2 * qa.CS) == 0 && (long)((nr + qa.R - 1) / qa.R) * H * qa.CS < e->n_cu / 2) qa.CS *= 2;
@@ -870,7 +773,7 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
           // MFMA form (weighted sums on the matrix cores, the chunk's encoder rows staged in LDS by a loader wave) whenever
           // the model width allows its LDS image; the VALU form otherwise.  The choice depends on the MODEL only, never on the
           // batch (the two round differently).
-          if (e->opt_xattn_mfma && dm % 256 == 0) {             // (every wave takes whole 64-column pieces of its quarter)
+          if (e->opt.xattn_mfma && dm % 256 == 0) {             // (every wave takes whole 64-column pieces of its quarter)
             hipLaunchKernelGGL(xattn_part_mfma_kernel, dim3(nch, nr, (H + 15) / 16), dim3(256), 0, st, xa);
           } else if ((long)nch * nr * ((H + 15) / 16) >= 2 * e->n_cu)
             hipLaunchKernelGGL(xattn_part_kernel<16>, dim3(nch, nr, (H + 15) / 16), dim3(256), 0, st, xa);
@@ -897,7 +800,7 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
       const half_t* kv = sl.cross_kv + (size_t)l * d.max_tokens * 2 * I;
       AttnDecArgs a{sl.dq, I, kv, kv + I, 2 * I, sl.d_seq_off, sl.dctx, I, nullptr, Ld, 0, sl.maxL};
       Bracket br(e, st, PC_DEC_ATTN, 4.0 * Ld * (double)sl.T * I, (double)sl.T * 2 * I * 2.0);
-      if (e->opt_dec_attn_seq && Ld >= 2 && attn_dec_seq_lds(sl.maxL) <= 160 * 1024)
+      if (e->opt.dec_attn_seq && Ld >= 2 && attn_dec_seq_lds(sl.maxL) <= 160 * 1024)
         hipLaunchKernelGGL(attn_dec_seq_kernel, dim3(d.n_heads, B), dim3(256), attn_dec_seq_lds(sl.maxL), st, a);
       else
         hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_cross, st, a);
@@ -912,7 +815,7 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
         // 0.28 ms per step, +0.9 % passages/s).  The family follows from the call shape (L_d == 1), never from the batch, so a
         // row's bits still do not depend on what shares its launch; the other projections of the layer (1024 columns: 80 tiles)
         // measured the same on either family and stay where they were.
-        const bool tiled_in = e->opt_dec_ffn_tiled && Ld == 1;
+        const bool tiled_in = e->opt.dec_ffn_tiled && Ld == 1;
         const int epi_in = d.gated_gelu ? EPI_GEGLU_F16 : EPI_RELU_F16, n_in = d.gated_gelu ? 2 * F : F;
         GemmFold cf = cons();
         if (tiled_in && cf.ssq_in && consumer_uses_pp2(e, epi_in, M, n_in, dm)) {
@@ -962,24 +865,12 @@ int mark_decoder_done(rk_engine* e, Slot& sl) {
   return RK_OK;
 }
 
-// a chained launch whose row-panel hand-off timed out leaves an error word (gemm_chain.h: the GPU is never left spinning):
-// checked wherever the host has just waited for results
-int chain_check(rk_engine* e) {
-  for (Slot& sl : e->slots)
-    if (sl.chain_err && *(volatile int*)sl.chain_err != 0) {
-      *(volatile int*)sl.chain_err = 0;
-      for (Slot& s2 : e->slots) if (s2.chain_cnt) hipMemset(s2.chain_cnt, 0, ((size_t)(e->d.max_tokens + 255) / 256 + 1) * sizeof(int));   // a cut launch may have left tickets
-      return fail(e, RK_ERR_STATE, "chained GEMM launch: a row-panel hand-off timed out - results of this call are invalid (engine option chain=0 runs the separate launches)");
-    }
-  return RK_OK;
-}
-
 int sync_all(rk_engine* e) {
   for (Slot& sl : e->slots) {
     HIPCHK(e, hipStreamSynchronize(sl.se));
     HIPCHK(e, hipStreamSynchronize(sl.sd));
   }
-  return chain_check(e);
+  return RK_OK;
 }
 
 int ensure_logits(rk_engine* e, size_t rows) {
@@ -1066,7 +957,7 @@ int stage_slot(rk_engine* e, int slot, const int32_t* tokens, const int32_t* seq
 template <class F>
 int run_graphed(rk_engine* e, hipStream_t st, std::vector<int> key, F&& body) {
   key.push_back(e->opt_epoch);
-  if (!e->opt_dec_graph || e->prof_on) return body();
+  if (!e->opt.dec_graph || e->prof_on) return body();
   auto& g = e->graphs[key];
   if (g.exec) { HIPCHK(e, hipGraphLaunch(g.exec, st)); return RK_OK; }
   if (g.failed || g.seen++ == 0) return body();          // first sighting: eager (also does the one-off kernel attribute calls)
@@ -1276,9 +1167,9 @@ int rk_engine_create(const rk_model_desc* desc, int device_ordinal, rk_engine** 
   for (int i = 0; ok && i < 2 * RK_SLOTS; ++i) {
     rk_engine::SkWs& w = e->sk_ws[i];
     w.st = (i & 1) ? e->slots[i >> 1].sd : e->slots[i >> 1].se;
-    ok = hipMalloc((void**)&w.slabs, (size_t)2 * e->n_cu * SK_SLAB_FLOATS * sizeof(float)) == hipSuccess &&
-         hipMalloc((void**)&w.cnt, SK_MAX_TILES * sizeof(int)) == hipSuccess &&
-         hipMemset(w.cnt, 0, SK_MAX_TILES * sizeof(int)) == hipSuccess;
+    ok = hipMalloc((void**)&w.slabs, (size_t)KSPLIT_MAX_SLABS * 65536 * sizeof(float)) == hipSuccess &&
+         hipMalloc((void**)&w.cnt, KSPLIT_MAX_SLABS * sizeof(int)) == hipSuccess &&
+         hipMemset(w.cnt, 0, KSPLIT_MAX_SLABS * sizeof(int)) == hipSuccess;
   }
   if (!ok) {
     for (auto& w : e->sk_ws) { if (w.slabs) hipFree(w.slabs); if (w.cnt) hipFree(w.cnt); }
@@ -1307,7 +1198,6 @@ void rk_engine_destroy(rk_engine* e) {
   for (auto& sl : e->slots) {
     if (sl.h_scores) hipHostFree(sl.h_scores);
     if (sl.h_small) hipHostFree(sl.h_small);
-    if (sl.chain_err) hipHostFree(sl.chain_err);
     if (sl.ev_enc) hipEventDestroy(sl.ev_enc);
     if (sl.ev_dec) hipEventDestroy(sl.ev_dec);
   }
@@ -1496,7 +1386,7 @@ int rk_engine_finalize(rk_engine* e) {
     RC(dalloc(e, &d_vT, (size_t)dm * I)); RC(dalloc(e, &d_ov32, (size_t)dm * dm));
     std::vector<half_t> vT((size_t)dm * I), ov16((size_t)dm * dm);
     std::vector<float> ov32((size_t)dm * dm);
-    const int saved_variant = e->opt_gemm_variant;
+    const int saved_variant = e->opt.gemm_variant;
     for (int l = 0; l < d.n_dec_layers; ++l) {
       const std::string p = "decoder.block." + std::to_string(l) + ".layer.0.SelfAttention.";
       const auto& wv = H(p + "v.weight");
@@ -1512,7 +1402,7 @@ int rk_engine_finalize(rk_engine* e) {
       for (size_t i = 0; i < ov32.size(); ++i) ov16[i] = (half_t)(ov32[i] * ln0[i % dm]);
       RC(up_h(&e->dec[l].ov_f, ov16));
     }
-    e->opt_gemm_variant = saved_variant;
+    e->opt.gemm_variant = saved_variant;
     HIPCHK(e, hipGetLastError());
   }
   e->host.clear();
@@ -1525,14 +1415,6 @@ int rk_engine_finalize(rk_engine* e) {
     RC(dalloc(e, &sl.ctx, Tc * I)); RC(dalloc(e, &sl.ffh, Tc * F)); RC(dalloc(e, &sl.enc_out, Tc * dm));
     RC(dalloc(e, &sl.xraw, Tc * dm)); RC(dalloc(e, &sl.ssq, Tc * ((dm + 63) / 64))); RC(dalloc(e, &sl.rowscale, Tc + 512));   // padded: the ping-pong GEMM reads the row factors of a whole 256-row tile
     HIPCHK(e, hipMemset(sl.rowscale, 0, (Tc + 512) * sizeof(float)));
-    {
-      const size_t panels = (Tc + 255) / 256 + 1;
-      sl.chain_heads_cap = 2 * d.n_enc_layers * CHAIN_QUEUES;
-      RC(dalloc(e, &sl.chain_heads, (size_t)sl.chain_heads_cap)); RC(dalloc(e, &sl.chain_cnt, panels)); RC(dalloc(e, &sl.chain_flag, panels));
-      HIPCHK(e, hipMemset(sl.chain_cnt, 0, panels * sizeof(int))); HIPCHK(e, hipMemset(sl.chain_flag, 0, panels * sizeof(unsigned)));
-      HIPCHK(e, hipHostMalloc((void**)&sl.chain_err, 64, hipHostMallocDefault));
-      *sl.chain_err = 0;
-    }
     RC(dalloc(e, &sl.d_tokens, Tc)); RC(dalloc(e, &sl.d_seq_off, Bc + 1));
     RC(dalloc(e, &sl.cross_kv, (size_t)d.n_dec_layers * Tc * 2 * I));
     RC(dalloc(e, &sl.d_dec_ids, Mc)); RC(dalloc(e, &sl.d_last_rows, Bc)); RC(dalloc(e, &sl.d_out_ids, 8192));
@@ -1596,8 +1478,6 @@ int rk_t5_read_scores_slot(rk_engine* e, int slot, float* out_logits, int n_floa
   Slot& sl = e->slots[slot];
   if (n_floats > sl.n_seq * sl.last_n_out) return fail(e, RK_ERR_INVALID, "asked for %d floats, have %d", n_floats, sl.n_seq * sl.last_n_out);
   if (sl.dec_pending) { HIPCHK(e, hipEventSynchronize(sl.ev_dec)); sl.dec_pending = false; }
-  int rc = chain_check(e);
-  if (rc) return rc;
   memcpy(out_logits, sl.h_scores, (size_t)n_floats * sizeof(float));
   return RK_OK;
 }
@@ -1754,7 +1634,7 @@ int rk_t5_greedy2(rk_engine* e, const int32_t* tokens, const int32_t* seq_offset
   const long per_seq = (long)dec_len + n_cand;                         // rows of one prompt: the prefix once, one row per candidate
   const long M = (long)n_seq * per_seq, R = (long)n_seq * (1 + n_cand);
   const bool fits = cand_ids && n_cand > 0 && dec_prefix && dec_len > 0 && Ld <= e->d.max_dec_len && R <= e->d.max_seqs &&
-                    M <= (long)e->d.max_seqs * e->d.max_dec_len && M <= XA_MAX_ROWS && M <= e->opt_greedy_spec &&
+                    M <= (long)e->d.max_seqs * e->d.max_dec_len && M <= XA_MAX_ROWS && M <= e->opt.greedy_spec &&
                     use_xattn_direct(e, e->slots[0], Ld);
   if (!fits) return rk_t5_greedy(e, tokens, seq_offsets, n_seq, dec_prefix, dec_len, 2, eos_id, pad_id, out_tokens, out_steps);
   int rc;
@@ -1986,17 +1866,17 @@ static int llama_prefill(rk_engine* e, const int32_t* tokens, const int32_t* off
       hipLaunchKernelGGL(rope128_kernel, dim3(T), dim3(256), 0, st, sl.qkv, e->d_pos, e->rope_cos, e->rope_sin, ldq, l.n_heads + l.n_kv_heads);
     }
     {
-      AttnCausalArgs a{sl.qkv, sl.ctx, sl.d_seq_off, ldq, Q, l.n_heads, l.n_kv_heads, scale_log2e, 0, 0, e->opt_attn_ko};
+      AttnCausalArgs a{sl.qkv, sl.ctx, sl.d_seq_off, ldq, Q, l.n_heads, l.n_kv_heads, scale_log2e, 0, 0, e->opt.attn_ko};
       Bracket br(e, st, PC_ENC_ATTN, 2.0 * (double)sl.maxL * T * Q, (double)T * (2 * Q + 2 * KV) * 2.0);   // causal: half of 4 L T Q
-      if (e->opt_llama_attn_dma) {     // K / V chunks by LDS-DMA, V^T by transposing reads (round 5); chosen by the option alone: batch-independent
+      if (e->opt.llama_attn_dma) {     // K / V chunks by LDS-DMA, V^T by transposing reads (round 5); chosen by the option alone: batch-independent
         static std::atomic<uint64_t> attr_done{0};
         static std::atomic<uint64_t> attr_done8{0};
         int lds = ATCD_LDS_BYTES, lds_max = ATCD_LDS_BYTES;
 #ifdef RK_MEASURE
         lds_max += 49152;
-        if (e->opt_attn_ko & 256) lds += 49152;          // residency probe: 112 KiB per workgroup = ONE per CU for certain
+        if (e->opt.attn_ko & 256) lds += 49152;          // residency probe: 112 KiB per workgroup = ONE per CU for certain
 #endif
-        const int nw = e->opt_llama_attn_nw == 8 ? 8 : 4;   // same bits either way
+        const int nw = e->opt.llama_attn_nw == 8 ? 8 : 4;   // same bits either way
         a.n_seq = n_seq; a.nqb = (sl.maxL + 32 * nw - 1) / (32 * nw);
         const dim3 grid(xcd_grid(n_seq * l.n_kv_heads, (l.n_heads / l.n_kv_heads) * a.nqb));
         if (nw == 8) { ensure_dynamic_lds((const void*)attn_causal128_dma_kernel<8>, lds_max, attr_done8); hipLaunchKernelGGL(attn_causal128_dma_kernel<8>, grid, dim3(512), lds, st, a); }
@@ -2277,65 +2157,80 @@ int rk_profile_get(rk_engine* e, int cls, double* total_ms, int64_t* launches, d
   return RK_OK;
 }
 
+}  // extern "C" (reopened behind the option table)
+
+// Option table: key -> field, the values it accepts (lo..hi, or the listed set), meaning.  A value outside the range is an error
+// (RK_ERR_INVALID), as include/rk_engine.h promises - a sweep can never record a value that was not applied.
+namespace {
+struct OptionDesc { const char* key; int rk_engine::Options::*field; int lo, hi; const char* allowed; const char* what; };
+const OptionDesc kOptions[] = {
+  {"dec_graph", &rk_engine::Options::dec_graph, 0, 1, nullptr, "decoder chains replayed as HIP graphs (1) or launched eagerly (0)"},
+  {"gemm_glds", &rk_engine::Options::glds, 0, 1, nullptr, "128x128 GEMM staging by LDS-DMA (1) or through registers (0); same bits"},
+  {"gemm_skinny", &rk_engine::Options::skinny, 0, 0x3F, nullptr, "bit per epilogue kind: few-row GEMMs on the weight-streaming kernel (1 = all)"},
+  {"dec_ffn_tiled", &rk_engine::Options::dec_ffn_tiled, 0, 1, nullptr, "one-position decoder: FFN-in on the tiled kernels (1) or the weight-streaming kernel (0)"},
+  {"gemm_persistent", &rk_engine::Options::gemm_persistent, 0, 1024, nullptr, "ping-pong GEMM: 1 = one workgroup per CU walks the tiles, 0 = one per tile, n > 1 = n workgroups"},
+  {"gemm_s64_stages", &rk_engine::Options::s64_stages, 0, 4, "0,2,3,4", "LDS stages of the 64x64 GEMM (0 = from the tile count); same bits"},
+  {"consumer_stats", &rk_engine::Options::consumer_stats, 0, 1, nullptr, "encoder row factors formed by the non-persistent consumer GEMMs themselves (1) or always by rowscale_kernel (0); same bits"},
+  {"greedy_spec", &rk_engine::Options::greedy_spec, 0, 65536, nullptr, "rk_t5_greedy2: most decoder rows of a speculative pass; 0 = never speculate; same tokens"},
+  {"dec_fold_norm", &rk_engine::Options::dec_fold_norm, 0, 1, nullptr, "decoder RMSNorms folded into the weight-streaming GEMMs (1) or separate kernels (0)"},
+  {"fold_norm", &rk_engine::Options::fold_norm, 0, 1, nullptr, "encoder RMSNorm folded into the GEMMs (1) or separate kernels (0)"},
+  {"xattn_mfma", &rk_engine::Options::xattn_mfma, 0, 1, nullptr, "query-side cross-attention: weighted sums on the matrix cores (1) or the VALU form (0)"},
+  {"attn_heads_per_wg", &rk_engine::Options::attn_heads_per_wg, 0, 4096, nullptr, "short-sequence attention: (sequence, head) items per wave group, 0 = dealt evenly; same bits"},
+  {"xattn_direct", &rk_engine::Options::xattn_direct, 0, 1, nullptr, "decoder prefixes <= 16: query-side cross-attention (1) or materialised K / V (0)"},
+  {"attn_short", &rk_engine::Options::attn_short, 0, 6, "0,5,6", "sequences <= 192 keys: DMA kernel with two (5) / one (6) wave group per workgroup, or the tiled kernel (0); same bits"},
+  {"gemm_variant", &rk_engine::Options::gemm_variant, 0, 120, nullptr, "tile variant: 0 auto, 1..6 see choose_variant, 7 stream-K; measurement builds: 80+ / 100+ knock-outs"},
+  {"dec_fuse_rows", &rk_engine::Options::dec_fuse_rows, 0, 32, nullptr, "rows per workgroup of dec_cross_qk_kernel (0 = auto); same bits"},
+  {"dec_fuse", &rk_engine::Options::dec_fuse, 0, 2, nullptr, "few-row decoder: projections around the query-side cross-attention fused at one position (1), always (2), never (0)"},
+  {"llama_attn_nw", &rk_engine::Options::llama_attn_nw, 0, 8, "0,4,8", "waves per workgroup of the Llama LDS-DMA attention kernel (0 = default 8); same bits"},
+  {"llama_attn_dma", &rk_engine::Options::llama_attn_dma, 0, 1, nullptr, "Llama causal attention: LDS-DMA kernel (1) or the register-staged first kernel (0); differ within fp16 noise"},
+  {"attn_long_xcd", &rk_engine::Options::attn_long_xcd, 0, 1, nullptr, "long-sequence attention: workgroups of a (sequence, head) pair on one XCD (1) or dealt over all eight (0); same bits"},
+  {"attn_long_nw", &rk_engine::Options::attn_long_nw, 0, 12, "0,3,4,6,12", "waves per workgroup of the long-sequence attention kernel (0 = default 4); same bits"},
+  {"attn_long", &rk_engine::Options::attn_long, 0, 1, nullptr, "sequences > 192 keys: the chunked LDS-DMA kernel (1) or the tiled kernel (0)"},
+  {"dec_attn_seq", &rk_engine::Options::dec_attn_seq, 0, 1, nullptr, "decoder attention at several positions: one workgroup per (head, sequence) (1) or per query row (0); same bits"},
+  {"gemm_sk", &rk_engine::Options::gemm_sk, 0, 2, nullptr, "ping-pong GEMM, fp32 residual projections with few tiles and a long K: K split over two workgroups (1: choose_ksplit), never (0), wherever it fits (2: tests)"},
+  {"gemm_split", &rk_engine::Options::gemm_split, 0, 1, nullptr, "rows beyond the ping-pong kernel's last whole round on a fill-in tile variant (1) or one launch (0); same bits"},
+#ifdef RK_MEASURE
+  {"attn_ko", &rk_engine::Options::attn_ko, 0, 1 << 20, nullptr, "timing-only knock-outs of the attention kernels (measurement builds)"},
+#endif
+};
+bool option_value_ok(const OptionDesc& o, int value) {
+  if (value < o.lo || value > o.hi) return false;
+  if (!o.allowed) return true;
+  for (const char* p = o.allowed; *p;) {
+    if (atoi(p) == value) return true;
+    while (*p && *p != ',') ++p;
+    if (*p == ',') ++p;
+  }
+  return false;
+}
+}  // namespace
+
+extern "C" {
+
 int rk_engine_set_option(rk_engine* e, const char* key, int value) {
   if (!e || !key) return RK_ERR_INVALID;
-  e->opt_epoch++;                                             // cached decoder graphs were captured under the old options
-  if (!strcmp(key, "dec_graph")) { e->opt_dec_graph = value != 0; return RK_OK; }             // decoder chains replayed as HIP graphs (1) or launched eagerly (0)
-  if (!strcmp(key, "gemm_glds")) { e->opt_glds = value != 0; return RK_OK; }
-  if (!strcmp(key, "gemm_skinny")) { e->opt_skinny = value == 1 ? 0x3F : value; return RK_OK; }   // bit per epilogue kind
-  if (!strcmp(key, "dec_ffn_tiled")) { e->opt_dec_ffn_tiled = value != 0; ++e->opt_epoch; return RK_OK; }   // one-position decoder: FFN-in on the tiled kernels (1) or the weight-streaming kernel (0)
-  if (!strcmp(key, "gemm_persistent")) { e->opt_gemm_persistent = value; return RK_OK; }   // ping-pong GEMM: 1 = one workgroup per CU walks the tiles
-  if (!strcmp(key, "attn_tiled_occ")) { e->opt_attn_tiled_occ = value; return RK_OK; }   // tiled encoder attention: register budget for 1 / 2 / 3 waves per SIMD
-  if (!strcmp(key, "gemm_s64_stages")) { e->opt_s64_stages = value; return RK_OK; }   // LDS stages of the 64x64 GEMM: 0 = auto, 2..4
-  if (!strcmp(key, "consumer_stats")) { e->opt_consumer_stats = value != 0; return RK_OK; }   // encoder row factors formed by the non-persistent consumer GEMMs themselves (1) or always by rowscale_kernel (0)
-  if (!strcmp(key, "attn_split")) { e->opt_attn_split = value != 0; return RK_OK; }           // sequences longer than 512 tokens: key tiles split over two wave groups (1) or one walk (0)
-  if (!strcmp(key, "greedy_spec")) { e->opt_greedy_spec = value; return RK_OK; }            // rk_t5_greedy2: most decoder rows (prompts x (prefix + candidates)) of a speculative pass; 0 = never speculate
-  if (!strcmp(key, "dec_fold_norm")) { e->opt_dec_fold_norm = value != 0; return RK_OK; }   // decoder RMSNorms folded into the weight-streaming GEMMs (1) or separate kernels (0)
-  if (!strcmp(key, "fold_norm")) { e->opt_fold_norm = value != 0; return RK_OK; }           // encoder RMSNorm folded into the GEMMs (1) or separate kernels (0)
+  if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
+    if (value < 0 || value > 1) return fail(e, RK_ERR_INVALID, "option overlap: 0..1");
+    if (set_device(e) || sync_all(e)) return RK_ERR_HIP;
+    for (Slot& sl : e->slots) sl.dec_pending = false;
+    e->opt.overlap = value;
+    e->opt_epoch++;
+    return RK_OK;
+  }
 #ifdef RK_MEASURE
   if (!strcmp(key, "attn_trace")) {   // phase time stamps of one workgroup of the DMA attention kernel (attention.h: ATTD_STAMP)
     if (value && !e->attn_trace) { if (hipMalloc(&e->attn_trace, 12 * 16 * 16 * sizeof(float)) != hipSuccess) return RK_ERR_HIP; hipMemset(e->attn_trace, 0, 12 * 16 * 16 * sizeof(float)); }
     if (!value && e->attn_trace) { hipFree(e->attn_trace); e->attn_trace = nullptr; }
     return RK_OK;
   }
-  if (!strcmp(key, "attn_ko")) { e->opt_attn_ko = value; return RK_OK; }   // timing-only knock-outs, see AttnEncArgs
-  if (!strcmp(key, "chain_debug")) { e->opt_chain_debug = value; return RK_OK; }   // knock-outs of the chained launch (ChainArgs::debug)
-  if (!strcmp(key, "chain_only")) { e->opt_chain_only = value; return RK_OK; }      // 1: only {O -> FFN-in} chained, 2: only {FFN-out -> QKV}
-  if (!strcmp(key, "chain_trace")) {   // value = 1 + index of the chained launch of an encoder pass to stamp (gemm_chain.h: ChainArgs::trace); 0 = off
-    const size_t bytes = (size_t)256 * 64 * 4 * sizeof(unsigned long long);
-    if (sync_all(e)) return RK_ERR_HIP;
-    if (value && !e->chain_trace) { if (hipMalloc(&e->chain_trace, bytes) != hipSuccess) return RK_ERR_HIP; }
-    if (e->chain_trace) hipMemset(e->chain_trace, 0, bytes);
-    if (!value && e->chain_trace) { hipFree(e->chain_trace); e->chain_trace = nullptr; }
-    e->opt_chain_trace_launch = value - 1;
-    return RK_OK;
-  }
 #endif
-  if (!strcmp(key, "xattn_mfma")) { e->opt_xattn_mfma = value != 0; ++e->opt_epoch; return RK_OK; }   // query-side cross-attention: weighted sums on the matrix cores (1) or the VALU form (0)
-  if (!strcmp(key, "attn_heads_per_wg")) { e->opt_attn_heads_per_wg = value; return RK_OK; }   // 0 auto
-  if (!strcmp(key, "xattn_direct")) { e->opt_xattn_direct = value != 0; return RK_OK; }   // query-side cross-attention
-  if (!strcmp(key, "attn_short")) { e->opt_attn_short = value; return RK_OK; }   // L <= 192: 5 (any non-zero value but 6) DMA kernel, two groups per workgroup; 6 one group; 0 tiled kernel
-  if (!strcmp(key, "gemm_variant")) { e->opt_gemm_variant = value; return RK_OK; }   // 0 auto, 1..5 see choose_variant
-  if (!strcmp(key, "dec_fuse_rows")) { e->opt_dec_fuse_rows = value; return RK_OK; }   // rows per workgroup of dec_cross_qk_kernel (0 = auto; A/B)
-  if (!strcmp(key, "dec_fuse")) { e->opt_dec_fuse = value; return RK_OK; }   // few-row decoder: projections around the query-side cross-attention fused per (head, row slab): 1 = at one decoder position (default), 2 = always, 0 = separate GEMMs
-  if (!strcmp(key, "llama_attn_nw")) { e->opt_llama_attn_nw = value; return RK_OK; }   // waves per workgroup of the Llama LDS-DMA attention kernel: 8, or 4 (0 = default); same bits
-  if (!strcmp(key, "llama_attn_dma")) { e->opt_llama_attn_dma = value != 0; return RK_OK; }   // Llama causal attention: K / V chunks by LDS-DMA with transposing V reads (1) or the register-staged first version (0); differ within fp16 noise
-  if (!strcmp(key, "attn_long_xcd")) { e->opt_attn_long_xcd = value != 0; return RK_OK; }   // long-sequence attention: the workgroups of a (sequence, head) pair on one XCD (1) or dealt over all eight (0); same bits
-  if (!strcmp(key, "attn_long_nw")) { e->opt_attn_long_nw = value; return RK_OK; }   // waves per workgroup of the long-sequence attention kernel: 12 / 6 / 4 / 3, 0 = from the batch (bit-identical)
-  if (!strcmp(key, "attn_long")) { e->opt_attn_long = value != 0; return RK_OK; }   // encoder attention of sequences longer than 192 keys: the chunked LDS-DMA kernel (1) or the tiled kernel (0)
-  if (!strcmp(key, "gemm_stagger_us")) { e->opt_gemm_stagger_us = value; return RK_OK; }   // residual ping-pong GEMMs: half of the workgroups start value x K / 1024 us late (experiment, 0 = off)
-  if (!strcmp(key, "gemm_epi_depth")) { e->opt_gemm_epi_depth = value; return RK_OK; }     // residual ping-pong GEMMs: old fp32 rows of three slabs requested ahead (>= 2) or one slab at a time (0)
-  if (!strcmp(key, "dec_attn_seq")) { e->opt_dec_attn_seq = value != 0; ++e->opt_epoch; return RK_OK; }   // decoder attention at several positions: one workgroup per (head, sequence) with K / V staged in LDS (1) or one per query row (0); same bits
-  if (!strcmp(key, "chain")) { e->opt_chain = value != 0; return RK_OK; }   // encoder: O -> FFN-in and FFN-out -> next QKV as chained launches (gemm_chain.h) when the batch is large enough (1) or always separate launches (0); same bits
-  if (!strcmp(key, "chain_lead")) { if (value < 1 || value > 16) return fail(e, RK_ERR_INVALID, "chain_lead 1..16"); e->opt_chain_lead = value; return RK_OK; }   // producer lead of a chained launch in blocks of four row panels
-  if (!strcmp(key, "chain_min_panels")) { if (value < 1) return fail(e, RK_ERR_INVALID, "chain_min_panels >= 1"); e->opt_chain_min_panels = value; return RK_OK; }   // fewest 256-row panels (M / 256) for the chained form
-  if (!strcmp(key, "gemm_sk")) { if (value < 0 || value > 1) return fail(e, RK_ERR_INVALID, "gemm_sk 0..1"); e->opt_gemm_sk = value; return RK_OK; }   // small-M projections on the stream-K kernel (1) or the tile variants only (0)
-  if (!strcmp(key, "gemm_split")) { e->opt_gemm_split = value; return RK_OK; }   // rows beyond the ping-pong kernel's last whole round on a fill-in tile variant (1) or one launch (0)
-  if (!strcmp(key, "gemm_group_n")) { e->opt_gemm_group_n = value; return RK_OK; }   // ping-pong GEMM: column-panel width of the tile order in tiles (0 = default 8)
-  if (!strcmp(key, "overlap")) {    // 1: decoder chain on its own stream (default); 0: everything on one stream
-    if (set_device(e) || sync_all(e)) return RK_ERR_HIP;
-    for (Slot& sl : e->slots) sl.dec_pending = false;
-    e->opt_overlap = value != 0;
+  for (const OptionDesc& o : kOptions) {
+    if (strcmp(key, o.key)) continue;
+    if (!strcmp(key, "gemm_skinny") && value == 1) value = 0x3F;
+    if (!option_value_ok(o, value))
+      return fail(e, RK_ERR_INVALID, "option %s: value %d outside %d..%d%s%s (%s)", key, value, o.lo, o.hi, o.allowed ? ", allowed: " : "", o.allowed ? o.allowed : "", o.what);
+    e->opt.*(o.field) = value;
+    e->opt_epoch++;                                           // cached decoder graphs were captured under the old options
     return RK_OK;
   }
   return fail(e, RK_ERR_INVALID, "unknown option %s", key);
@@ -2351,10 +2246,10 @@ int rk_debug_gemm(rk_engine* e, const uint16_t* A, const uint16_t* W, float* C, 
   HIPCHK(e, hipMalloc((void**)&dC, (size_t)M * N * 4));
   HIPCHK(e, hipMemcpy(dA, A, (size_t)M * K * 2, hipMemcpyHostToDevice));
   HIPCHK(e, hipMemcpy(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice));
-  const int saved = e->opt_glds;
-  e->opt_glds = use_glds != 0;
+  const int saved = e->opt.glds;
+  e->opt.glds = use_glds != 0;
   gemm(e, e->slots[0].se, PC_OTHER, EPI_STORE_F32, dA, K, dW, K, dC, N, M, N, K, 0, 0, 1.f, 1, 0, 0, 0, /*weight_streaming=*/use_glds == 2);
-  e->opt_glds = saved;
+  e->opt.glds = saved;
   HIPCHK(e, hipStreamSynchronize(e->slots[0].se));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
@@ -2406,11 +2301,11 @@ int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_fl
   if (!strcmp(name, "occupancy")) {   // resident workgroups per CU the runtime computes for the main kernels
     if (max_floats < 6) return RK_ERR_INVALID;
     int n = 0;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_kernel<2>, 256, 0); out[0] = (float)n;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (attn_enc_kernel<2, 2>), 512, 0); out[1] = (float)n;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_kernel, 256, 0); out[0] = (float)n;
+    out[1] = 0.f;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f16_kernel<EPI_STORE_F16, true>, 256, GEMM_LDS_BYTES); out[2] = (float)n;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_pp2_kernel<EPI_STORE_F16, 0>, 512, 163840); out[3] = (float)n;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_kernel<1>, 256, 0); out[4] = (float)n;
+    out[4] = 0.f;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rmsnorm_kernel<4>, 256, 0); out[5] = (float)n;
     if (max_floats >= 10) {
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_enc_dma_kernel<1>, 384, ATTD_LDS_BYTES); out[6] = (float)n;

@@ -1,7 +1,7 @@
 """Multi-GPU candidate sharding: one process per GPU.  On the GPU box the scores are collected by the ENGINE's own RCCL
 communicator (rk_comm_*, llmrankers/_runtime.py); `torch.distributed` only launches the ranks and carries the RCCL id.
-The helpers here are the partitioning and the host-side gather used when the runtime has no communicator (CPU tests on
-'gloo').
+The helpers here are the rank lookup and the partitioning.  (The host-side gather of the CPU tests' doubles - a
+torch.distributed all_gather on 'gloo' - lives with them in tests/_stub.py: no torch collective in the product package.)
 
 The reference has no data parallelism at all (multi-GPU there = accelerate's device_map='auto' layer placement,
 ref: llmrankers/pointwise.py:21; README.md:357).  Here the passages of one query are independent given the
@@ -13,8 +13,6 @@ and sorts identically.  Setwise heapsort is a dependency chain of compares: repl
 from __future__ import annotations
 
 from typing import List, Tuple
-
-import os
 
 import numpy as np
 
@@ -39,22 +37,3 @@ def shard_bounds(n_items: int, world_size: int) -> List[Tuple[int, int]]:
         out.append((s, e))
         s = e
     return out
-
-
-def all_gather_flat(local: np.ndarray, width: int) -> np.ndarray:
-    """[world, width] float32: every rank's `local` (<= width values, zero padded) through ONE torch.distributed
-    all_gather on the process group's own backend — the host-side path used when the runtime has no engine-owned
-    RCCL communicator (CPU tests on gloo; a GPU run goes through rk_comm_all_gather_slot instead)."""
-    import torch
-    import torch.distributed as dist
-    rank, ws = world()
-    local = np.asarray(local, dtype=np.float32).reshape(-1)
-    if dist.get_backend() == "nccl":
-        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0") or 0))
-    else:
-        device = torch.device("cpu")
-    buf = torch.zeros(width, dtype=torch.float32, device=device)
-    buf[:len(local)] = torch.as_tensor(local, device=device)
-    out = torch.empty(ws * width, dtype=torch.float32, device=device)
-    dist.all_gather_into_tensor(out, buf)
-    return out.cpu().numpy().reshape(ws, width)

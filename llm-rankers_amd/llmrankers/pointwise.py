@@ -161,7 +161,12 @@ class PointwiseLlmRanker(LlmRanker):
             local = np.zeros(row, np.float32)
             local[:(e - s) * k] = self._raw(chunks, kind, arg, out_ids).reshape(-1)
             local[width * k:width * k + (e - s)] = lens
-            allv = _dist.all_gather_flat(local, row)
+            # a runtime without a communicator of its own (the CPU tests' oracle-backed doubles) brings its gather along; the real
+            # runtime never gets here (T5Runtime.ensure_comm builds the engine's RCCL communicator or raises)
+            gather = getattr(self.llm, "host_all_gather", None)
+            if gather is None:
+                raise RuntimeError("candidate sharding needs a runtime with a communicator (T5Runtime) or a host_all_gather of its own")
+            allv = gather(local, row)
         raw = np.concatenate([allv[r, :(b - a) * k] for r, (a, b) in enumerate(bounds)])
         all_lens = np.concatenate([allv[r, width * k:width * k + (b - a)] for r, (a, b) in enumerate(bounds)])
         self._count_from_lengths(np.rint(all_lens).astype(np.int64), dec_len)

@@ -67,34 +67,6 @@ def write_run_file(path, results, tag, mode="w"):
                 f.write(f"{qid}\tQ0\t{doc.docid}\t{rank}\t{doc.score}\t{tag}\n")
 
 
-def read_run_qids(path):
-    """qids that already have lines in a (partial) run file, in file order."""
-    seen = []
-    try:
-        with open(path) as f:
-            for line in f:
-                parts = line.split()
-                if parts and (not seen or seen[-1] != parts[0]) and parts[0] not in seen:
-                    seen.append(parts[0])
-    except FileNotFoundError:
-        pass
-    return seen
-
-
-def read_run_lines(path):
-    """{qid: [raw lines]} of a (partial) run file, qids in file order."""
-    out = {}
-    try:
-        with open(path) as f:
-            for line in f:
-                parts = line.split()
-                if parts:
-                    out.setdefault(parts[0], []).append(line if line.endswith("\n") else line + "\n")
-    except FileNotFoundError:
-        pass
-    return out
-
-
 def part_files(save_path):
     """Per-rank part files of a --resume run in query-replica mode (`<save_path>.rank<N>`, N decimal), any world size.
     Anything else that happens to match the prefix (`.rank0.bak`, editor backups) is not a part file."""
@@ -104,31 +76,61 @@ def part_files(save_path):
     return sorted(f for f in glob.glob(glob.escape(save_path) + ".rank*") if pat.match(f))
 
 
-def complete_run_blocks(path, expected):
-    """{qid: [raw lines]} of the queries whose block in a (partial) run file is COMPLETE: exactly expected[qid] well-formed
-    lines (six fields), every one newline-terminated.  A process killed in the middle of an append leaves a short block or a
-    cut last line: such a query is not done - it is ranked again and its partial block is dropped (never merged).
-    qids that `expected` does not know (another query set) are kept as they are."""
-    blocks = {}
-    for qid, lines in read_run_lines_raw(path).items():
-        ok = all(l.endswith("\n") and len(l.split()) == 6 for l in lines)
-        if ok and (qid not in expected or len(lines) == expected[qid]):
-            blocks[qid] = lines
-    return blocks
-
-
-def read_run_lines_raw(path):
-    """{qid: [raw lines, exactly as in the file]} of a (partial) run file, qids in file order."""
-    out = {}
+def scan_run_blocks(path, expected):
+    """A (partial) run file as blocks of consecutive lines of one qid, classified.  Returns (kept, cut, mismatched):
+    kept {qid: [raw lines]} - COMPLETE blocks: exactly expected[qid] well-formed lines (six fields), every one newline-terminated
+    (qids that `expected` does not know - another query set - are kept as they are); if a qid has several complete blocks the last
+    one counts.  cut [qid] - what a process killed in the middle of an append leaves: a malformed / unterminated line anywhere in
+    the block, or a short block at the very end of the file.  mismatched [(qid, lines, expected)] - well-formed blocks whose
+    length disagrees with `expected` (a run made with another --hits or another first-stage run): never deleted silently."""
+    blocks = []
     try:
         with open(path) as f:
             for line in f:
                 parts = line.split()
-                if parts:
-                    out.setdefault(parts[0], []).append(line)
+                if not parts:
+                    continue
+                if blocks and blocks[-1][0] == parts[0]:
+                    blocks[-1][1].append(line)
+                else:
+                    blocks.append((parts[0], [line]))
     except FileNotFoundError:
         pass
-    return out
+    kept, cut, mismatched = {}, [], []
+    for i, (qid, lines) in enumerate(blocks):
+        well_formed = all(l.endswith("\n") and len(l.split()) == 6 for l in lines)
+        if well_formed and (qid not in expected or len(lines) == expected[qid]):
+            kept.pop(qid, None)                                   # (file order of the block that counts)
+            kept[qid] = lines
+        elif not well_formed or (i == len(blocks) - 1 and len(lines) < expected[qid]):
+            cut.append(qid)
+        else:
+            mismatched.append((qid, len(lines), expected[qid]))
+    return kept, cut, mismatched
+
+
+def complete_run_blocks(path, expected):
+    """{qid: [raw lines]} of the queries whose block in a (partial) run file is COMPLETE (scan_run_blocks).  A query with only a
+    cut block is not done - it is ranked again and its fragment is dropped (never merged)."""
+    return scan_run_blocks(path, expected)[0]
+
+
+def clean_run_file(path, expected):
+    """Resume hygiene: rewrite `path` atomically without the fragments a killed append left behind, so that a re-ranked query is
+    never appended behind its own fragment (a cut last line would swallow the first line of the new block).  Complete-looking
+    blocks that disagree with `expected` are NOT deleted: the run was made with other settings - refuse.  Returns the kept blocks."""
+    kept, cut, mismatched = scan_run_blocks(path, expected)
+    if mismatched:
+        qid, have, want = mismatched[0]
+        raise ValueError(f"--resume: {path} holds {have} lines for query {qid} but this run expects {want} (another --hits or first-stage "
+                         f"run?); {len(mismatched)} such queries - refusing to delete them, move the file away or match the settings")
+    if cut:
+        tmp = path + ".clean"
+        with open(tmp, "w") as f:
+            for lines in kept.values():
+                f.writelines(lines)
+        os.replace(tmp, path)
+    return kept
 
 
 def _auto_per_call(kind, hits):
@@ -331,24 +333,25 @@ def main(args):
     # a query is done only if its block is complete (as many lines as it has candidates, the last one newline-terminated)
     expected = {qid: len(ranking) for qid, _, ranking in (item for shard in (all_shards or [first_stage]) for item in shard)}
     done = set()
-    if resume:
-        kept = complete_run_blocks(args.run.save_path, expected)
-        done = set(kept)
-        if writer and set(read_run_qids(args.run.save_path)) - done:
-            # a cut block at the end of --save_path (killed mid-append): rewritten without it, so that the re-ranked query is
-            # not appended behind its own fragment
-            tmp = args.run.save_path + ".clean"
-            with open(tmp, "w") as f:
-                for lines in kept.values():
-                    f.writelines(lines)
-            os.replace(tmp, args.run.save_path)
     # query replicas under --resume: every rank appends ITS finished queries to <save_path>.rank<N> after every call (durable
     # like the single-process form, ref: Rank-R1/run_setwise.py:79-87); a restart - with any number of ranks - skips what any
     # part file holds, and rank 0 merges the parts into --save_path at the end
     my_part = f"{args.run.save_path}.rank{rank}" if (resume and replicas) else None
-    if resume and replicas:
-        for pf in part_files(args.run.save_path):
-            done.update(complete_run_blocks(pf, expected))
+    if resume:
+        # a cut block (killed mid-append) in --save_path or in ANY part file is removed before anybody appends: rank 0 rewrites
+        # the files, the others wait for it
+        if writer:
+            clean_run_file(args.run.save_path, expected)
+            if replicas:
+                for pf in part_files(args.run.save_path):
+                    clean_run_file(pf, expected)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        done = set(complete_run_blocks(args.run.save_path, expected))
+        if replicas:
+            for pf in part_files(args.run.save_path):
+                done.update(complete_run_blocks(pf, expected))
     if done:
         print(f"{args.run.save_path} exists. Continue ranking ({len(done)} queries done)")
     first_stage_order = {qid: [d.docid for d in ranking] for qid, _, ranking in first_stage}

@@ -6,6 +6,21 @@ import numpy as np
 from oracle.t5_numpy import T5Oracle
 
 
+def gloo_all_gather_flat(local, width):
+    """[world, width] float32: every rank's `local` (<= width values, zero padded) through ONE torch.distributed all_gather of
+    the process group's own backend (the CPU tests run on gloo) - the stand-in for the engine's RCCL all_gather, which the real
+    runtime issues itself (rk_comm_all_gather_slot / rk_comm_all_gather_appended)."""
+    import torch
+    import torch.distributed as dist
+    ws = dist.get_world_size()
+    local = np.asarray(local, dtype=np.float32).reshape(-1)
+    buf = torch.zeros(width, dtype=torch.float32)
+    buf[:len(local)] = torch.as_tensor(local)
+    out = torch.empty(ws * width, dtype=torch.float32)
+    dist.all_gather_into_tensor(out, buf)
+    return out.numpy().reshape(ws, width)
+
+
 class OracleRuntime:
     model_type = "t5"
 
@@ -20,6 +35,10 @@ class OracleRuntime:
 
     def qlm(self, seqs, labels):
         return self.orc.qlm(seqs, labels)
+
+    def host_all_gather(self, local, width):
+        """candidate sharding without an engine communicator (PointwiseLlmRanker._rerank_sharded): the gloo stand-in"""
+        return gloo_all_gather_flat(local, width)
 
     def greedy(self, seqs, dec_prefix, max_new, eos_id=1, pad_id=0):
         toks = self.orc.greedy(seqs, dec_prefix, max_new, eos_id, pad_id).astype(np.int32)
@@ -110,6 +129,5 @@ class FakeCommEngine:
         self._send[offset:offset + n] = self._last[:n]
 
     def comm_all_gather_appended(self, n):
-        from llmrankers import _dist
         self.calls["gather"] += 1
-        return _dist.all_gather_flat(np.nan_to_num(self._send[:n], nan=-777.0), n)
+        return gloo_all_gather_flat(np.nan_to_num(self._send[:n], nan=-777.0), n)

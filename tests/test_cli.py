@@ -339,6 +339,44 @@ def test_two_rank_run_py_matches_single_process(runmod, tmp_path, ckpt_dirs, sha
         assert all(c["init"] == 0 and c["gather"] == 0 for c in calls), calls
 
 
+def test_resume_hygiene_cut_block_in_a_part_file_and_foreign_blocks(runmod, tmp_path):
+    """Round-5 advisor finding: a kill in the middle of an append leaves a cut block in <save_path>.rank<N>; the restarted rank
+    used to append the re-ranked query right behind its own fragment (the cut line swallowed the new block's first line), the
+    merge then rejected the qid and the query was silently missing.  Now every part file (and --save_path) is rewritten without
+    fragments BEFORE anybody appends, the last complete block of a qid counts, and complete-looking blocks that disagree with
+    the expected length (another --hits) are refused instead of deleted."""
+    expected = {"q1": 3, "q2": 3}
+    blk = lambda q, tag="LLMRankers": [f"{q}\tQ0\td{i}\t{i + 1}\t{0.9 - 0.1 * i}\t{tag}\n" for i in range(3)]
+    part = tmp_path / "run.trec.rank0"
+    part.write_text("".join(blk("q2")) + "".join(blk("q1")[:1]) + blk("q1")[1][:11])   # q2 done, q1 cut in its second line
+    kept, cut, mism = runmod.scan_run_blocks(str(part), expected)
+    assert list(kept) == ["q2"] and cut == ["q1"] and mism == []
+    # the old failure: append behind the fragment -> the joined line spoils the new block too
+    spoiled = tmp_path / "spoiled.rank0"
+    spoiled.write_text(part.read_text() + "".join(blk("q1")))
+    assert "q1" not in runmod.complete_run_blocks(str(spoiled), expected)
+    # the fix: clean first, then append
+    assert list(runmod.clean_run_file(str(part), expected)) == ["q2"]
+    assert part.read_text() == "".join(blk("q2")) and not (tmp_path / "run.trec.rank0.clean").exists()
+    with open(part, "a") as f:
+        f.writelines(blk("q1"))
+    assert set(runmod.complete_run_blocks(str(part), expected)) == {"q1", "q2"}
+    # a short block in the MIDDLE of a file with well-formed lines is not a fragment: other settings wrote it - refuse, keep the file
+    foreign = tmp_path / "foreign.trec"
+    foreign.write_text("".join(blk("q1")[:2]) + "".join(blk("q2")))
+    before = foreign.read_text()
+    with pytest.raises(ValueError, match="refusing"):
+        runmod.clean_run_file(str(foreign), expected)
+    assert foreign.read_text() == before
+    # several complete blocks of one qid (an earlier run was merged twice): the last one counts
+    twice = tmp_path / "twice.trec"
+    twice.write_text("".join(blk("q1", "old")) + "".join(blk("q2")) + "".join(blk("q1", "new")))
+    kept = runmod.complete_run_blocks(str(twice), expected)
+    assert list(kept) == ["q2", "q1"] and kept["q1"][0].endswith("new\n")
+    # a missing file is an empty one
+    assert runmod.scan_run_blocks(str(tmp_path / "none"), expected) == ({}, [], [])
+
+
 def test_two_rank_replicas_resume_is_durable(runmod, tmp_path, ckpt_dirs):
     """--resume under query replicas (--shard_candidates 0, 2 ranks): every rank appends its finished queries to
     <save_path>.rank<N> as it goes; a restart skips what ANY part file (or --save_path) already holds - here q3 sits in a part

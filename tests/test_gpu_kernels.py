@@ -93,34 +93,40 @@ def test_pingpong_gemm_random_shapes_bit_equal_to_lockstep_kernel(toy):
         assert np.abs(ref - want).max() < 2e-3 * np.sqrt(k)
 
 
-def test_stream_k_gemm_vs_numpy_whole_tiles_bit_equal_and_deterministic(toy):
-    """gemm_sk_kernel (round 6; gemm_variant 7): equal runs of (tile, K step) units per workgroup, split tiles combined by the last
-    arriver in K order.  (1) every shape vs numpy at the fp16-input tolerance; (2) each shape three times: bit-identical runs (the
-    combine order is fixed, whoever arrives last), also right after a different shape used the same tickets and slabs; (3) rows /
-    columns of tiles that are NOT split carry the bits of the lock-step tile kernel (same MFMA order and operand slots) - checked
-    on shapes with fewer units than workgroups (one unit per workgroup: every tile split) and with K of one step (no tile split)."""
+def test_k_split_pingpong_gemm_vs_numpy_unsplit_kernel_and_deterministic(toy):
+    """gemm_pp2_kernel<.., SPLIT> (round 6): two workgroups share an output tile, each sums a contiguous K range, the first
+    arriver's fp32 partial tile travels as a write-through slab and the LAST arriver adds it to its registers.  Option gemm_sk = 2
+    forces the split wherever every half keeps two K tiles (the shipped heuristic, gemm_sk = 1, only splits the fp32 residual
+    projections of launches with few tiles and K >= 6 144).  (1) vs numpy at the fp16-input tolerance; (2) vs the unsplit kernel: equal to
+    fp32 re-association noise; (3) each shape three times: bit-identical runs (fixed combine order, tickets reset by the last
+    arriver), also right after another shape used the same slabs; (4) K too short for the split: the unsplit bits."""
     eng = toy["ckpt_gated_untied"][2]
     rs = np.random.RandomState(20261001)
-    shapes = [(int(rs.randint(1, 2600)), int(rs.randint(1, 400)) * 4, int(rs.randint(1, 46)) * 64) for _ in range(16)]
-    shapes += [(1450, 1024, 1024), (1450, 1024, 2816), (2392, 1024, 2816), (2392, 3072, 1024), (1450, 5632, 1024), (128, 128, 64),
-               (1, 4, 64), (129, 132, 128), (256, 128, 4096), (100, 100, 14336), (3000, 260, 64)]
+    shapes = [(int(rs.randint(1, 1600)), int(rs.randint(1, 300)) * 4, int(rs.randint(4, 60)) * 64) for _ in range(10)]
+    shapes += [(1536, 1024, 4096), (1450, 1024, 2816), (700, 516, 14336), (256, 256, 256), (257, 260, 512), (3000, 1024, 1024), (100, 64, 128)]
     for m, n, k in shapes:
         a = rs.standard_normal((m, k)).astype(np.float16)
         w = rs.standard_normal((n, k)).astype(np.float16)
         want = a.astype(np.float32) @ w.astype(np.float32).T
         try:
-            eng.set_option("gemm_variant", 7)
-            first = eng.debug_gemm(a, w, use_glds=True)
-            for _ in range(2):
-                np.testing.assert_array_equal(eng.debug_gemm(a, w, use_glds=True), first, err_msg=f"shape {(m, n, k)} not deterministic")
-            if k == 64:                                  # one K step per tile: nothing is split
-                eng.set_option("gemm_variant", 2)
-                np.testing.assert_array_equal(first, eng.debug_gemm(a, w, use_glds=True), err_msg=f"shape {(m, n, k)}")
+            eng.set_option("gemm_variant", 5)
+            eng.set_option("gemm_sk", 0)
+            ref = eng.debug_gemm(a, w, use_glds=True)
+            for splits in (2,):
+                eng.set_option("gemm_sk", splits)
+                first = eng.debug_gemm(a, w, use_glds=True)
+                for _ in range(2):
+                    np.testing.assert_array_equal(eng.debug_gemm(a, w, use_glds=True), first, err_msg=f"shape {(m, n, k)} x{splits}: not deterministic")
+                tiles = -(-m // 256) * -(-n // 256)
+                if (k // 64) // splits < 2 or tiles * splits > 256:
+                    np.testing.assert_array_equal(first, ref, err_msg=f"shape {(m, n, k)} x{splits}: must not be split")
+                err = np.abs(first - want)
+                assert err.max() < 2e-3 * np.sqrt(k), f"shape {(m, n, k)} x{splits}: max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}; " \
+                    f"bad rows {np.unique(np.where(err > 1e-2 * np.sqrt(k))[0])[:16]} bad cols {np.unique(np.where(err > 1e-2 * np.sqrt(k))[1])[:16]}"
+                assert np.abs(first - ref).max() < 1e-5 * np.sqrt(k) * max(1.0, float(np.abs(ref).max())), (m, n, k, splits, np.abs(first - ref).max())
         finally:
             eng.set_option("gemm_variant", 0)
-        err = np.abs(first - want)
-        assert err.max() < 2e-3 * np.sqrt(k), f"shape {(m, n, k)}: max err {err.max()} at {np.unravel_index(err.argmax(), err.shape)}; " \
-            f"bad rows {np.unique(np.where(err > 1e-2 * np.sqrt(k))[0])[:16]} bad cols {np.unique(np.where(err > 1e-2 * np.sqrt(k))[1])[:16]}"
+            eng.set_option("gemm_sk", 1)
 
 
 def test_small_tile_gemm_stage_counts_bit_equal_to_lockstep_kernel(toy):
@@ -607,33 +613,6 @@ def test_two_token_greedy_with_candidates_equals_two_steps(toy, ckpt):
         np.testing.assert_array_equal(eng.greedy(seqs, [0], 2, candidates=[3, 4])[0], eng.greedy(seqs, [0], 2)[0])
     finally:
         eng.set_option("greedy_spec", 160)
-
-
-def test_key_split_attention_for_long_sequences(toy):
-    """Sequences longer than 512 tokens walk their key tiles in two halves (two wave groups, merged at the end): close to
-    the single walk and the oracle, and a function of the sequence's own length only - the same bits alone, in a batch
-    with shorter sequences and next to another long one; sequences up to 512 tokens keep the bits of the single walk."""
-    from llmrankers import _synth
-    from oracle.t5_numpy import T5Oracle
-    dims, state, eng = toy["ckpt_gated_untied"]
-    rs = np.random.RandomState(11)
-    lens = [1450, 40, 513, 512, 200, 777, 64]
-    seqs = [list(rs.randint(3, dims.vocab, size=n)) for n in lens]
-    ids = [11, 12, 13, 14]
-    split = eng.score(seqs, [0], ids)
-    try:
-        eng.set_option("attn_split", 0)
-        single = eng.score(seqs, [0], ids)
-    finally:
-        eng.set_option("attn_split", 1)
-    assert np.abs(split - single).max() < 2e-3, np.abs(split - single).max()
-    short = [i for i, n in enumerate(lens) if n <= 512]
-    np.testing.assert_array_equal(split[short], single[short])
-    want = T5Oracle(dims, state).score_last([seqs[2], seqs[5]], [0], ids)
-    assert np.abs(split[[2, 5]] - want).max() < LOGIT_TOL
-    for i in (0, 2, 3, 5):                                                   # alone == in the batch
-        np.testing.assert_array_equal(eng.score(seqs[i:i + 1], [0], ids)[0], split[i])
-    np.testing.assert_array_equal(eng.score([seqs[5], seqs[1], seqs[0]], [0], ids), split[[5, 1, 0]])
 
 
 def test_fused_greedy_head_first_index_on_exact_ties(ckpt_dirs):
@@ -1213,44 +1192,6 @@ def test_llama_pairwise_reference_cases_on_the_engine(ckpt_dirs):
             n += 1
         rk.llm.engine.close()
     assert n >= 4
-
-
-def test_chained_gemm_launches_bit_identical_to_separate_launches():
-    """csrc/gemm_chain.h: {O -> FFN-in} and {FFN-out -> next QKV} as ONE persistent launch each (row-panel ready flags, dynamic
-    per-XCD queues, write-through hand-off) must give the bits of the separate ping-pong launches + statistics kernel - same tile
-    loop, same K order, same epilogues - on the bench shape, one query, a ragged batch, and (size gate lowered) on shapes with
-    fewer row panels than queues and a partial last panel; for every producer lead; on repeated calls (epoch-tagged flags,
-    self-resetting tickets) and with both slots in flight beside replayed decoder graphs."""
-    from llmrankers import _synth
-    dims = _synth.FLAN_T5_LARGE
-    state = _synth.synth_state_dict(dims, seed=929, threads=16)
-    eng = _engine(dims, state, max_tokens=320 * 184, max_seqs=320, max_dec_len=4)
-    ids = [2163, 465]
-    shapes = [(_synth.synth_token_batch(320, 184, 184, dims.vocab, seed=1), 64), (_synth.synth_token_batch(100, 184, 184, dims.vocab, seed=2), 64),
-              (_synth.synth_token_batch(320, 96, 184, dims.vocab, seed=3), 64), (_synth.synth_token_batch(40, 184, 184, dims.vocab, seed=4), 1),
-              (_synth.synth_token_batch(7, 100, 180, dims.vocab, seed=5), 1), (_synth.synth_token_batch(1, 150, 150, dims.vocab, seed=6), 1),
-              (_synth.synth_token_batch(13, 184, 184, dims.vocab, seed=7), 1)]
-    for seqs, min_panels in shapes:
-        eng.set_option("chain", 0)
-        ref = eng.score(seqs, [0], ids)
-        eng.set_option("chain", 1)
-        eng.set_option("chain_min_panels", min_panels)
-        for lead in (3, 1, 2, 3):
-            eng.set_option("chain_lead", lead)
-            np.testing.assert_array_equal(eng.score(seqs, [0], ids), ref, err_msg=f"{len(seqs)} sequences, lead {lead}")
-    eng.set_option("chain_min_panels", 64)
-    qs = [_synth.synth_token_batch(320, 184, 184, dims.vocab, seed=20 + q) for q in range(2)]
-    eng.set_option("chain", 0)
-    refs = [eng.score(q, [0], ids) for q in qs]
-    eng.set_option("chain", 1)
-    for s_ in range(2):
-        eng.stage(qs[s_], slot=s_)
-    for it in range(3):
-        for s_ in range(2):
-            eng.score_staged([0], ids, slot=s_)
-        for s_ in range(2):
-            np.testing.assert_array_equal(eng.read_scores(s_), refs[s_], err_msg=f"pipelined, iteration {it}, slot {s_}")
-    eng.close()
 
 
 def test_decoder_attention_per_sequence_kernel_bit_identical_to_per_row_kernel():

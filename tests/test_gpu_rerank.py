@@ -213,37 +213,40 @@ def test_config3_full_size_setwise_query_flan_t5_large():
     eng = RkEngine(dims, 0, max_tokens=32768, max_seqs=16, max_dec_len=8).load_state(state.items())
     rt = T5Runtime.from_engine(eng, dims)
     tok = T5Tokenizer.from_pretrained(os.path.join(GOLD, "tok"))
-    text = {d: t for d, t in gold["docs"]}
     floor = gold["floor"]
     for scoring in ("likelihood", "generation"):
         run = gold["runs"][scoring]
+        # a run may carry a corpus of its own (tools/make_setwise_large_golden.py --generation-only: the generation margins are
+        # top-2 gaps over the FULL vocabulary, so a corpus that is decisive for likelihood need not be for generation)
+        query, docs = run.get("query", gold["query"]), run.get("docs", gold["docs"])
+        text = {d: t for d, t in docs}
+        # no dead branch on the committed fixture: BOTH scorings are asserted in full below (round-5 review, weak #1a)
+        assert run["min_margin"] > floor, (scoring, run["min_margin"])
         rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=gold["num_child"], k=gold["k"], scoring=scoring, method="heapsort")
         worst, decided = 0.0, 0
         for docids, out, rec in run["compares"]:
             window = [SearchResult(docid=d, score=0.0, text=text[d]) for d in docids]
             with contextlib.redirect_stdout(io.StringIO()):
-                got = rk.compare(gold["query"], window)
+                got = rk.compare(query, window)
             if scoring == "likelihood":
-                prompt = tokenize_ids(rk, gold["query"], window)
+                prompt = tokenize_ids(rk, query, window)
                 lg = rt.score([prompt], rk.decoder_input_ids, rk.target_token_ids[:len(window)])[0]
                 worst = max(worst, float(np.abs(lg - np.array(rec["logits"])).max()))
             if rec["margin"] > floor:
                 decided += 1
                 assert got == out, (scoring, docids, got, out, rec["margin"])
-        assert decided >= 0.8 * len(run["compares"]), (scoring, decided)
+        assert decided == len(run["compares"]), (scoring, decided)
         if scoring == "likelihood":
             assert worst < floor / 2, worst        # label logits (lm_head rows boosted x6) vs the fp32 oracle
         # the whole query through the shipped driver (build phase level-batched)
         rk = SetwiseLlmRanker.from_runtime(rt, tok, num_child=gold["num_child"], k=gold["k"], scoring=scoring, method="heapsort")
         assert rk._batched_ok()
-        ranking = [SearchResult(docid=d, score=float(100 - i), text=t) for i, (d, t) in enumerate(gold["docs"])]
+        ranking = [SearchResult(docid=d, score=float(100 - i), text=t) for i, (d, t) in enumerate(docs)]
         with contextlib.redirect_stdout(io.StringIO()):
-            res = rk.rerank(gold["query"], ranking)
-        assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens][:2] == run["counters"][:2], scoring
-        if run["min_margin"] > floor:
-            assert [[r.docid, r.score] for r in res] == run["result"], scoring
-            assert [r.docid for r in ranking] == run["caller_list_after"], scoring
-            assert rk.total_completion_tokens == run["counters"][2]
+            res = rk.rerank(query, ranking)
+        assert [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens] == run["counters"], scoring
+        assert [[r.docid, r.score] for r in res] == run["result"], scoring
+        assert [r.docid for r in ranking] == run["caller_list_after"], scoring
     eng.close()
 
 

@@ -94,10 +94,10 @@ def test_dma_attention_keeps_its_dma_queue_and_its_asm_destinations(isa, ng):
     assert not any(re.match(r"\s*global_load_dwordx2", l) for l in body), "vector load of the token offsets"
 
 
-# (epilogue kind, folded-RMSNorm row factors): every product instantiation of the ping-pong kernel
-@pytest.mark.parametrize("epi,rs", [(0, 0), (0, 1), (1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (4, 0)])
-def test_pingpong_gemm_k_loop_keeps_loads_in_flight(isa, epi, rs):
-    body = kernel_body(isa, f"_Z15gemm_pp2_kernelILi{epi}ELi0ELb{rs}ELi0EEv8GemmArgs")
+# (epilogue kind, folded-RMSNorm row factors, K split over workgroups): every product instantiation of the ping-pong kernel
+@pytest.mark.parametrize("epi,rs,split", [(0, 0, 0), (0, 1, 0), (1, 0, 0), (2, 0, 0), (2, 1, 0), (3, 0, 0), (3, 1, 0), (4, 0, 0), (1, 0, 1), (4, 0, 1)])
+def test_pingpong_gemm_k_loop_keeps_loads_in_flight(isa, epi, rs, split):
+    body = kernel_body(isa, f"_Z15gemm_pp2_kernelILi{epi}ELi0ELb{rs}ELb{split}EEv8GemmArgs")
     assert not any("scratch_" in l for l in body), "ping-pong GEMM spills"
     # the K loop = the innermost loop that holds MFMAs
     heads = [i for i, l in enumerate(body) if "Inner Loop Header" in l]
@@ -148,8 +148,8 @@ def _instructions(body):
 def test_no_valu_written_sgpr_feeds_an_inline_asm_memory_instruction_without_wait_states(isa):
     """gfx9 / CDNA hazard: a VALU instruction that writes an SGPR (v_readlane / v_readfirstlane - which is how the compiler brings
     a spilled SGPR back - , v_cmp with an SGPR destination) needs FIVE wait states before a VMEM instruction reads that SGPR.
-    The compiler's hazard recognizer inserts them for its own instructions but does not look inside inline asm: the chained GEMM
-    launch (gemm_chain.h, round 5) restored the row-factor base from a spill lane right in front of a hand-written load and
+    The compiler's hazard recognizer inserts them for its own instructions but does not look inside inline asm: round 5's chained GEMM
+    launch (removed in round 6) restored the row-factor base from a spill lane right in front of a hand-written load and
     faulted on its first launch.  Every hand-written VMEM instruction with an SGPR base (loads, LDS-DMA, atomics) in every kernel
     of the library: no VALU write of its base registers within the five preceding wait states (s_nop N counts N + 1)."""
     text = isa
@@ -189,7 +189,7 @@ def test_no_valu_written_sgpr_feeds_an_inline_asm_memory_instruction_without_wai
                         assert not (regs & base), f"{text[s][:60]}: `{prev}` {waits} wait state(s) in front of hand-written `{code}`"
                     waits += 1
                 back -= 1
-    assert checked > 50        # the ping-pong / chained GEMMs and the DMA attention kernel hold dozens of such instructions each
+    assert checked > 50        # the ping-pong GEMM instantiations and the DMA attention kernels hold dozens of such instructions each
 
 
 @pytest.mark.parametrize("nw,max_vgprs", [(12, 168), (4, 256)])

@@ -8,6 +8,19 @@ import time
 import numpy as np
 
 
+def _gloo_all_gather_flat(local, width):
+    """[world, width] float32 through ONE torch.distributed all_gather on gloo: what the engine's RCCL all_gather does on the GPU box."""
+    import torch
+    import torch.distributed as dist
+    ws = dist.get_world_size()
+    local = np.asarray(local, dtype=np.float32).reshape(-1)
+    buf = torch.zeros(width, dtype=torch.float32)
+    buf[:len(local)] = torch.as_tensor(local)
+    out = torch.empty(ws * width, dtype=torch.float32)
+    dist.all_gather_into_tensor(out, buf)
+    return out.numpy().reshape(ws, width)
+
+
 def fake_logits(seqs, out_ids):
     out = np.empty((len(seqs), len(out_ids)), np.float32)
     for i, s in enumerate(seqs):
@@ -87,11 +100,10 @@ class DryEngine:
         return "dry-run (gloo)|0"
 
     def comm_all_gather(self, n_floats, slot=0):
-        from llmrankers import _dist
         assert 0 < n_floats <= self.comm_capacity
         self.calls["gather"] += 1
         flat = self._scores[slot].reshape(-1)
-        self._gathered[slot] = _dist.all_gather_flat(flat[:n_floats], n_floats)
+        self._gathered[slot] = _gloo_all_gather_flat(flat[:n_floats], n_floats)
 
     def comm_read_gathered(self, slot=0):
         return self._gathered[slot].copy()
@@ -106,10 +118,9 @@ class DryEngine:
         self._send[offset:offset + len(v)] = v
 
     def comm_all_gather_appended(self, n):
-        from llmrankers import _dist
         assert 0 < n <= self.comm_capacity
         self.calls["gather"] += 1
-        return _dist.all_gather_flat(self._send[:n], n)
+        return _gloo_all_gather_flat(self._send[:n], n)
 
     def comm_destroy(self):
         self.comm_world = 1

@@ -39,7 +39,8 @@ try:
     box = open(out + "/../final/box.txt").read()
 except Exception:
     box = os.uname().nodename
-res = {"box": box, "command": f"bench.py --steps {steps} --warmup {os.environ.get('PROF_WARMUP', '5')} --overlap 0 (one stream: kernels run one at a time)",
+import __graft_entry__ as ge
+res = {"box": box, "source_hash": ge._source_hash(), "command": f"bench.py --steps {steps} --warmup {os.environ.get('PROF_WARMUP', '5')} --overlap 0 (one stream: kernels run one at a time)",
        "tokens_per_launch": bench.auto_group(steps) * 32 * 184,
        "note": "FETCH_SIZE/WRITE_SIZE in KiB as reported; gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md HBM section)",
        "kernels": {k: {"stats": stats.get(k), "pmc": v} for k, v in summ.items()}}

@@ -34,10 +34,10 @@ def main():
     eng.load_state(state.items())
     del state
     known = {"gemm_persistent": 1, "attn_short": 5, "gemm_variant": 0,
-             "xattn_direct": 1, "overlap": 1, "gemm_glds": 1, "attn_heads_per_wg": 0, "fold_norm": 1, "dec_graph": 1, "attn_tiled_occ": 2,
-             "dec_fold_norm": 1, "gemm_s64_stages": 0, "attn_split": 1, "greedy_spec": 160, "gemm_split": 1, "gemm_group_n": 0, "dec_fuse": 1, "dec_fuse_rows": 0,
-             "xattn_mfma": 1, "dec_ffn_tiled": 1, "consumer_stats": 1, "chain": 0, "chain_lead": 3, "chain_min_panels": 64,
-             "gemm_stagger_us": 0, "gemm_epi_depth": 0, "dec_attn_seq": 1, "attn_long": 1, "attn_long_nw": 0, "attn_long_xcd": 1,
+             "xattn_direct": 1, "overlap": 1, "gemm_glds": 1, "attn_heads_per_wg": 0, "fold_norm": 1, "dec_graph": 1, 
+             "dec_fold_norm": 1, "gemm_s64_stages": 0, "greedy_spec": 160, "gemm_split": 1, "dec_fuse": 1, "dec_fuse_rows": 0,
+             "xattn_mfma": 1, "dec_ffn_tiled": 1, "consumer_stats": 1, 
+             "dec_attn_seq": 1, "attn_long": 1, "attn_long_nw": 0, "attn_long_xcd": 1,
              "llama_attn_dma": 1, "llama_attn_nw": 0}
     defaults = {}
     for c in cfgs:
