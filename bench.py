@@ -255,22 +255,27 @@ def llama_leg():
     return _tool("bench_llama").run(layers=32, L=1536, pool=True, iters=5, profile=True)
 
 
-def shard_share_leg(eng, dims, L, hits=100, world=8, steps=40):
+def shard_share_leg(eng, dims, L, hits=100, world=8, steps=40, queries_per_step=1):
     """What ONE of `world` ranks does per query in --mode shard (strong scaling): its 13-passage share of a hits=100 query per
     step through the two slots, no collective (one rank).  100 / (ms per step) is the 1-GPU prediction of the 8-GPU
-    strong-scaling number (the gather adds one ~20 us collective per query)."""
+    strong-scaling number (the gather adds one ~20 us collective per query).  queries_per_step = 16: what run.py does by default
+    under --shard_candidates 1 since round 6 (PointwiseLlmRanker.rerank_many -> _rerank_sharded_many: every rank's share of
+    sixteen queries in ONE launch sequence, one gather for all of them) - 208 passages per rank and step instead of 13."""
     from llmrankers import _synth
     from llmrankers._dist import shard_bounds
     lo, hi = shard_bounds(hits, world)[0]
     n_slots = eng.num_slots
-    queries = [_synth.synth_token_batch(hits, L, L, dims.vocab, seed=4000 + q) for q in range(n_slots)]
-    pipe = ShardPipeline(eng, [q[lo:hi] for q in queries], [0], [YES_ID, NO_ID], 1, hi - lo)
+    nq = queries_per_step
+    queries = [[_synth.synth_token_batch(hits, L, L, dims.vocab, seed=4000 + q * nq + j) for j in range(nq)] for q in range(n_slots)]
+    pipe = ShardPipeline(eng, [[s for qq in qs for s in qq[lo:hi]] for qs in queries], [0], [YES_ID, NO_ID], 1, (hi - lo) * nq)
     pipe.stage_all()
     elapsed, _ = timed_run(eng, pipe, steps, 8, eng.sync)
-    ms = elapsed / steps * 1e3
+    ms = elapsed / steps * 1e3 / nq                              # per query
     gfl = algorithmic_gflop_per_passage(dims, L) * (hi - lo)
-    return {"workload": f"one rank's share of ONE query per step: {hi - lo} of hits={hits} candidates (world = {world}), L_e={L}, {steps} steps",
-            "ms_per_step": round(ms, 3), "share_passages_per_s": round((hi - lo) / ms * 1e3, 1),
+    what = "ONE query" if nq == 1 else f"{nq} queries (one launch sequence, one gather)"
+    return {"workload": f"one rank's share of {what} per step: {hi - lo} of hits={hits} candidates each (world = {world}), L_e={L}, {steps} steps",
+            "queries_per_step": nq, "ms_per_query": round(ms, 3), "ms_per_step": round(ms * nq, 3),
+            "share_passages_per_s": round((hi - lo) / ms * 1e3, 1),
             "predicted_8gpu_strong_scaling_passages_per_s": round(hits / ms * 1e3, 1),
             "frac_of_mfma_peak_per_gpu": round(gfl / ms / MFMA_PEAK_TFLOPS, 4)}
 
@@ -577,6 +582,7 @@ def main():
 
         try:
             extras["shard_share"] = shard_share_leg(eng, dims, L, args.hits)
+            extras["shard_share"]["grouped16"] = shard_share_leg(eng, dims, L, args.hits, steps=10, queries_per_step=16)
         except Exception as exc:
             extras["shard_share"] = {"error": repr(exc)[:300]}
 
@@ -617,6 +623,21 @@ def main():
         passages = args.steps * (args.hits if shard else B * world)
         gfl = algorithmic_gflop_per_passage(dims, L)
         value = passages / elapsed
+        # What the first real 8-GPU lease should show, predicted from THIS 1-GPU run (no curve is claimed: SCALE records have been
+        # skipped for want of an 8-GPU node): --mode weak = 8 replicas of this pipeline, each adding ONE engine-issued all_gather of
+        # its launch sequence's scores (G * B * 2 floats per rank; latency-bound, ASSUMED 25 us - the N > 1 collective never ran on
+        # hardware); --mode shard = one query per step, every rank scoring its 12-13 passage share (config.shard_share).
+        predicted_8gpu = None
+        if world == 1 and not shard and not dry:
+            GATHER_US = 25.0
+            seq_ms = elapsed / args.steps * 1e3 * G
+            predicted_8gpu = {"weak_passages_per_s": round(8 * value * seq_ms / (seq_ms + GATHER_US * 1e-3), 1),
+                              "weak_basis": f"8 x this line's value, one assumed {GATHER_US:.0f}-us all_gather per {seq_ms:.1f}-ms launch sequence and rank",
+                              "shard_passages_per_s": (extras.get("shard_share") or {}).get("predicted_8gpu_strong_scaling_passages_per_s"),
+                              "shard_basis": "hits / (ms per 13-passage share on one GPU), config.shard_share; + one gather per query",
+                              "shard_grouped16_passages_per_s": ((extras.get("shard_share") or {}).get("grouped16") or {}).get("predicted_8gpu_strong_scaling_passages_per_s"),
+                              "shard_grouped16_basis": "the same with every rank's share of 16 queries per launch sequence (run.py's default under --shard_candidates 1)",
+                              "north_star_target_passages_per_s": 10000}
         line = {
             "metric": "passages/sec (pointwise yes_no reranking, flan-t5-large shape)", "value": round(value, 1),
             "unit": "passages/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -642,6 +663,7 @@ def main():
                        "whole_path_tflops_per_gpu": round(value / world * gfl / 1e3, 1),
                        "whole_path_frac_of_mfma_peak": round(value / world * gfl / 1e3 / MFMA_PEAK_TFLOPS, 4),
                        "per_query": per_query, "ragged": extras.get("ragged"), "shard_share": extras.get("shard_share"),
+                       "predicted_8gpu": predicted_8gpu,
                        "setwise_query": extras.get("setwise_query"), "qlm_xl": extras.get("qlm_xl"), "llama_compare": extras.get("llama_compare")},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -1169,6 +1169,11 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
 // scores (q broadcast from LDS, 64 MACs per key in-lane), block reductions for max / sum, then the 4 waves split the
 // keys for P V with lanes parallel over d, combined through LDS in a fixed order (bitwise reproducible).
 // grid = (Lq, H, B); dynamic LDS = (64 + 4*64 + 8 + max_keys) floats.
+#define ATTX_MAXK 192        // most keys per sequence of attn_dec_cross_mfma_kernel (six 32-key tiles: the whole score row in registers)
+#define ATTX_MAXQ 64         // most decoder positions per sequence (two 32-query tiles, one wave each)
+#define ATTX_KSTR 72         // halfs per K row in LDS (144 B: the 32 rows of a fragment read spread over the banks)
+#define ATTX_VSTR 200        // halfs per V^T row in LDS (ATTX_MAXK keys + padding; 400 B)
+#define ATTX_LDS_BYTES (ATTX_MAXK * ATTX_KSTR * 2 + 64 * ATTX_VSTR * 2 + (RK_LUT_N + 3) * 4)
 struct AttnDecArgs {
   const half_t* q;  int ldq;     // query rows b*Lq + i, head columns h*64..
   const half_t* k;  const half_t* v;  int ldkv;   // key/value rows key_off + j
@@ -1179,6 +1184,10 @@ struct AttnDecArgs {
   // tree form of the causal self-attention (grid = (1, H, rows)): query row r sits at position tree_pos[r] and sees the
   // rows tree_keys[r * Lq + j], j = 0 .. tree_pos[r] - several continuations share the rows of their common prefix
   const int* tree_keys; const int* tree_pos;
+  // cross-attention over the materialised K / V (long decoder prefixes, qlm): sequences of at most ATTX_MAXK keys are taken by
+  // attn_dec_cross_mfma_kernel, the others by the staged kernels; which kernel computes a sequence follows from ITS key count
+  // alone (its bits never depend on the batch): skip_short = 1 makes attn_dec_seq_kernel / attn_dec_kernel leave those to it
+  int skip_short;
 };
 
 // The arithmetic of ONE query row of the decoder attention, shared by attn_dec_kernel (one workgroup per row: the tree form of
@@ -1251,6 +1260,7 @@ __global__ __launch_bounds__(256) void attn_dec_kernel(AttnDecArgs p) {
   if (tkeys) { koff = 0; Lk = i + 1; }
   else if (p.key_off) { koff = p.key_off[b]; Lk = p.key_off[b + 1] - koff; }
   else { koff = b * p.Lq; Lk = p.Lq; }
+  if (p.skip_short && Lk <= ATTX_MAXK) return;                // attn_dec_cross_mfma_kernel's sequence (uniform for the workgroup)
   const int nk = p.causal ? (i + 1 < Lk ? i + 1 : Lk) : Lk;   // keys 0..nk-1 are visible
   const size_t qrow = tkeys ? (size_t)b : (size_t)(b * p.Lq + i);
   auto krow = [&](int j) { return tkeys ? (size_t)tkeys[j] : (size_t)(koff + j); };
@@ -1303,6 +1313,127 @@ __host__ __device__ inline size_t attn_dec_seq_lds(int max_keys) {
   const size_t kp = ((size_t)max_keys + 3) & ~(size_t)3;
   return kp * ATTS_KSTR * 2 + kp * 64 * 2 + RK_LUT_N * sizeof(float) + 12 + 4 * (64 * 4 + kp * 4) * sizeof(float);
 }
+// Cross-attention of the long-prefix decoder (qlm: ~30 label positions per passage over its ~140 encoder rows; hf:
+// modeling_t5.py:404-432 with the materialised K / V, no position bias, no mask) on the matrix cores (round 6).  The staged kernel
+// below spent 128 us per launch on explicit fma chains (1.5 G fma per layer at flan-t5-xl dims, VALU-bound) for 114 MB of K / V -
+// a 25-us read.  One workgroup of two waves per (head, sequence), each wave 32 decoder positions: K rows staged row-major, V
+// TRANSPOSED (sVt[d][key]); S^T = K Q^T with mfma 32x32x16 - a lane owns ONE query column, its 16 registers per 32-key tile are
+// keys (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the tile - the whole score row (<= 192 keys) stays in registers: one maximum, one
+// sum (one exchange with the partner lane), P packed to fp16 in place; O^T = V^T P^T: registers 8 s .. 8 s + 7 of a tile ARE the
+// B operand of its s-th 16-key step, and the matching V^T fragment is two 8-byte reads (keys 16 s + 4 hh + {0..3, 8..11}).
+// Which sequences it takes follows from their own key count (<= ATTX_MAXK) and the call's position count (<= ATTX_MAXQ).
+// The SAME kernel serves the causal self-attention of those prefixes (key_off = nullptr: the keys are the sequence's own Lq <= 64
+// decoder rows; unidirectional position bias from the head's table, key > query masked; hf: modeling_t5.py:144-173).
+__global__ __launch_bounds__(128) void attn_dec_cross_mfma_kernel(AttnDecArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float dec_smem[];
+  half_t* sK = (half_t*)dec_smem;                   // [ATTX_MAXK][ATTX_KSTR]
+  half_t* sVt = sK + ATTX_MAXK * ATTX_KSTR;         // [64][ATTX_VSTR]
+  float* sLut = (float*)(sVt + 64 * ATTX_VSTR);     // [RK_LUT_N] (self-attention form only)
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int koff = p.key_off ? p.key_off[b] : b * p.Lq, Lk = p.key_off ? p.key_off[b + 1] - koff : p.Lq;
+  if (Lk > ATTX_MAXK || Lk <= 0) return;            // the staged kernel's sequence (uniform)
+  const int nt = (Lk + 31) >> 5;                    // key tiles
+  if (p.bias_lut)
+    for (int idx = tid; idx < RK_LUT_N; idx += 128) sLut[idx] = p.bias_lut[h * RK_LUT_N + idx];
+  // ---- stage K (row-major) and V (transposed); rows beyond Lk are zero: their scores are masked, their P is exactly 0 ----
+  for (int idx = tid; idx < nt * 32 * 8; idx += 128) {
+    const int r = idx >> 3, c = idx & 7;
+    half8 kk = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kk;
+    if (r < Lk) {
+      const size_t g = (size_t)(koff + r) * p.ldkv + h * 64 + c * 8;
+      kk = *(const half8*)(p.k + g);
+      vv = *(const half8*)(p.v + g);
+    }
+    *(half8*)(sK + r * ATTX_KSTR + c * 8) = kk;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sVt[(c * 8 + j) * ATTX_VSTR + r] = vv[j];
+  }
+  __syncthreads();
+  if (wave * 32 >= p.Lq) return;                    // a second wave without decoder positions
+  // ---- Q fragments of this wave's 32 positions (B operand: k = 16 ks + 8 hh .. + 7 of query l31) ----
+  const int qi = wave * 32 + l31;
+  const size_t qrow = (size_t)b * p.Lq + (qi < p.Lq ? qi : p.Lq - 1);
+  half8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8*)(p.q + qrow * p.ldq + h * 64 + ks * 16 + 8 * hh);
+  // ---- scores: S^T tile t = K_t Q^T ----
+  f32x16 sc[ATTX_MAXK / 32];
+  float mx = -1e30f;
+#pragma unroll
+  for (int t = 0; t < ATTX_MAXK / 32; ++t) {
+    if (t < nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8 kf = *(const half8*)(sK + (t * 32 + l31) * ATTX_KSTR + ks * 16 + 8 * hh);
+        sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (p.bias_lut) {
+          int rel = key - qi;
+          rel = rel < -RK_LUT_R ? -RK_LUT_R : (rel > RK_LUT_R ? RK_LUT_R : rel);
+          sc[t][r] += sLut[rel + RK_LUT_R];
+        }
+        if (key >= Lk || (p.causal && key > qi)) sc[t][r] = -1e30f;
+        mx = fmaxf(mx, sc[t][r]);
+      }
+    }
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  // ---- softmax over the row (this lane's keys + the partner lane's), P to fp16 in place of the scores ----
+  float sum = 0.f;
+  half8 pf[ATTX_MAXK / 32][2];
+#pragma unroll
+  for (int t = 0; t < ATTX_MAXK / 32; ++t) {
+    if (t < nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(sc[t][r] - mx);       // masked keys: exp(-1e30 - mx) = 0
+        sum += e;
+        pf[t][r >> 3][r & 7] = (half_t)e;
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 32);
+  // ---- O^T = V^T P^T: two 32-row d tiles ----
+  f32x16 o[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < ATTX_MAXK / 32; ++t) {
+    if (t < nt) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const half_t* vr = sVt + (dt * 32 + l31) * ATTX_VSTR + t * 32 + 16 * st + 4 * hh;
+          const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 8);
+          const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[t][st], o[dt], 0, 0, 0);
+        }
+    }
+  }
+  // ---- context row of query l31: d = 32 dt + (r & 3) + 8 (r >> 2) + 4 hh -> 8-byte pieces ----
+  if (qi < p.Lq) {
+    const float inv = 1.0f / sum;
+    half_t* dst = p.ctx + ((size_t)b * p.Lq + qi) * p.ldctx + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const half4 x = {f2h_sat(o[dt][4 * q] * inv), f2h_sat(o[dt][4 * q + 1] * inv), f2h_sat(o[dt][4 * q + 2] * inv), f2h_sat(o[dt][4 * q + 3] * inv)};
+        *(half4*)(dst + dt * 32 + 8 * q + 4 * hh) = x;
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
   extern __shared__ __attribute__((aligned(16))) float dec_smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1316,6 +1447,7 @@ __global__ __launch_bounds__(256) void attn_dec_seq_kernel(AttnDecArgs p) {
   int koff, Lk;
   if (p.key_off) { koff = p.key_off[b]; Lk = p.key_off[b + 1] - koff; }
   else { koff = b * p.Lq; Lk = p.Lq; }
+  if (p.skip_short && Lk <= ATTX_MAXK) return;     // attn_dec_cross_mfma_kernel's sequence (uniform for the workgroup)
   for (int idx = tid; idx < Lk * 8; idx += 256) {
     const int r = idx >> 3, c = idx & 7;
     const size_t g = (size_t)(koff + r) * p.ldkv + h * 64 + c * 8;

@@ -115,7 +115,7 @@ struct rk_engine {
     int glds = 1, skinny = 0x3F, overlap = 1, gemm_variant = 0, attn_short = 5, xattn_direct = 1, attn_heads_per_wg = 0, attn_ko = 0,
         gemm_persistent = 1, fold_norm = 1, s64_stages = 0, dec_fold_norm = 1, greedy_spec = 160, consumer_stats = 1, xattn_mfma = 1,
         dec_ffn_tiled = 1, gemm_split = 1, dec_fuse = 1, dec_fuse_rows = 0, dec_attn_seq = 1, attn_long = 1, attn_long_nw = 0,
-        llama_attn_dma = 1, attn_long_xcd = 1, llama_attn_nw = 0, dec_graph = 1, gemm_sk = 1;
+        llama_attn_dma = 1, attn_long_xcd = 1, llama_attn_nw = 0, dec_graph = 1, gemm_sk = 1, dec_cross_mfma = 1;
   } opt;
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
@@ -724,6 +724,10 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
         if (tree) {
           a.tree_keys = tree->keys; a.tree_pos = tree->pos;
           hipLaunchKernelGGL(attn_dec_kernel, dim3(1, d.n_heads, M), dim3(256), smem_self, st, a);
+        } else if (e->opt.dec_cross_mfma && Ld > XA_MAX_LD && Ld <= ATTX_MAXQ) {
+          // long prefixes (the materialised-K / V regime, qlm): causal self-attention on the matrix cores too (round 6); the choice
+          // follows from the call's position count alone, like the cross-attention's
+          hipLaunchKernelGGL(attn_dec_cross_mfma_kernel, dim3(d.n_heads, B), dim3(128), ATTX_LDS_BYTES, st, a);
         } else if (e->opt.dec_attn_seq && attn_dec_seq_lds(Ld) <= 160 * 1024) {   // one workgroup per (head, sequence): K / V staged once (same bits)
           hipLaunchKernelGGL(attn_dec_seq_kernel, dim3(d.n_heads, B), dim3(256), attn_dec_seq_lds(Ld), st, a);
         } else {
@@ -800,7 +804,14 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
       const half_t* kv = sl.cross_kv + (size_t)l * d.max_tokens * 2 * I;
       AttnDecArgs a{sl.dq, I, kv, kv + I, 2 * I, sl.d_seq_off, sl.dctx, I, nullptr, Ld, 0, sl.maxL};
       Bracket br(e, st, PC_DEC_ATTN, 4.0 * Ld * (double)sl.T * I, (double)sl.T * 2 * I * 2.0);
-      if (e->opt.dec_attn_seq && Ld >= 2 && attn_dec_seq_lds(sl.maxL) <= 160 * 1024)
+      // sequences of at most ATTX_MAXK keys (every pointwise prompt): the matrix-core kernel; longer ones: the staged kernels.  The
+      // call's position count decides whether the MFMA kernel runs at all, a sequence's own key count which kernel takes it.
+      const bool mfma = e->opt.dec_cross_mfma && Ld >= 2 && Ld <= ATTX_MAXQ;
+      if (mfma) hipLaunchKernelGGL(attn_dec_cross_mfma_kernel, dim3(d.n_heads, B), dim3(128), ATTX_LDS_BYTES, st, a);
+      a.skip_short = mfma ? 1 : 0;
+      if (mfma && sl.maxL <= ATTX_MAXK) {
+        // nothing left for the staged kernels
+      } else if (e->opt.dec_attn_seq && Ld >= 2 && attn_dec_seq_lds(sl.maxL) <= 160 * 1024)
         hipLaunchKernelGGL(attn_dec_seq_kernel, dim3(d.n_heads, B), dim3(256), attn_dec_seq_lds(sl.maxL), st, a);
       else
         hipLaunchKernelGGL(attn_dec_kernel, dim3(Ld, d.n_heads, B), dim3(256), smem_cross, st, a);
@@ -2186,6 +2197,7 @@ const OptionDesc kOptions[] = {
   {"attn_long_xcd", &rk_engine::Options::attn_long_xcd, 0, 1, nullptr, "long-sequence attention: workgroups of a (sequence, head) pair on one XCD (1) or dealt over all eight (0); same bits"},
   {"attn_long_nw", &rk_engine::Options::attn_long_nw, 0, 12, "0,3,4,6,12", "waves per workgroup of the long-sequence attention kernel (0 = default 4); same bits"},
   {"attn_long", &rk_engine::Options::attn_long, 0, 1, nullptr, "sequences > 192 keys: the chunked LDS-DMA kernel (1) or the tiled kernel (0)"},
+  {"dec_cross_mfma", &rk_engine::Options::dec_cross_mfma, 0, 1, nullptr, "long decoder prefixes (qlm), cross-attention over the materialised K / V: matrix-core kernel for sequences <= 192 keys (1) or the staged fma-chain kernels (0); differ within fp16 noise"},
   {"dec_attn_seq", &rk_engine::Options::dec_attn_seq, 0, 1, nullptr, "decoder attention at several positions: one workgroup per (head, sequence) (1) or per query row (0); same bits"},
   {"gemm_sk", &rk_engine::Options::gemm_sk, 0, 2, nullptr, "ping-pong GEMM, fp32 residual projections with few tiles and a long K: K split over two workgroups (1: choose_ksplit), never (0), wherever it fits (2: tests)"},
   {"gemm_split", &rk_engine::Options::gemm_split, 0, 1, nullptr, "rows beyond the ping-pong kernel's last whole round on a fill-in tile variant (1) or one launch (0); same bits"},

@@ -323,6 +323,30 @@ def synth_state_dict(d, seed: int = 929, gain: float = 1.0, threads: int = 0) ->
     return dict(synth_tensors(d, seed, gain, threads))
 
 
+OUTLIER_CHANNELS, OUTLIER_HIDDEN, OUTLIER_GAIN_WO, OUTLIER_GAIN_WI1 = (17, 300, 777), (5, 1200, 2001, 2777), 60.0, 100.0
+
+
+def with_outlier_channels(state: Dict[str, np.ndarray], d: T5Dims) -> Dict[str, np.ndarray]:
+    """The trained-checkpoint shape the N(0, init-std) weights lack: a few residual-stream channels and a few FFN hidden units
+    two orders of magnitude above the rest (real T5 checkpoints have them; the engine's 1 / 16-scaled fp16 copy of the fp32 stream
+    and its fp16 saturation exist for them).  In every block the `wo` rows of OUTLIER_CHANNELS are multiplied by OUTLIER_GAIN_WO
+    (those stream channels then run in the hundreds to thousands and dominate every RMSNorm) and the `wi_1` (or `wi`) rows of
+    OUTLIER_HIDDEN by OUTLIER_GAIN_WI1; values stay fp16-representable like every synthetic weight.  Returns a new dict."""
+    out = dict(state)
+    ch = [c for c in OUTLIER_CHANNELS if c < d.d_model]
+    hid = [h for h in OUTLIER_HIDDEN if h < d.d_ff]
+    for name, w in state.items():
+        if name.endswith("DenseReluDense.wo.weight"):
+            w = np.array(w, dtype=np.float32, copy=True)
+            w[ch] = _fp16_round(w[ch] * np.float32(OUTLIER_GAIN_WO))
+            out[name] = w
+        elif name.endswith("DenseReluDense.wi_1.weight") or name.endswith("DenseReluDense.wi.weight"):
+            w = np.array(w, dtype=np.float32, copy=True)
+            w[hid] = _fp16_round(w[hid] * np.float32(OUTLIER_GAIN_WI1))
+            out[name] = w
+    return out
+
+
 def synth_token_batch(n_seq: int, min_len: int, max_len: int, vocab: int, seed: int):
     """Ragged synthetic prompts: ids ~ U{3..vocab-29}, last id = 1 (EOS). Returns list of int32 arrays."""
     rs = np.random.RandomState(seed)   # MT19937: stable across numpy versions

@@ -175,6 +175,65 @@ class PointwiseLlmRanker(LlmRanker):
             doc.score = float(sc)
         return sorted(ranking, key=lambda x: x.score, reverse=True)
 
+    def _rerank_sharded_many(self, items):
+        """Candidate sharding for SEVERAL queries per engine launch sequence (round 6): every rank takes its contiguous share of
+        EVERY query (100 candidates over 8 ranks: 13,13,13,13,12,12,12,12 each), scores all the shares in one launch sequence -
+        sixteen queries are 208 passages per rank instead of 13, the regime the GEMMs are built for - and ONE all_gather carries
+        the raw outputs and the prompts' token counts of all of them.  A rank's row: its scores packed in query order
+        [sum_q n_rq * k], then at offset W * k (W = sum_q of the widest share) the token counts [sum_q n_rq].  Rankings, scores
+        and counters are those of `rerank` query by query (a passage's score does not depend on what shares its call).
+        Returns None when the queries cannot share a call (mixed call shapes, a row beyond the communicator's capacity)."""
+        from . import _dist
+        rank, ws = _dist.world()
+        if ws == 1 and getattr(self.llm, "comm_ready", lambda: False)():
+            rank, ws = self.llm.comm_rank_world()
+        plans, W = [], 0
+        for query, ranking in items:
+            bounds = _dist.shard_bounds(len(ranking), ws)
+            s, e = bounds[rank]
+            spec = self._spec(query, ranking[s:e])
+            if spec is None or spec[1] != "score" or (plans and (spec[2], spec[3]) != (plans[0][2][2], plans[0][2][3])):
+                return None
+            plans.append((bounds, (s, e), spec))
+            W += max(b - a for a, b in bounds)
+        if not plans or W == 0:
+            return None
+        arg, out_ids, dec_len = plans[0][2][2], plans[0][2][3], plans[0][2][4]
+        k = len(out_ids)
+        row = W * (k + 1)
+        have_comm = getattr(self.llm, "ensure_comm", lambda: False)()
+        if have_comm and row > self.llm.comm_capacity:
+            return None
+        flat = [q for _, _, spec in plans for q in tokenize_prompts(self.tokenizer, spec[0])]
+        lens = np.asarray([len(q) for q in flat], dtype=np.float32)
+        if have_comm:
+            local, allv = self.llm.sharded_scores("score", flat, arg, out_ids, row, tail=lens, tail_offset=W * k)
+            assert len(local) == len(flat) * k
+            allv = np.asarray(allv, dtype=np.float32).reshape(ws, row)
+        else:
+            gather = getattr(self.llm, "host_all_gather", None)
+            if gather is None:
+                raise RuntimeError("candidate sharding needs a runtime with a communicator (T5Runtime) or a host_all_gather of its own")
+            chunks = [flat[i:j] for i, j in batches(len(flat), self.batch_size)]
+            local = np.zeros(row, np.float32)
+            local[:len(flat) * k] = self._raw(chunks, "score", arg, out_ids).reshape(-1)
+            local[W * k:W * k + len(flat)] = lens
+            allv = gather(local, row)
+        out, counters = [], []
+        pos = [0] * ws                                                    # passages of rank r consumed so far
+        for (query, ranking), (bounds, _, spec) in zip(items, plans):
+            raw = np.concatenate([allv[r, pos[r] * k:(pos[r] + b - a) * k] for r, (a, b) in enumerate(bounds)])
+            all_lens = np.concatenate([allv[r, W * k + pos[r]:W * k + pos[r] + b - a] for r, (a, b) in enumerate(bounds)])
+            for r, (a, b) in enumerate(bounds):
+                pos[r] += b - a
+            self._reset()
+            self._count_from_lengths(np.rint(all_lens).astype(np.int64), dec_len)
+            counters.append((self.total_compare, self.total_prompt_tokens, self.total_completion_tokens))
+            for doc, sc in zip(ranking, spec[5](raw.reshape(-1, k))):
+                doc.score = float(sc)
+            out.append(sorted(ranking, key=lambda x: x.score, reverse=True))
+        return out, counters
+
     def rerank(self, query: str, ranking: List[SearchResult]) -> List[SearchResult]:
         if self.shard_candidates:
             from . import _dist
@@ -198,9 +257,16 @@ class PointwiseLlmRanker(LlmRanker):
         query at a time (ref: run.py:183-201); a passage's score does not depend on what shares its engine call (ragged
         execution, bit-exact), so the batches of all the queries go to the engine together - its GEMMs then run on several
         hundred passages instead of a hundred and the decoder chain runs once (grouped launches).
-        qlm (per-query labels), unknown methods and sharded runs take the one-by-one path."""
+        Candidate-sharded runs group the same way (_rerank_sharded_many: every rank's share of every query in one launch
+        sequence, ONE all_gather); qlm (per-query labels) and unknown methods take the one-by-one path."""
         items = list(items)
         specs = []
+        if self.shard_candidates and items:
+            from . import _dist
+            if _dist.world()[1] > 1 or getattr(self.llm, "comm_ready", lambda: False)():
+                res = self._rerank_sharded_many(items)                # every rank's share of every query in one launch sequence
+                if res is not None:
+                    return res
         grouped = not self.shard_candidates
         for query, ranking in items:
             spec = self._spec(query, ranking) if grouped else None

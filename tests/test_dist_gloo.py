@@ -140,3 +140,63 @@ def test_two_rank_engine_gather_path_with_multi_chunk_shards(ckpt_dirs, tmp_path
             for ranking in o["rankings"]:
                 assert [d for d, _ in ranking] == [d for d, _ in case["result"]]
                 np.testing.assert_allclose([s for _, s in ranking], [s for _, s in case["result"]], atol=2e-5, rtol=1e-5)
+
+
+WORKER_MANY = r'''
+import json, os, sys
+sys.path[:0] = [os.path.join(sys.argv[1], "llm-rankers_amd"), sys.argv[1], os.path.join(sys.argv[1], "tests")]
+import torch.distributed as dist
+from conftest import load_state
+from _stub import FakeCommEngine, OracleRuntime
+from llmrankers._runtime import T5Runtime
+from llmrankers.rankers import SearchResult
+from llmrankers.pointwise import PointwiseLlmRanker
+from transformers import T5Tokenizer
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=int(sys.argv[4]))
+ck = sys.argv[5]
+dims, state = load_state(ck)
+cases = json.load(open(sys.argv[6]))
+tok = T5Tokenizer.from_pretrained(ck)
+out = {}
+for name in ("double", "engine"):
+    eng = FakeCommEngine(dims, state, max_seqs=4)
+    rt = OracleRuntime(dims, state) if name == "double" else T5Runtime.from_engine(eng, dims)
+    rk = PointwiseLlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=cases[0]["batch_size"], shard_candidates=True)
+    items = [(c["query"], [SearchResult(docid=d, score=s, text=t) for d, s, t in c["input"]]) for c in cases]
+    items.append((cases[0]["query"], []))                     # a query without candidates rides along
+    ranked, counters = rk.rerank_many(items)
+    one = []
+    for c in cases:                                            # the same queries one at a time: rankings, scores, counters
+        r = rk.rerank(c["query"], [SearchResult(docid=d, score=s, text=t) for d, s, t in c["input"]])
+        one.append([[[x.docid, x.score] for x in r], [rk.total_compare, rk.total_prompt_tokens, rk.total_completion_tokens]])
+    out[name] = {"many": [[[x.docid, x.score] for x in r] for r in ranked], "counters": [list(c) for c in counters], "one": one,
+                 "calls": dict(eng.calls)}
+print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sharded_rerank_many_groups_the_shares_of_several_queries(ckpt_dirs, tmp_path):
+    """Round 6: PointwiseLlmRanker.rerank_many under candidate sharding - every rank's share of EVERY query in one launch sequence,
+    ONE gather for all of them (scores + token counts) - against the same queries one at a time and the reference's recorded
+    results: rankings, scores, counters; through the test double's host gather and through the real T5Runtime (engine
+    communicator path: one init, ONE gather for the group, the scores appended chunk by chunk)."""
+    with open(os.path.join(GOLD, "rerank_cases.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["kind"] == "pointwise" and c["ckpt"] == "ckpt_gated_untied" and c["method"] == "yes_no"]
+    bs = cases[0]["batch_size"]
+    cases = [c for c in cases if c["batch_size"] == bs][:3]
+    assert len(cases) >= 2
+    outs = _run_two_ranks(tmp_path, WORKER_MANY, ckpt_dirs["ckpt_gated_untied"], cases)
+    assert outs[0] == outs[1] or all(outs[0][k]["many"] == outs[1][k]["many"] for k in outs[0])   # every rank holds the same rankings
+    for rank, o in enumerate(outs):
+        for name in ("double", "engine"):
+            r = o[name]
+            assert r["many"][-1] == [] and r["counters"][-1] == [0, 0, 0]
+            for c, many, cnt, (one, one_cnt) in zip(cases, r["many"], r["counters"], r["one"]):
+                assert [d for d, _ in many] == [d for d, _ in c["result"]] == [d for d, _ in one]
+                np.testing.assert_allclose([s for _, s in many], [s for _, s in c["result"]], atol=2e-5, rtol=1e-5)
+                np.testing.assert_allclose([s for _, s in many], [s for _, s in one], atol=1e-6)
+                assert cnt == one_cnt == list(c["counters"]) if "counters" in c else cnt == one_cnt
+        calls = o["engine"]["calls"]
+        # grouped call: ONE gather; then the three single queries: one gather each
+        assert calls["init"] == 1 and calls["gather"] == 1 + len(cases), calls

@@ -761,6 +761,46 @@ def test_comm_single_rank_appended_gather_of_a_multi_chunk_share(toy):
         eng.close()
 
 
+def test_comm_single_rank_grouped_sharded_rerank_many(toy, ckpt_dirs):
+    """Round 6: PointwiseLlmRanker.rerank_many under candidate sharding (run.py's default with --shard_candidates 1): the shares
+    of SEVERAL queries in one launch sequence - here through a one-rank RCCL communicator (the one-GPU box's way into the
+    sharded code path), engine calls of at most five sequences so that the group takes several appends - and ONE gather for all
+    of them; rankings, scores (bit for bit: a passage's score does not depend on what shares its call) and counters equal the
+    same queries one at a time, sharded and unsharded."""
+    import contextlib, io
+    from transformers import T5Tokenizer
+    from llmrankers._runtime import T5Runtime
+    from llmrankers.pointwise import PointwiseLlmRanker
+    from llmrankers.rankers import SearchResult
+    dims, state, _ = toy["ckpt_gated_untied"]
+    with open(os.path.join(GOLD, "rerank_cases.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["kind"] == "pointwise" and c["ckpt"] == "ckpt_gated_untied" and c["method"] == "yes_no"]
+    bs = cases[0]["batch_size"]
+    cases = [c for c in cases if c["batch_size"] == bs]
+    eng = _engine(dims, state, max_tokens=2048, max_seqs=5, max_dec_len=8)
+    rt = T5Runtime.from_engine(eng, dims)
+    tok = T5Tokenizer.from_pretrained(ckpt_dirs["ckpt_gated_untied"])
+    fresh = lambda c: [SearchResult(docid=d, score=s, text=t) for d, s, t in c["input"]]
+    plain = PointwiseLlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=bs)
+    want = []
+    for c in cases:
+        r = plain.rerank(c["query"], fresh(c))
+        want.append(([(x.docid, x.score) for x in r], (plain.total_compare, plain.total_prompt_tokens, plain.total_completion_tokens)))
+    eng.comm_init(eng.comm_unique_id(), 0, 1, 4096)
+    try:
+        rk = PointwiseLlmRanker.from_runtime(rt, tok, method="yes_no", batch_size=bs, shard_candidates=True)
+        ranked, counters = rk.rerank_many([(c["query"], fresh(c)) for c in cases] + [(cases[0]["query"], [])])
+        assert ranked[-1] == [] and tuple(counters[-1]) == (0, 0, 0)
+        for c, r, cnt, (w, wc) in zip(cases, ranked, counters, want):
+            assert [(x.docid, x.score) for x in r] == w and tuple(cnt) == wc
+            assert [x.docid for x in r] == [d for d, _ in c["result"]]
+        one = rk.rerank(cases[0]["query"], fresh(cases[0]))           # and the single-query sharded path still agrees
+        assert [(x.docid, x.score) for x in one] == want[0][0]
+    finally:
+        eng.comm_destroy()
+        eng.close()
+
+
 TWO_RANK_API_WORKER = r'''
 import json, os, sys
 repo, ck = sys.argv[1], sys.argv[2]
@@ -1091,6 +1131,25 @@ def test_llama_3_8b_full_depth_vs_oracle_golden():
     best2 = np.sort(cl)[-2:]
     if (not boost_ids and gold["top_logits"][0] - gold["top_logits"][1] > 4e-2 * scale) or (boost_ids and best2[1] - best2[0] > 4e-2 * scale):
         assert int(eng.greedy1(ids)[0]) == cand[int(np.argmax(cl))]
+    # (1b) round 6: compares OF THE HEAPSORT QUERY at the full depth against the fp32 oracle (tools/make_llama8b_compares_golden.py:
+    # the first prompts of the one-by-one sort, ~500 tokens each, label rows boosted as here): label logits, greedy token wherever
+    # the oracle's margin is above the fp16 noise floor - and at least three of them are (asserted: no dead branch)
+    qc = gold.get("query_compares")
+    if qc:
+        assert qgold and list(qc["boost_ids"]) == boost_ids and float(qc["boost"]) == boost
+        decided = 0
+        for k, rec in enumerate(qc["compares"]):
+            prompt = [np.asarray(rec["prompt"], dtype=np.int32)]
+            cscale = rec["logit_abs_max"]
+            lg = eng.last_logits(prompt, boost_ids)[0]
+            lerr = float(np.abs(lg - np.asarray(rec["label_logits"], dtype=np.float32)).max())
+            print(f"[llama8b full depth] query compare {k}: {len(rec['prompt'])} tokens, max |label logit - oracle| = {lerr:.4f} at scale {cscale:.2f}, "
+                  f"oracle margin {rec['margin']:.3f}")
+            assert lerr < 4e-3 * cscale, (k, lerr, cscale)
+            if rec["margin"] > 4e-2 * cscale:
+                decided += 1
+                assert int(eng.greedy1(prompt)[0]) == rec["token"], (k, rec["margin"])
+        assert decided >= 3, decided
     if qgold:
         from transformers import AutoTokenizer
         from llmrankers._runtime import LlamaRuntime
@@ -1142,19 +1201,48 @@ def test_flan_t5_large_full_batch_vs_hf_golden():
     """BASELINE.json configs[1] at full size against the reference's arithmetic: the whole bench batch (32 x 184 tokens) and
     a ragged batch (32 passages of 96..184 tokens, the S2 workload) at flan-t5-large dimensions vs HF fp32 logits generated
     once in the build container (tools/make_large_batch_golden.py): probabilities within 1e-3 (north_star's tolerance),
-    same order wherever the reference's adjacent scores differ by more than the tolerance."""
+    same order wherever the reference's adjacent scores differ by more than the tolerance.  Third tag (round 6), "outlier": the
+    same model with a few stream channels / FFN hidden units two orders of magnitude above the rest (a TRAINED T5's activation
+    shape): held to the reference's own fp16-path error against fp32, recorded with the fixture."""
     from llmrankers import _synth
     path = os.path.join(GOLD, "config2_large_batch.npz")
     if not os.path.exists(path):
         pytest.skip("golden not generated")
     g = np.load(path)
     dims = _synth.FLAN_T5_LARGE
-    eng = _engine(dims, _synth.synth_state_dict(dims, seed=int(g["seed"]), threads=16), max_tokens=8192, max_seqs=32, max_dec_len=4)
+    base_state = _synth.synth_state_dict(dims, seed=int(g["seed"]), threads=16)
+    eng = _engine(dims, base_state, max_tokens=8192, max_seqs=32, max_dec_len=4)
     ids = g["ids"].tolist()
-    for tag in ("uniform", "ragged"):
+    assert "outlier.logits" in g.files                     # round 6: the trained-checkpoint-shaped case is part of the fixture
+    for tag in ("uniform", "ragged", "outlier"):
         n, lo, hi, seed = (int(x) for x in g[f"{tag}.args"])
         seqs = _synth.synth_token_batch(n, lo, hi, dims.vocab, seed=seed)
+        if tag == "outlier":
+            # a few stream channels / FFN hidden units two orders of magnitude above the rest (what a trained T5 looks like and
+            # what the 1 / 16-scaled fp16 copy of the stream and the fp16 saturation are for): a fresh engine with those weights
+            eng.close()
+            eng = _engine(dims, _synth.with_outlier_channels(base_state, dims), max_tokens=8192, max_seqs=32, max_dec_len=4)
+            print(f"[outlier] HF fp32 stream: max |x| {float(g['outlier.stream_absmax']):.0f}, median {float(g['outlier.stream_median']):.2f}")
+            assert float(g["outlier.stream_absmax"]) > 100 * float(g["outlier.stream_median"])
         got, want = eng.score(seqs, [0], ids), g[f"{tag}.logits"]
+        if tag == "outlier":
+            # With activations this peaked the attention scores run in the hundreds and fp16 q / k alone move them by tenths: 1e-3
+            # against fp32 is not what fp16 inference delivers on such a model - the REFERENCE's own accelerator precision (HF
+            # torch_dtype=float16 with fp32 `wo`, recorded on the first 8 passages: outlier.logits_hf_fp16) is 0.12 away from fp32
+            # at logit scale 1.6.  The engine is held to that: no further from fp32 than 1.5 x the reference's fp16 path on the
+            # same passages, 2 x over the whole batch; the probability error likewise.
+            ref16 = g["outlier.logits_hf_fp16"]
+            n16 = len(ref16)
+            ref_err = float(np.abs(ref16 - want[:n16]).max())
+            err8, err_all = float(np.abs(got[:n16] - want[:n16]).max()), float(np.abs(got - want).max())
+            p_ref_err = float(np.abs(_sigm(ref16[:, 0] - ref16[:, 1]) - _sigm(want[:n16, 0] - want[:n16, 1])).max())
+            p_err = float(np.abs(_sigm(got[:, 0] - got[:, 1]) - _sigm(want[:, 0] - want[:, 1])).max())
+            print(f"[outlier] max |logit - HF fp32|: engine {err8:.4f} (8 passages) / {err_all:.4f} (32), HF fp16 {ref_err:.4f} (8); "
+                  f"max |P(yes) - fp32|: engine {p_err:.4f}, HF fp16 {p_ref_err:.4f}")
+            assert ref_err > 10 * SCORE_TOL                      # the case is hard for fp16 (else it pins nothing)
+            assert err8 < 1.5 * ref_err and err_all < 2.0 * ref_err, (err8, err_all, ref_err)
+            assert p_err < 2.0 * p_ref_err, (p_err, p_ref_err)
+            continue
         p_got, p_want = _sigm(got[:, 0] - got[:, 1]), _sigm(want[:, 0] - want[:, 1])
         err = float(np.abs(p_got - p_want).max())
         print(f"[{tag}] max |P(yes) - HF fp32| over {n} passages = {err:.2e}")
@@ -1206,6 +1294,7 @@ def test_decoder_attention_per_sequence_kernel_bit_identical_to_per_row_kernel()
     eng = _engine(dims, state, max_tokens=8192, max_seqs=16, max_dec_len=40)
     labels = [0] + np.random.RandomState(5).randint(3, dims.vocab, size=32).tolist()
     prefix = [0] + np.random.RandomState(6).randint(3, dims.vocab, size=19).tolist()
+    eng.set_option("dec_cross_mfma", 0)                  # (round 6: short sequences' cross-attention has a kernel of its own - next test)
     for seqs in (_synth.synth_token_batch(6, 40, 150, dims.vocab, seed=31), _synth.synth_token_batch(5, 200, 700, dims.vocab, seed=32),
                  _synth.synth_token_batch(1, 64, 64, dims.vocab, seed=33)):
         out = {}
@@ -1215,6 +1304,48 @@ def test_decoder_attention_per_sequence_kernel_bit_identical_to_per_row_kernel()
         np.testing.assert_array_equal(out[1][0], out[0][0])
         np.testing.assert_array_equal(out[1][1], out[0][1])
     eng.set_option("dec_attn_seq", 1)
+    eng.set_option("dec_cross_mfma", 1)
+    eng.close()
+
+
+def test_decoder_cross_attention_on_the_matrix_cores_vs_oracle_staged_kernels_and_batch_independence():
+    """attn_dec_cross_mfma_kernel (round 6): the cross-attention of long decoder prefixes (qlm) for sequences of at most 192 keys
+    on the matrix cores.  qlm scores and multi-token-prefix label logits (1) against the fp32 oracle at the suite's tolerances,
+    (2) against the staged fma-chain kernels (option dec_cross_mfma = 0): equal to fp16 noise, (3) which kernel takes a sequence
+    follows from ITS key count alone: in a batch that also holds prompts longer than 192 keys (those go to the staged kernel in
+    the same call) every sequence has the bits it has alone or in any other batch, (4) 64 < positions: the staged kernels only."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle
+    dims = _synth.FLAN_T5_SMALL
+    state = _synth.synth_state_dict(dims, seed=929, threads=8)
+    eng = _engine(dims, state, max_tokens=8192, max_seqs=16, max_dec_len=80)
+    orc = T5Oracle(dims, state)
+    labels = [0] + np.random.RandomState(5).randint(3, dims.vocab, size=32).tolist()     # 33 positions: two query tiles
+    short = [0] + np.random.RandomState(7).randint(3, dims.vocab, size=18).tolist()      # 19 positions: one
+    mixed = _synth.synth_token_batch(7, 20, 192, dims.vocab, seed=41) + _synth.synth_token_batch(2, 193, 400, dims.vocab, seed=42)
+    only_short = mixed[:7]
+    got = eng.qlm(mixed, labels)
+    want = orc.qlm(mixed, labels)
+    assert np.abs(got - want).max() < 5e-4 * np.abs(want).max(), (np.abs(got - want).max(), np.abs(want).max())
+    got19 = eng.qlm(only_short, short)
+    want19 = orc.qlm(only_short, short)
+    assert np.abs(got19 - want19).max() < 5e-4 * np.abs(want19).max()
+    np.testing.assert_array_equal(eng.qlm(only_short, labels), got[:7])                   # alone == beside longer prompts
+    np.testing.assert_array_equal(eng.qlm(mixed[7:], labels), got[7:])
+    for i in (0, 3, 8):
+        np.testing.assert_array_equal(eng.qlm(mixed[i:i + 1], labels)[0], got[i])
+    np.testing.assert_array_equal(eng.qlm(mixed[::-1], labels), got[::-1])
+    lg = eng.score(only_short, short, [5, 6, 7, 8])
+    assert np.abs(lg - orc.score_last(only_short, short, [5, 6, 7, 8])).max() < LOGIT_TOL
+    eng.set_option("dec_cross_mfma", 0)
+    staged = eng.qlm(mixed, labels)
+    eng.set_option("dec_cross_mfma", 1)
+    assert np.abs(got - staged).max() < 2e-4 * np.abs(staged).max(), np.abs(got - staged).max()   # (cross- AND self-attention differ in kernel)
+    long_labels = [0] + np.random.RandomState(8).randint(3, dims.vocab, size=69).tolist()   # 70 positions > ATTX_MAXQ
+    a = eng.qlm(only_short[:3], long_labels)
+    eng.set_option("dec_cross_mfma", 0)
+    np.testing.assert_array_equal(eng.qlm(only_short[:3], long_labels), a)
+    eng.set_option("dec_cross_mfma", 1)
     eng.close()
 
 

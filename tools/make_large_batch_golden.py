@@ -3,7 +3,12 @@
 CPU (oracle/hf_path.py - output-identical to the imported reference on the fixtures) over the bench's batch of 32 x 184
 tokens, flan-t5-large dimensions, the synthetic weights of seed 929 -> the two label logits of every passage.  Written once
 in the build container to tests/golden/config2_large_batch.npz (a few hundred bytes);
-tests/test_gpu_kernels.py::test_flan_t5_large_full_batch_vs_hf_golden replays it on the engine."""
+tests/test_gpu_kernels.py::test_flan_t5_large_full_batch_vs_hf_golden replays it on the engine.
+Third tag (round 6), "outlier": the same weights with a few residual-stream channels / FFN hidden units two orders of magnitude
+above the rest (llmrankers._synth.with_outlier_channels - the shape of a TRAINED T5's activations, which the engine's
+1 / 16-scaled fp16 stream copy and fp16 saturation exist for), bench batch, HF fp32.
+
+    python tools/make_large_batch_golden.py [outlier]      ("outlier": add / refresh that tag only)"""
 import os
 import sys
 import time
@@ -23,16 +28,49 @@ def main():
     torch.set_num_threads(os.cpu_count() or 8)
     dims = _synth.FLAN_T5_LARGE
     state = _synth.synth_state_dict(dims, seed=929, threads=os.cpu_count() or 8)
-    model = hf_path.build_hf_model(dims, state)
-    out = {"seed": np.array(929), "ids": np.array([YES_ID, NO_ID])}
-    for tag, (n, lo, hi, seed) in {"uniform": (32, 184, 184, 929), "ragged": (32, 96, 184, 930)}.items():
+    path = os.path.join(REPO, "tests", "golden", "config2_large_batch.npz")
+    only_outlier = "outlier" in sys.argv[1:]
+    if only_outlier:
+        out = dict(np.load(path))
+        tags = {"outlier": (32, 184, 184, 931)}
+    else:
+        out = {"seed": np.array(929), "ids": np.array([YES_ID, NO_ID])}
+        tags = {"uniform": (32, 184, 184, 929), "ragged": (32, 96, 184, 930), "outlier": (32, 184, 184, 931)}
+    model = None
+    for tag, (n, lo, hi, seed) in tags.items():
+        if tag == "outlier":
+            model = hf_path.build_hf_model(dims, _synth.with_outlier_channels(state, dims))
+            with torch.no_grad():                            # how far out the outliers are (recorded with the fixture)
+                ids = torch.tensor([list(_synth.synth_token_batch(1, 184, 184, dims.vocab, seed=seed)[0])])
+                hs = model.encoder(input_ids=ids, output_hidden_states=True).hidden_states
+                mags = [float(h.abs().max()) for h in hs[:-1]]
+                med = float(hs[12].abs().median())
+            print(f"[outlier] max |stream| by layer: {[round(m) for m in mags[::4]]} ... max {max(mags):.0f}, median at layer 12 {med:.2f}", flush=True)
+            out["outlier.stream_absmax"] = np.array(max(mags), dtype=np.float32)
+            out["outlier.stream_median"] = np.array(med, dtype=np.float32)
+        elif model is None:
+            model = hf_path.build_hf_model(dims, state)
         seqs = [list(s) for s in _synth.synth_token_batch(n, lo, hi, dims.vocab, seed=seed)]
         t0 = time.time()
         logits = hf_path.pointwise_yes_no(model, seqs, 32, YES_ID, NO_ID)
         print(f"[{tag}] HF fp32 forward of {n} sequences in {time.time() - t0:.1f}s; logit range {logits.min():.3f}..{logits.max():.3f}", flush=True)
         out[f"{tag}.args"] = np.array([n, lo, hi, seed])
         out[f"{tag}.logits"] = logits.astype(np.float32)
-    np.savez_compressed(os.path.join(REPO, "tests", "golden", "config2_large_batch.npz"), **out)
+        if tag == "outlier":
+            # the REFERENCE's accelerator precision on the same weights (ref: llmrankers/pointwise.py:22-23 torch_dtype=float16;
+            # hf keeps every `wo` in fp32: modeling_t5.py _keep_in_fp32_modules): with activations this peaked, attention scores run
+            # in the hundreds and fp16 q / k alone move them by tenths - 1e-3 against fp32 is not what fp16 inference delivers on
+            # such a model, the engine is held to the reference's own fp16 error instead (first 8 passages: CPU fp16 is slow)
+            t0 = time.time()
+            half = model.half()
+            for mod_name, mod in half.named_modules():
+                if mod_name.endswith("DenseReluDense.wo"):
+                    mod.float()
+            l16 = hf_path.pointwise_yes_no(half, seqs[:8], 8, YES_ID, NO_ID)
+            print(f"[outlier] HF fp16 (wo fp32) forward of 8 sequences in {time.time() - t0:.1f}s; max |logit - fp32| = "
+                  f"{np.abs(l16 - logits[:8]).max():.4f}", flush=True)
+            out["outlier.logits_hf_fp16"] = np.asarray(l16, dtype=np.float32)
+    np.savez_compressed(path, **out)
 
 
 if __name__ == "__main__":
