@@ -178,13 +178,11 @@ int rk_profile_reset(rk_engine* e);
 int rk_profile_num_classes(void);
 const char* rk_profile_class_name(int cls);
 int rk_profile_get(rk_engine* e, int cls, double* total_ms, int64_t* launches, double* flops, double* bytes);
-/* variant switches for A/B measurements; the defaults are the fast path and every switch keeps the results within the
- * parity tolerance (most keep the bits).  Examples: "gemm_glds" (1 = direct-to-LDS DMA staging, 0 = registers),
- * "gemm_skinny" (1 = weight-streaming kernel for M <= 32), "overlap" (1 = decoder chain on its own stream), "fold_norm",
- * "dec_graph", "attn_long" (sequences > 192 keys on the chunked LDS-DMA attention kernel), "dec_attn_seq", "chain"
- * (0 by default: two encoder GEMMs per launch with row-panel flags, gemm_chain.h).  The full list with defaults and value
- * ranges is in INTEGRATION.md (the rk_engine_set_option bullet) and next to rk_engine_set_option in csrc/rk_engine.hip.
- * Returns RK_ERR_INVALID for an unknown key or a value out of range. */
+/* Engine options: the defaults are the fast path; every option selects between TESTED implementations of the same arithmetic (the
+ * on-device cross-check of a default path: "fold_norm", "gemm_glds", "attn_short", "attn_long", "dec_attn_seq", "dec_cross_mfma",
+ * "llama_attn_dma", ...) or is a measurement knob ("overlap", "dec_graph", "gemm_variant", "gemm_split", "gemm_sk", ...).  ONE
+ * table holds key, accepted range / set and meaning: kOptions next to rk_engine_set_option in csrc/rk_engine.hip; INTEGRATION.md
+ * lists them by purpose.  Returns RK_ERR_INVALID for an unknown key or a value outside the key's range (nothing is applied). */
 int rk_engine_set_option(rk_engine* e, const char* key, int value);
 
 /* ---- host-only helpers (no device needed) ---- */
