@@ -1810,12 +1810,21 @@ __global__ __launch_bounds__(256) void xattn_part_kernel(XAttnArgs p) {
 // dec_attn 0.170 -> 0.202 ms per step.  One workgroup per CU cannot overlap its own load and compute; four can.)
 // Always 16 heads per workgroup (H > 16: blockIdx.z).  grid = (nch, M, ceil(H / 16)); 256 threads.
 #define XAM_PSTR 72                                            // sP row stride in halfs: 144 B -> the 16 head rows start in 16 different 16-byte slots
-#define XAM_LDS_BYTES (4 * 64 * 64 * 2 + 16 * XAM_PSTR * 2 + 2 * 4 * 16 * 4)
+#define XAM_LDS_TAIL (16 * XAM_PSTR * 2 + 2 * 4 * 16 * 4)                               // P, reduction scratch
+template <bool FEW> constexpr int xam_lds_bytes() { return (FEW ? 8 : 4) * 64 * 64 * 2 + XAM_LDS_TAIL; }   // one / two [64 keys][64 columns] pieces per wave
 #define XAM_F(key) ((((key) >> 1) & 1) | ((((key) >> 3) & 1) << 1))   // XOR on the 32-byte pair index (4 pairs per 128-byte row)
+// FEW (round 6): the same arithmetic in the same order, scheduled for the few-row calls (one setwise compare: 23 chunks x 2 - 13 rows
+// = 46 - 299 workgroups on 256 CUs, each a chain of exposed round trips: 15.2 us per launch): the score loop keeps sixteen k32 steps
+// of operand loads in flight instead of four, and the wave's NEXT piece of encoder rows travels (asm LDS-DMA: the builtin makes the
+// compiler drain the queue in front of every LDS read) while the current one is multiplied - two pieces per wave, counted vmcnt.
+// The large pointwise launches (960 workgroups, four per CU hiding each other's latency) keep the one-piece form: twice the LDS
+// would halve their residency.  Chosen from the launch's workgroup count; a row's bits do not depend on it.
+template <bool FEW>
 __global__ __launch_bounds__(256) void xattn_part_mfma_kernel(XAttnArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char xam_smem[XAM_LDS_BYTES];
-  half_t* sP = (half_t*)(xam_smem + 4 * 64 * 64 * 2);
-  float (*sRed)[4][16] = (float (*)[4][16])(xam_smem + 4 * 64 * 64 * 2 + 16 * XAM_PSTR * 2);
+  constexpr int NPIECE = FEW ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) unsigned char xam_smem[xam_lds_bytes<FEW>()];
+  half_t* sP = (half_t*)(xam_smem + NPIECE * 4 * 64 * 64 * 2);
+  float (*sRed)[4][16] = (float (*)[4][16])(xam_smem + NPIECE * 4 * 64 * 64 * 2 + 16 * XAM_PSTR * 2);
   const int ck = blockIdx.x, m = blockIdx.y, hg = blockIdx.z;
   const int b = p.row_seq ? p.row_seq[p.row0 + m] : (p.row0 + m) / p.Ld;
   const int tok0 = p.seq_off[b];
@@ -1836,9 +1845,23 @@ __global__ __launch_bounds__(256) void xattn_part_mfma_kernel(XAttnArgs p) {
   const int t = t0 + wave * 16 + l15;
   const half_t* bp = p.enc + (size_t)(tok0 + min(t, L - 1)) * p.d + 8 * g;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (FEW) {
+    for (int c1 = 0; c1 < p.d; c1 += 512) {                    // sixteen k32 steps of operand loads in flight (128 registers)
+      half8 av[16], bv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int c0 = c1 + 32 * u < p.d ? c1 + 32 * u : c1;  // (d is a multiple of 32; a short tail re-reads the first step, unused)
+        av[u] = *(const half8*)(ap + c0); bv[u] = *(const half8*)(bp + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (c1 + 32 * u < p.d) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[u], bv[u], acc, 0, 0, 0);
+    }
+  } else {
 #pragma unroll 4
-  for (int c0 = 0; c0 < p.d; c0 += 32)
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8*)(ap + c0), *(const half8*)(bp + c0), acc, 0, 0, 0);
+    for (int c0 = 0; c0 < p.d; c0 += 32)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8*)(ap + c0), *(const half8*)(bp + c0), acc, 0, 0, 0);
+  }
   // lane holds heads 4g..4g+3 for key t (C layout: col = lane&15, row = 4*(lane>>4) + r)
   float mx[4];
 #pragma unroll
@@ -1874,7 +1897,7 @@ __global__ __launch_bounds__(256) void xattn_part_mfma_kernel(XAttnArgs p) {
   half8 pa[2];                                                 // P fragments of the two k32 steps: head l15, keys 32 kk + 8 g .. +8
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) pa[kk] = *(const half8*)(sP + l15 * XAM_PSTR + 32 * kk + 8 * g);
-  half_t* sE = (half_t*)xam_smem + wave * (64 * 64);           // this wave's [64 keys][64 columns] piece
+  half_t* sE0 = (half_t*)xam_smem + wave * (NPIECE * 64 * 64);   // this wave's [64 keys][64 columns] piece(s)
   // DMA piece i fills LDS slots i * 64 + lane of the piece: key row r = slot >> 3, 16-byte chunk c = slot & 7; it fetches
   // global chunk c ^ (F(r) << 1).  Byte offsets of the eight source rows from the piece's first column:
   unsigned soff[8];
@@ -1888,13 +1911,43 @@ __global__ __launch_bounds__(256) void xattn_part_mfma_kernel(XAttnArgs p) {
   const int i16 = lane & 15, kj = i16 >> 2;
   const int fsw = ((kj >> 1) & 1) | ((g & 1) << 1);
   const int wcols = p.d >> 2;                                  // columns of this wave
-  for (int cs = 0; cs < wcols; cs += 64) {
+  const unsigned lds_e = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) half_t*)sE0);
+  auto fetch_piece = [&](int cs, int buf) {
     const char* src = (const char*)(p.enc + wave * wcols + cs);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
-                                       (__attribute__((address_space(3))) void*)(sE + i * 512), 16, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's piece has landed (wave-private: no barrier)
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (FEW) {
+        // (s_nop 4 in front: a base pair that comes out of a spill lane is a VALU-written SGPR, five wait states before a VMEM read)
+        const unsigned dst = lds_e + (unsigned)(buf * (64 * 64) + i * 512) * 2u;
+        const unsigned o = soff[i];
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(o), "s"(src) : "memory", "m0");
+#pragma clang diagnostic pop
+      } else {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
+                                         (__attribute__((address_space(3))) void*)(sE0 + buf * (64 * 64) + i * 512), 16, 0, 0);
+      }
+    }
+  };
+  fetch_piece(0, 0);
+  int buf = 0;
+  for (int cs = 0; cs < wcols; cs += 64) {
+    if constexpr (FEW) {
+      // the NEXT piece travels while this one is multiplied (its buffer was last read two iterations ago: lgkmcnt(0) below).  Counted
+      // wait: the eight instructions of the next piece may stay in flight - LDS-DMA instructions retire in order among themselves, and
+      // the partial-sum stores in between only make the count stricter
+      if (cs + 64 < wcols) {
+        fetch_piece(cs + 64, buf ^ 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else {
+      if (cs > 0) fetch_piece(cs, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's piece has landed (wave-private: no barrier)
+    }
+    half_t* sE = sE0 + buf * (64 * 64);                        // (wave-private: no barrier)
 #pragma unroll
     for (int cb = 0; cb < 64; cb += 16) {
       const int col = cb + 4 * (i16 & 3);                      // column (within the piece) this lane's read starts at
@@ -1913,6 +1966,7 @@ __global__ __launch_bounds__(256) void xattn_part_mfma_kernel(XAttnArgs p) {
       for (int r = 0; r < 4; ++r)
         if (4 * g + r < nh) part[(size_t)(4 * g + r) * p.d + cout] = o[r];
     }
+    if constexpr (FEW) buf ^= 1;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every read of the piece has returned before the next DMA overwrites it
   }
 }

@@ -778,7 +778,9 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
           // the model width allows its LDS image; the VALU form otherwise.  The choice depends on the MODEL only, never on the
           // batch (the two round differently).
           if (e->opt.xattn_mfma && dm % 256 == 0) {             // (every wave takes whole 64-column pieces of its quarter)
-            hipLaunchKernelGGL(xattn_part_mfma_kernel, dim3(nch, nr, (H + 15) / 16), dim3(256), 0, st, xa);
+            // few workgroups (a setwise compare): the latency-scheduled form, two pieces per wave (same bits; attention.h)
+            if ((long)nch * nr * ((H + 15) / 16) <= 2 * e->n_cu) hipLaunchKernelGGL(xattn_part_mfma_kernel<true>, dim3(nch, nr, (H + 15) / 16), dim3(256), 0, st, xa);
+            else hipLaunchKernelGGL(xattn_part_mfma_kernel<false>, dim3(nch, nr, (H + 15) / 16), dim3(256), 0, st, xa);
           } else if ((long)nch * nr * ((H + 15) / 16) >= 2 * e->n_cu)
             hipLaunchKernelGGL(xattn_part_kernel<16>, dim3(nch, nr, (H + 15) / 16), dim3(256), 0, st, xa);
           else
