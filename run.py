@@ -340,14 +340,22 @@ def main(args):
     if resume:
         # a cut block (killed mid-append) in --save_path or in ANY part file is removed before anybody appends: rank 0 rewrites
         # the files, the others wait for it
+        refusal = None
         if writer:
-            clean_run_file(args.run.save_path, expected)
-            if replicas:
-                for pf in part_files(args.run.save_path):
-                    clean_run_file(pf, expected)
+            try:
+                clean_run_file(args.run.save_path, expected)
+                if replicas:
+                    for pf in part_files(args.run.save_path):
+                        clean_run_file(pf, expected)
+            except ValueError as exc:                                # foreign blocks: every rank must stop, not only rank 0
+                refusal = str(exc)
         if world > 1:
             import torch.distributed as dist
-            dist.barrier()
+            box = [refusal]
+            dist.broadcast_object_list(box, src=0)                   # (also the barrier: nobody appends before rank 0 is done)
+            refusal = box[0]
+        if refusal:
+            raise ValueError(refusal)
         done = set(complete_run_blocks(args.run.save_path, expected))
         if replicas:
             for pf in part_files(args.run.save_path):

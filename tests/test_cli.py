@@ -428,3 +428,20 @@ def test_two_rank_replicas_resume_is_durable(runmod, tmp_path, ckpt_dirs):
     calls = [json.loads(next(l for l in o.splitlines() if l.startswith("CALLS "))[6:]) for o in outs]
     # shards: rank 0 = (q1, q2), rank 1 = (q3,): q3 was done, so rank 1 scored nothing; rank 0 scored 2 queries x 4 engine calls
     assert calls[1]["score"] == 0 and calls[0]["score"] == 8, calls
+    # a --save_path written with other settings (a complete-looking 2-line block in the middle): rank 0 refuses to clean it and
+    # EVERY rank stops with that message - nobody is left waiting at a barrier (the refusal travels in the broadcast)
+    foreign = tmp_path / "foreign.trec"
+    fl = want.splitlines()
+    foreign.write_text("".join(l + "\n" for l in fl[:2]) + "".join(l + "\n" for l in fl[7:14]))
+    before = foreign.read_text()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, str(tmp_path / "worker.py"), REPO, ck, json.dumps(argv(foreign, ["--resume"]))],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(base_env, OMP_NUM_THREADS="2", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode != 0 and "refusing" in err, err[-1500:]
+    assert foreign.read_text() == before

@@ -1,8 +1,4 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_rerank.py -x -q -m gpu -k "greedy or setwise or fused_decoder or toy_logits or config3 or monot5 or pipelined or rerank_many or lockstep or pairwise or flan_t5_large_dims" 2>&1 | tail -n 6
-RK_L=1450 RK_B=1 timeout 300 python tools/profile_compare.py 2>/dev/null | tee gpurun_out/x/compare_profile_few.json
-O=$PWD/gpurun_out/x/trace2; rm -rf $O; mkdir -p $O; R=$PWD
-cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O -o t -- python $R/tools/compare_trace.py run > $O/stdout.txt 2>&1
-cd $R && python tools/compare_trace.py summarize $O | tee gpurun_out/x/compare_trace2.txt
-find $O -name "*.csv" -size +4M -delete
+mkdir -p gpurun_out/x
+RK_BENCH_M=2700 RK_BENCH_SHAPES=2700x6144x2048x0,2700x2048x2048x1,2700x10240x2048x2,2700x2048x5120x1,13900x6144x2048x0,13900x2048x2048x1,13900x2048x5120x1 RK_GEMM_VARIANTS=0,1,2,4,5,6 timeout 300 python tools/gemm_bench.py 20 x0,x1,x2,x3,x4,x5,x6 2>&1 | grep -v "JSON\|amdgpu" | tee gpurun_out/x/gemm_xl.log
