@@ -190,7 +190,8 @@ int rk_abi_version(void);
 /* T5 relative-position bucket (hf: modeling_t5.py:216-262) as used to build the device bias tables */
 int rk_rel_bucket(int relative_position, int bidirectional, int num_buckets, int max_distance);
 /* debug: run one GEMM through the engine's kernel on host data (A[M,K] fp16, W[N,K] fp16 -> C[M,N] fp32);
- * use_glds: 1 = tiled kernel with LDS-DMA staging, 0 = register staging, 2 = the weight-streaming (decoder) kernel */
+ * use_glds: 1 = tiled kernel with LDS-DMA staging, 0 = register staging, 2 = the weight-streaming (decoder) kernel,
+ * 3 = the few-row GEMV kernel (M <= 16, K <= 3072; falls back to 2 otherwise) */
 int rk_debug_gemm(rk_engine* e, const uint16_t* A, const uint16_t* W, float* C, int M, int N, int K, int use_glds);
 /* measurement: average ms per launch of the engine's GEMM kernel at one shape (epi = 0 store f16, 1 residual f32,
  * 2 GEGLU, 3 ReLU, 4 store f32), random operands, `iters` back-to-back launches timed with HIP events */

@@ -24,6 +24,7 @@
 #include "attention.h"
 #include "decoder_kernels.h"
 #include "gemm.h"
+#include "gemv_rows.h"
 #include "llama_kernels.h"
 #include "misc_kernels.h"
 
@@ -80,6 +81,7 @@ struct Slot {
   int *d_dec_ids = nullptr, *d_last_rows = nullptr, *d_out_ids = nullptr, *d_labels = nullptr, *d_argmax = nullptr, *d_row_seq = nullptr, *d_tree_keys = nullptr, *d_tree_pos = nullptr;
   float* dhidden = nullptr; half_t *dxn = nullptr, *dqkv = nullptr, *dctx = nullptr, *dq = nullptr, *dffh = nullptr, *dlast = nullptr;
   half_t* dxraw[2] = {nullptr, nullptr}; float* dssq[2] = {nullptr, nullptr}; float* drowscale = nullptr;   // folded decoder norms (run_decoder)
+  float* dssq_few[2] = {nullptr, nullptr};   // the same for the few-row GEMV family (gemv_rows.h): one partial per producing workgroup
   half_t *xqk = nullptr, *xctx = nullptr;                      // direct cross-attention: [32][H*d] each
   float *xpart = nullptr, *xstat = nullptr; bool have_cross_kv = false;
   float* d_scores = nullptr; float* h_scores = nullptr;
@@ -115,7 +117,7 @@ struct rk_engine {
     int glds = 1, skinny = 0x3F, overlap = 1, gemm_variant = 0, attn_short = 5, xattn_direct = 1, attn_heads_per_wg = 0, attn_ko = 0,
         gemm_persistent = 1, fold_norm = 1, s64_stages = 0, dec_fold_norm = 1, greedy_spec = 160, consumer_stats = 1, xattn_mfma = 1,
         dec_ffn_tiled = 1, gemm_split = 1, dec_fuse = 1, dec_fuse_rows = 0, dec_attn_seq = 1, attn_long = 1, attn_long_nw = 0,
-        llama_attn_dma = 1, attn_long_xcd = 1, llama_attn_nw = 0, dec_graph = 1, gemm_sk = 1, dec_cross_mfma = 1;
+        llama_attn_dma = 1, attn_long_xcd = 1, llama_attn_nw = 0, dec_graph = 1, gemm_sk = 1, dec_cross_mfma = 1, dec_gemv = 1;
   } opt;
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
@@ -419,7 +421,8 @@ void launch_gemm_epi(rk_engine* e, hipStream_t st, const GemmArgs& a_in, int for
 // Folded RMSNorm hooks of one GEMM launch (GemmArgs): consumer side = rowscale, producer side = xraw + ssq.
 #define RK_XRAW_SCALE 0.0625f   // the fp16 copy of the fp32 residual stream is stored x 2^-4: head-room for the outlier
                                 // channels of real T5 checkpoints (fp16 max 65504 -> 1.0e6), exact (power of two)
-struct GemmFold { const float* rowscale = nullptr; half_t* xraw = nullptr; float* ssq = nullptr; const float* ssq_in = nullptr; int nb_in = 0; };
+struct GemmFold { const float* rowscale = nullptr; half_t* xraw = nullptr; float* ssq = nullptr; const float* ssq_in = nullptr; int nb_in = 0;
+                  bool few = false; };   // few: the few-row GEMV family (gemv_rows.h; run_decoder decides from the pass's rows / positions)
 
 GemmArgs make_gemm_args(const rk_engine* e, const half_t* A, int lda, const half_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                         int n_split, long split_stride, float scale, long bsA, long bsW, long bsC, const GemmFold& fold) {
@@ -440,6 +443,31 @@ void gemm(rk_engine* e, hipStream_t st, int cls, int epi, const half_t* A, int l
   const double bytes = 2.0 * ((double)M * K + (double)N * K) +
                        out_elems * (epi == EPI_RESID_F32 ? 8.0 : (epi == EPI_STORE_F32 ? 4.0 : 2.0));
   Bracket br(e, st, cls, flops, bytes);
+  // Few-row GEMV family (gemv_rows.h): the decoder pass of ONE setwise compare (run_decoder sets fold.few from the pass's row and
+  // position counts): one wave per output column over all CUs instead of 32-column MFMA tiles.
+  if (fold.few && weight_streaming && batch == 1 && n_split == 0 && M <= GEMV_MAX_ROWS && K % 8 == 0 && K <= 512 * GEMV_MAX_PIECES &&
+      (epi == EPI_STORE_F16 || epi == EPI_RESID_F32 || epi == EPI_GEGLU_F16 || epi == EPI_RELU_F16 || epi == EPI_STORE_F32)) {
+    const int n_out = EPI_IS_GATED(epi) ? N / 2 : N;
+    const int grid = gemv_grid(n_out, e->n_cu);
+    a.nb = gemv_grid(N, e->n_cu);                                   // producer: one partial sum of squares per workgroup
+    const int mr = M <= 2 ? 2 : (M <= 4 ? 4 : (M <= 8 ? 8 : 16));
+    const int smem = mr * K * 2 + (GEMV_MAX_ROWS + 4 * GEMV_MAX_ROWS) * 4;
+    auto go = [&](auto kern) {
+      static std::atomic<uint64_t> attr_done{0};
+      if (smem > 65536) ensure_dynamic_lds((const void*)kern, 160 * 1024, attr_done);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, a);
+    };
+#define RK_GEMV_CASE(E)                                                                                                   \
+    case E: if (mr == 2) go(gemv_rows_kernel<E, 2>); else if (mr == 4) go(gemv_rows_kernel<E, 4>);                        \
+            else if (mr == 8) go(gemv_rows_kernel<E, 8>); else go(gemv_rows_kernel<E, 16>); break;
+    switch (epi) {
+      RK_GEMV_CASE(EPI_STORE_F16) RK_GEMV_CASE(EPI_RESID_F32) RK_GEMV_CASE(EPI_GEGLU_F16) RK_GEMV_CASE(EPI_STORE_F32)
+      default: if (mr == 2) go(gemv_rows_kernel<EPI_RELU_F16, 2>); else if (mr == 4) go(gemv_rows_kernel<EPI_RELU_F16, 4>);
+               else if (mr == 8) go(gemv_rows_kernel<EPI_RELU_F16, 8>); else go(gemv_rows_kernel<EPI_RELU_F16, 16>); break;
+    }
+#undef RK_GEMV_CASE
+    return;
+  }
   // Kernel family is chosen by the CALLER's regime, never by M: a row's result must not depend on how many other rows
   // share the launch (the split-K weight-streaming kernel and the tiled kernels sum K in different orders).
   if ((weight_streaming || batch > 1) && n_split == 0 && (((e->opt.skinny >> epi) & 1) || batch > 1 || epi == EPI_ARGMAX_F32)) {
@@ -696,8 +724,23 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
   const bool dfold = ws && e->opt.dec_fold_norm && (e->opt.skinny & 0x3F) == 0x3F;
   int cur = 0; bool from_embed = true;
   // (the producers of dssq are weight-streaming GEMMs: 32-column blocks, whichever kernel family consumes them)
-  auto cons = [&]() { GemmFold f; if (from_embed) f.rowscale = sl.drowscale; else { f.ssq_in = sl.dssq[cur]; f.nb_in = (dm + 31) / 32; } return f; };
-  auto with_prod = [&](GemmFold f) { f.xraw = sl.dxraw[cur ^ 1]; f.ssq = sl.dssq[cur ^ 1]; return f; };
+  // Few-row GEMV family (round 6, gemv_rows.h): the pass of ONE setwise / pairwise prompt - at most 16 rows at two or more
+  // positions ("<pad> Passage": 2 rows; rk_t5_greedy2's tree: 13) - runs its plain projections one wave per output column over all
+  // CUs.  Decided from the PASS (rows, positions), so every row of a pass takes one family; a row scored alone and the same row in
+  // a lockstep call of more than eight prompts differ in the last bits.  The one-position pointwise decoder
+  // (any row count) never takes it: its batch independence stays bit-exact.
+  const bool fuse_any = (e->opt.dec_fuse == 2 || (e->opt.dec_fuse == 1 && Ld == 1));
+  const bool few = dfold && e->opt.dec_gemv && Ld >= 2 && M <= GEMV_MAX_ROWS && !fuse_any && dm <= 512 * GEMV_MAX_PIECES && F <= 512 * GEMV_MAX_PIECES &&
+                   dm % 8 == 0 && F % 8 == 0 && I % 8 == 0;
+  const int nb_few = gemv_grid(dm, e->n_cu);
+  auto cons = [&]() {
+    GemmFold f; f.few = few;
+    if (from_embed) f.rowscale = sl.drowscale;
+    else if (few) { f.ssq_in = sl.dssq_few[cur]; f.nb_in = nb_few; }
+    else { f.ssq_in = sl.dssq[cur]; f.nb_in = (dm + 31) / 32; }
+    return f;
+  };
+  auto with_prod = [&](GemmFold f) { f.few = few; f.xraw = sl.dxraw[cur ^ 1]; f.ssq = few ? sl.dssq_few[cur ^ 1] : sl.dssq[cur ^ 1]; return f; };
   auto flip = [&]() { cur ^= 1; from_embed = false; };
   embed(e, st, sl.d_dec_ids, sl.dhidden, M, dfold ? sl.dxraw[0] : nullptr, dfold ? sl.drowscale : nullptr);
   const size_t smem_self = (64 + 256 + 8 + (size_t)Ld) * sizeof(float);
@@ -842,7 +885,8 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
       const bool last = l + 1 == d.n_dec_layers;   // the final norm (head kernels) reads the fp32 stream itself
       // (the same switch for FFN-out - 80 tiles of 64x64 with 44 K steps each - took 9 us per layer off the serial profile and
       // nothing measurable off the pipeline: left on the weight-streaming kernel)
-      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dffh, F, w.ffn_out, F, sl.dhidden, dm, M, dm, F, 0, 0, 1.f, 1, 0, 0, 0, ws, last ? GemmFold() : with_prod(GemmFold()));
+      GemmFold plain; plain.few = few;
+      gemm(e, st, PC_DEC_GEMM, EPI_RESID_F32, sl.dffh, F, w.ffn_out, F, sl.dhidden, dm, M, dm, F, 0, 0, 1.f, 1, 0, 0, 0, ws, last ? plain : with_prod(GemmFold()));
       if (!last) flip();
       continue;
     }
@@ -1436,7 +1480,7 @@ int rk_engine_finalize(rk_engine* e) {
     RC(dalloc(e, &sl.dhidden, Mc * dm)); RC(dalloc(e, &sl.dxn, Mc * dm)); RC(dalloc(e, &sl.dqkv, Mc * 3 * I));
     RC(dalloc(e, &sl.dctx, Mc * I)); RC(dalloc(e, &sl.dq, Mc * I)); RC(dalloc(e, &sl.dffh, Mc * F));
     RC(dalloc(e, &sl.dlast, Bc * dm));
-    for (int i = 0; i < 2; ++i) { RC(dalloc(e, &sl.dxraw[i], Mc * dm)); RC(dalloc(e, &sl.dssq[i], Mc * ((dm + 31) / 32))); }
+    for (int i = 0; i < 2; ++i) { RC(dalloc(e, &sl.dxraw[i], Mc * dm)); RC(dalloc(e, &sl.dssq[i], Mc * ((dm + 31) / 32))); RC(dalloc(e, &sl.dssq_few[i], (size_t)GEMV_MAX_ROWS * e->n_cu)); }
     RC(dalloc(e, &sl.drowscale, Mc));
     RC(dalloc(e, &sl.xqk, (size_t)XA_MAX_ROWS * d.n_heads * dm)); RC(dalloc(e, &sl.xctx, (size_t)XA_MAX_ROWS * d.n_heads * dm));
     RC(dalloc(e, &sl.xpart, (size_t)XA_MAX_CHUNKS * d.n_heads * dm)); RC(dalloc(e, &sl.xstat, (size_t)XA_MAX_CHUNKS * d.n_heads * 2));
@@ -2199,6 +2243,7 @@ const OptionDesc kOptions[] = {
   {"attn_long_xcd", &rk_engine::Options::attn_long_xcd, 0, 1, nullptr, "long-sequence attention: workgroups of a (sequence, head) pair on one XCD (1) or dealt over all eight (0); same bits"},
   {"attn_long_nw", &rk_engine::Options::attn_long_nw, 0, 12, "0,3,4,6,12", "waves per workgroup of the long-sequence attention kernel (0 = default 4); same bits"},
   {"attn_long", &rk_engine::Options::attn_long, 0, 1, nullptr, "sequences > 192 keys: the chunked LDS-DMA kernel (1) or the tiled kernel (0)"},
+  {"dec_gemv", &rk_engine::Options::dec_gemv, 0, 1, nullptr, "decoder pass of at most 16 rows at >= 2 positions (one setwise compare): plain projections on the wave-per-column GEMV kernel (1) or the weight-streaming MFMA kernel (0); differ within fp32 summation-order noise"},
   {"dec_cross_mfma", &rk_engine::Options::dec_cross_mfma, 0, 1, nullptr, "long decoder prefixes (qlm), cross-attention over the materialised K / V: matrix-core kernel for sequences <= 192 keys (1) or the staged fma-chain kernels (0); differ within fp16 noise"},
   {"dec_attn_seq", &rk_engine::Options::dec_attn_seq, 0, 1, nullptr, "decoder attention at several positions: one workgroup per (head, sequence) (1) or per query row (0); same bits"},
   {"gemm_sk", &rk_engine::Options::gemm_sk, 0, 2, nullptr, "ping-pong GEMM, fp32 residual projections with few tiles and a long K: K split over two workgroups (1: choose_ksplit), never (0), wherever it fits (2: tests)"},
@@ -2262,7 +2307,8 @@ int rk_debug_gemm(rk_engine* e, const uint16_t* A, const uint16_t* W, float* C, 
   HIPCHK(e, hipMemcpy(dW, W, (size_t)N * K * 2, hipMemcpyHostToDevice));
   const int saved = e->opt.glds;
   e->opt.glds = use_glds != 0;
-  gemm(e, e->slots[0].se, PC_OTHER, EPI_STORE_F32, dA, K, dW, K, dC, N, M, N, K, 0, 0, 1.f, 1, 0, 0, 0, /*weight_streaming=*/use_glds == 2);
+  GemmFold dbg_fold; dbg_fold.few = use_glds == 3;                 // 3: the few-row GEMV family (M <= 16)
+  gemm(e, e->slots[0].se, PC_OTHER, EPI_STORE_F32, dA, K, dW, K, dC, N, M, N, K, 0, 0, 1.f, 1, 0, 0, 0, /*weight_streaming=*/use_glds >= 2, dbg_fold);
   e->opt.glds = saved;
   HIPCHK(e, hipStreamSynchronize(e->slots[0].se));
   HIPCHK(e, hipGetLastError());

@@ -171,6 +171,60 @@ def test_weight_streaming_gemm_vs_numpy(toy, shape):
             np.testing.assert_array_equal(eng.debug_gemm(a[lo:hi], w, use_glds=2), got[lo:hi])
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 64), (2, 1024, 1024), (2, 3072, 1024), (2, 1024, 2816), (13, 1024, 1024), (13, 1024, 2816), (16, 516, 1024),
+                                    (7, 36, 3072), (5, 2052, 576), (9, 8, 64)])
+def test_few_row_gemv_vs_numpy(toy, shape):
+    """gemv_rows_kernel (round 6: the decoder projections of ONE setwise compare, M <= 16 rows): one wave per output column, lanes
+    split K, v_dot2 with fp32 accumulation, fixed xor tree - exact products, another summation order than the MFMA kernels: against
+    numpy at the fp16-input tolerance and against the weight-streaming kernel to fp32 re-association noise; three runs bit-identical."""
+    m, n, k = shape
+    rs = np.random.RandomState(m * 7 + n + k)
+    a = rs.standard_normal((m, k)).astype(np.float16)
+    w = rs.standard_normal((n, k)).astype(np.float16)
+    eng = toy["ckpt_gated_untied"][2]
+    got = eng.debug_gemm(a, w, use_glds=3)
+    for _ in range(2):
+        np.testing.assert_array_equal(eng.debug_gemm(a, w, use_glds=3), got)
+    want = a.astype(np.float32) @ w.astype(np.float32).T
+    assert np.abs(got - want).max() < 2e-3 * np.sqrt(k)
+    ws = eng.debug_gemm(a, w, use_glds=2)
+    assert np.abs(got - ws).max() < 1e-5 * np.sqrt(k) * max(1.0, float(np.abs(ws).max()))
+
+
+def test_few_row_decoder_family_vs_weight_streaming_family_and_oracle(toy):
+    """The decoder pass of one setwise prompt (<= 16 rows at >= 2 positions) on the few-row GEMV family (option dec_gemv = 1, the
+    default) against the weight-streaming family (0) and the fp32 oracle: label logits after a two-token prefix (2 rows), greedy
+    continuations (rows grow 2, 3, 4), a three-prompt call (6 rows) and rk_t5_greedy2's tree pass - same tokens, logits within the
+    suite's tolerance of the oracle and within fp32-order noise of each other; rows do not depend on what shares the call WITHIN the
+    family (one prompt alone == inside the three-prompt call, bit for bit); more than 16 rows take the other family either way."""
+    from llmrankers import _synth
+    from oracle.t5_numpy import T5Oracle
+    for ck in ("ckpt_gated_untied", "ckpt_relu_tied"):
+        dims, state, eng = toy[ck]
+        orc = T5Oracle(dims, state)
+        seqs = _synth.synth_token_batch(3, 20, 120, dims.vocab, seed=61)
+        prefix, ids = [0, 17], [11, 12, 13, 14, 15]
+        try:
+            got = eng.score(seqs, prefix, ids)
+            np.testing.assert_array_equal(eng.score(seqs[1:2], prefix, ids)[0], got[1])          # batch independence inside the family
+            tok = eng.greedy(seqs[:1], [0, 17], 3)[0]
+            tok2 = eng.greedy(seqs[:1], [0, 17], 2, candidates=ids)[0]               # the tree pass of rk_t5_greedy2
+            eng.set_option("dec_gemv", 0)
+            ref = eng.score(seqs, prefix, ids)
+            tok_ref = eng.greedy(seqs[:1], [0, 17], 3)[0]
+            big = _synth.synth_token_batch(9, 20, 60, dims.vocab, seed=62)                     # 18 rows: the other family either way
+            big_ref = eng.score(big, prefix, ids)
+            eng.set_option("dec_gemv", 1)
+            np.testing.assert_array_equal(eng.score(big, prefix, ids), big_ref)
+        finally:
+            eng.set_option("dec_gemv", 1)
+        want = orc.score_last(seqs, prefix, ids)
+        assert np.abs(got - want).max() < LOGIT_TOL and np.abs(ref - want).max() < LOGIT_TOL
+        assert np.abs(got - ref).max() < 2e-3, np.abs(got - ref).max()
+        np.testing.assert_array_equal(tok, tok_ref)
+        np.testing.assert_array_equal(tok2, tok[:, :2])                                   # tree pass == two steps (same family)
+
+
 def test_encoder_stages_one_layer():
     """1-layer model: every intermediate buffer vs the oracle (localises a wrong kernel)."""
     from llmrankers import _synth

@@ -1,4 +1,5 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
 mkdir -p gpurun_out/x
-RK_BENCH_M=2700 RK_BENCH_SHAPES=2700x6144x2048x0,2700x2048x2048x1,2700x10240x2048x2,2700x2048x5120x1,13900x6144x2048x0,13900x2048x2048x1,13900x2048x5120x1 RK_GEMM_VARIANTS=0,1,2,4,5,6 timeout 300 python tools/gemm_bench.py 20 x0,x1,x2,x3,x4,x5,x6 2>&1 | grep -v "JSON\|amdgpu" | tee gpurun_out/x/gemm_xl.log
+timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_rerank.py -x -q -m gpu -k "few_row or greedy or setwise or toy or pairwise or config3 or rerank_many or fused" 2>&1 | tail -n 8
+for o in "" "dec_gemv=0"; do echo "opts=$o"; RK_OPTS=$o RK_L=1450 RK_B=1 timeout 300 python tools/profile_compare.py 2>/dev/null; done | tee gpurun_out/x/compare_gemv.txt
