@@ -279,6 +279,11 @@ __device__ __forceinline__ void gemm_epilogue_lse(const GemmArgs& p, f32x16 (&ac
 #ifndef GEMM_EPI_NT
 #define GEMM_EPI_NT 7
 #endif
+// timing-only knock-outs of the residual epilogue (A/B libraries of tools/ only; results are garbage): bit 0 the old fp32 rows are not
+// read, 1 the new fp32 rows are not written, 2 the fp16 stream copy and its sums of squares are not written
+#ifndef GEMM_EPI_KO
+#define GEMM_EPI_KO 0
+#endif
 template <int EPI, int NI, int MI, bool RESID_IN_ACC = false, int ROWS = 32, int DEPTH = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (&acc)[NI][MI], int mbase, int nbase,
                                                      int lane, unsigned char* stage, const float (&rsc)[MI]) {
@@ -321,7 +326,8 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
       m = m < p.M ? m : p.M - 1;                                 // clamped rows are never stored
       const int nn = n_ok ? n : 0;
       const f32x4* src_ = (const f32x4*)((const float*)p.C + cbase + (size_t)m * p.ldc + nn);
-      if constexpr (GEMM_EPI_NT != 0) oldv[RMW ? sl : 0][i] = __builtin_nontemporal_load(src_);
+      if constexpr ((GEMM_EPI_KO & 1) != 0) oldv[RMW ? sl : 0][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      else if constexpr (GEMM_EPI_NT != 0) oldv[RMW ? sl : 0][i] = __builtin_nontemporal_load(src_);
       else oldv[RMW ? sl : 0][i] = *src_;
     }
   };
@@ -387,7 +393,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
       if (F32) {
         f32x4 v = *(const f32x4*)sp;
         if constexpr (RMW) { const f32x4 old = oldv[sl][i]; v = {old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]}; }
-        if (ok) {
+        if (ok && !(RMW && (GEMM_EPI_KO & 2) != 0)) {
           f32x4* dst_ = (f32x4*)((float*)p.C + cbase + (size_t)m * p.ldc + n);
           if constexpr (RMW && (GEMM_EPI_NT & 2) != 0) __builtin_nontemporal_store(v, dst_);
           else *dst_ = v;
@@ -398,7 +404,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmArgs& p, f32x16 (
             // this epilogue and the row statistics (hence every score) would depend on the tile shape
             float ss = ok ? __builtin_fmaf(v[3], v[3], __builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], v[0] * v[0]))) : 0.f;
             ss = row16_sum_f(ss);                                // the 16 lanes of one row
-            if (ok) {
+            if (ok && (GEMM_EPI_KO & 4) == 0) {
               half4 xr = {f2h_sat(v[0] * p.xs), f2h_sat(v[1] * p.xs), f2h_sat(v[2] * p.xs), f2h_sat(v[3] * p.xs)};
               if constexpr ((GEMM_EPI_NT & 8) != 0) __builtin_nontemporal_store(xr, (half4*)(p.xraw + (size_t)m * p.ldx + n));
               else *(half4*)(p.xraw + (size_t)m * p.ldx + n) = xr;
@@ -975,6 +981,9 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // Measured (r04, separately compiled libraries alternated on one box): 0 / 2 / 4 = 7 694-7 731 / 7 678-7 766 / 7 644-7 731 passages/s -
 // no difference: it is not the issuing wave's stall that sets the 2 us of a K tile but the CU's LDS-DMA throughput beside a busy
 // matrix pipe (64 pieces x ~50 cycles; probe r03), wherever the instructions sit.  Left at 0.
+#ifndef GEMM_PP2_EDEPTH
+#define GEMM_PP2_EDEPTH 0
+#endif
 #ifndef GEMM_PP2_RISSUE
 #define GEMM_PP2_RISSUE 0
 #endif
@@ -1298,7 +1307,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   // fp32 outputs: 16 rows per pass (16 x 272 B per wave); fp16 outputs fit whole 32-row slabs (32 x 144 B)
   constexpr bool F32OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32;
   constexpr int EROWS = F32OUT ? 16 : 32;
-  if (finish) gemm_epilogue_staged<EPI, 2, 4, false, EROWS>(p, acc, mbase, nbase, lane, gemm_smem + 114688 + wave * 4608, rsc);
+  if (finish) gemm_epilogue_staged<EPI, 2, 4, false, EROWS, GEMM_PP2_EDEPTH>(p, acc, mbase, nbase, lane, gemm_smem + 114688 + wave * 4608, rsc);
   if (next >= ntiles) break;
   tile = next;
   __syncthreads();   // staging rows are read before the next tile's DMA wraps around to W1 | stage 1

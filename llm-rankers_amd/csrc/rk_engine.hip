@@ -117,7 +117,7 @@ struct rk_engine {
     int glds = 1, skinny = 0x3F, overlap = 1, gemm_variant = 0, attn_short = 5, xattn_direct = 1, attn_heads_per_wg = 0, attn_ko = 0,
         gemm_persistent = 1, fold_norm = 1, s64_stages = 0, dec_fold_norm = 1, greedy_spec = 160, consumer_stats = 1, xattn_mfma = 1,
         dec_ffn_tiled = 1, gemm_split = 1, dec_fuse = 1, dec_fuse_rows = 0, dec_attn_seq = 1, attn_long = 1, attn_long_nw = 0,
-        llama_attn_dma = 1, attn_long_xcd = 1, llama_attn_nw = 0, dec_graph = 1, gemm_sk = 1, dec_cross_mfma = 1, dec_gemv = 1;
+        llama_attn_dma = 1, attn_long_xcd = 1, llama_attn_nw = 0, dec_graph = 1, gemm_sk = 1, dec_cross_mfma = 1, dec_gemv = 1, dec_gemv_rows = 4;
   } opt;
   float* attn_trace = nullptr;   // measurement builds only (option attn_trace)
   int n_cu = 256;
@@ -724,13 +724,17 @@ int run_decoder(rk_engine* e, Slot& sl, int Ld, const DecTree* tree = nullptr) {
   const bool dfold = ws && e->opt.dec_fold_norm && (e->opt.skinny & 0x3F) == 0x3F;
   int cur = 0; bool from_embed = true;
   // (the producers of dssq are weight-streaming GEMMs: 32-column blocks, whichever kernel family consumes them)
-  // Few-row GEMV family (round 6, gemv_rows.h): the pass of ONE setwise / pairwise prompt - at most 16 rows at two or more
-  // positions ("<pad> Passage": 2 rows; rk_t5_greedy2's tree: 13) - runs its plain projections one wave per output column over all
+  // Few-row GEMV family (round 6, gemv_rows.h): the pass of ONE setwise / pairwise prompt - a handful of rows at two or more
+  // positions ("<pad> Passage": 2 rows; the second greedy step: 3) - runs its plain projections one wave per output column over all
   // CUs.  Decided from the PASS (rows, positions), so every row of a pass takes one family; a row scored alone and the same row in
   // a lockstep call of more than eight prompts differ in the last bits.  The one-position pointwise decoder
   // (any row count) never takes it: its batch independence stays bit-exact.
+  // Row limit (option dec_gemv_rows, default 4): measured cross-over at flan-t5-large dims and 1 450-token prompts, whole calls,
+  // GEMV against weight-streaming MFMA family: 2 rows 4.87 / 5.20 ms, 4 rows 6.38 / 6.67, 6 rows 8.30 / 8.25, 8 rows 9.41 / 9.39,
+  // 12 rows 12.86 / 12.36, 16 rows 15.18 / 14.58 (profiles/r06_few_rows_ab.txt) - every workgroup stages ALL rows in LDS and the
+  // per-column VALU work grows with the rows; rk_t5_greedy2's 13-row tree pass stays on the matrix cores.
   const bool fuse_any = (e->opt.dec_fuse == 2 || (e->opt.dec_fuse == 1 && Ld == 1));
-  const bool few = dfold && e->opt.dec_gemv && Ld >= 2 && M <= GEMV_MAX_ROWS && !fuse_any && dm <= 512 * GEMV_MAX_PIECES && F <= 512 * GEMV_MAX_PIECES &&
+  const bool few = dfold && e->opt.dec_gemv && Ld >= 2 && M <= e->opt.dec_gemv_rows && !fuse_any && dm <= 512 * GEMV_MAX_PIECES && F <= 512 * GEMV_MAX_PIECES &&
                    dm % 8 == 0 && F % 8 == 0 && I % 8 == 0;
   const int nb_few = gemv_grid(dm, e->n_cu);
   auto cons = [&]() {
@@ -2244,6 +2248,7 @@ const OptionDesc kOptions[] = {
   {"attn_long_nw", &rk_engine::Options::attn_long_nw, 0, 12, "0,3,4,6,12", "waves per workgroup of the long-sequence attention kernel (0 = default 4); same bits"},
   {"attn_long", &rk_engine::Options::attn_long, 0, 1, nullptr, "sequences > 192 keys: the chunked LDS-DMA kernel (1) or the tiled kernel (0)"},
   {"dec_gemv", &rk_engine::Options::dec_gemv, 0, 1, nullptr, "decoder pass of at most 16 rows at >= 2 positions (one setwise compare): plain projections on the wave-per-column GEMV kernel (1) or the weight-streaming MFMA kernel (0); differ within fp32 summation-order noise"},
+  {"dec_gemv_rows", &rk_engine::Options::dec_gemv_rows, 1, GEMV_MAX_ROWS, nullptr, "largest row count of a decoder pass that takes the few-row GEMV family (default 4 = the measured cross-over; the kernel takes up to 16)"},
   {"dec_cross_mfma", &rk_engine::Options::dec_cross_mfma, 0, 1, nullptr, "long decoder prefixes (qlm), cross-attention over the materialised K / V: matrix-core kernel for sequences <= 192 keys (1) or the staged fma-chain kernels (0); differ within fp16 noise"},
   {"dec_attn_seq", &rk_engine::Options::dec_attn_seq, 0, 1, nullptr, "decoder attention at several positions: one workgroup per (head, sequence) (1) or per query row (0); same bits"},
   {"gemm_sk", &rk_engine::Options::gemm_sk, 0, 2, nullptr, "ping-pong GEMM, fp32 residual projections with few tiles and a long K: K split over two workgroups (1: choose_ksplit), never (0), wherever it fits (2: tests)"},
@@ -2341,16 +2346,23 @@ int rk_debug_gemm_bench(rk_engine* e, int M, int N, int K, int epi, int iters, f
     HIPCHK(e, hipMemset(dC, 0, nc * 4));
   }
   const int ldc = EPI_IS_GATED(epi) ? N / 2 : N;
-  for (int i = 0; i < 2; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, ldk, dW, ldk, dC, ldc, M, N, K);
+  // (RK_BENCH_FOLD: the residual epilogue as the encoder runs it - producer side of the folded RMSNorm: fp16 stream copy + sums of squares)
+  GemmFold fold;
+  half_t* dX = nullptr; float* dS = nullptr;
+  if (getenv("RK_BENCH_FOLD") && atoi(getenv("RK_BENCH_FOLD")) && epi == EPI_RESID_F32) {
+    HIPCHK(e, hipMalloc((void**)&dX, nc * 2)); HIPCHK(e, hipMalloc((void**)&dS, (size_t)M * ((N + 31) / 32) * 4));
+    fold.xraw = dX; fold.ssq = dS;
+  }
+  for (int i = 0; i < 2; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, ldk, dW, ldk, dC, ldc, M, N, K, 0, 0, 1.f, 1, 0, 0, 0, false, fold);
   HIPCHK(e, hipEventRecord(e->t0, e->slots[0].se));
-  for (int i = 0; i < iters; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, ldk, dW, ldk, dC, ldc, M, N, K);
+  for (int i = 0; i < iters; ++i) gemm(e, e->slots[0].se, PC_OTHER, epi, dA, ldk, dW, ldk, dC, ldc, M, N, K, 0, 0, 1.f, 1, 0, 0, 0, false, fold);
   HIPCHK(e, hipEventRecord(e->t1, e->slots[0].se));
   HIPCHK(e, hipEventSynchronize(e->t1));
   float ms = 0;
   HIPCHK(e, hipEventElapsedTime(&ms, e->t0, e->t1));
   HIPCHK(e, hipGetLastError());
   *out_ms = ms / iters;
-  hipFree(dA); hipFree(dW); hipFree(dC);
+  hipFree(dA); hipFree(dW); hipFree(dC); if (dX) hipFree(dX); if (dS) hipFree(dS);
   return RK_OK;
 }
 

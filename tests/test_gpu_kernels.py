@@ -14,6 +14,7 @@ from conftest import GOLD, load_state
 pytestmark = pytest.mark.gpu
 SCORE_TOL = 1e-3
 LOGIT_TOL = 2e-2
+DEC_GEMV_ROWS_DEFAULT = 4      # engine default of option dec_gemv_rows (csrc/rk_engine.hip, Options): restored by the tests that widen it
 
 
 def _engine(dims, state, **kw):
@@ -192,8 +193,8 @@ def test_few_row_gemv_vs_numpy(toy, shape):
 
 
 def test_few_row_decoder_family_vs_weight_streaming_family_and_oracle(toy):
-    """The decoder pass of one setwise prompt (<= 16 rows at >= 2 positions) on the few-row GEMV family (option dec_gemv = 1, the
-    default) against the weight-streaming family (0) and the fp32 oracle: label logits after a two-token prefix (2 rows), greedy
+    """The decoder pass of one setwise prompt (a handful of rows at >= 2 positions; option dec_gemv_rows, default 4, here 16 = all the
+    kernel takes) on the few-row GEMV family (option dec_gemv = 1, the default) against the weight-streaming family (0) and the fp32 oracle: label logits after a two-token prefix (2 rows), greedy
     continuations (rows grow 2, 3, 4), a three-prompt call (6 rows) and rk_t5_greedy2's tree pass - same tokens, logits within the
     suite's tolerance of the oracle and within fp32-order noise of each other; rows do not depend on what shares the call WITHIN the
     family (one prompt alone == inside the three-prompt call, bit for bit); more than 16 rows take the other family either way."""
@@ -205,6 +206,7 @@ def test_few_row_decoder_family_vs_weight_streaming_family_and_oracle(toy):
         seqs = _synth.synth_token_batch(3, 20, 120, dims.vocab, seed=61)
         prefix, ids = [0, 17], [11, 12, 13, 14, 15]
         try:
+            eng.set_option("dec_gemv_rows", 16)                                      # the whole family (default: up to 4 rows)
             got = eng.score(seqs, prefix, ids)
             np.testing.assert_array_equal(eng.score(seqs[1:2], prefix, ids)[0], got[1])          # batch independence inside the family
             tok = eng.greedy(seqs[:1], [0, 17], 3)[0]
@@ -216,8 +218,12 @@ def test_few_row_decoder_family_vs_weight_streaming_family_and_oracle(toy):
             big_ref = eng.score(big, prefix, ids)
             eng.set_option("dec_gemv", 1)
             np.testing.assert_array_equal(eng.score(big, prefix, ids), big_ref)
+            eng.set_option("dec_gemv_rows", DEC_GEMV_ROWS_DEFAULT)
+            np.testing.assert_array_equal(eng.score(seqs, prefix, ids), ref)         # 6 rows at the default limit: the other family
+            np.testing.assert_array_equal(eng.score(seqs[1:2], prefix, ids), eng.score(seqs[1:3], prefix, ids)[:1])   # 2 and 4 rows: this one
         finally:
             eng.set_option("dec_gemv", 1)
+            eng.set_option("dec_gemv_rows", DEC_GEMV_ROWS_DEFAULT)
         want = orc.score_last(seqs, prefix, ids)
         assert np.abs(got - want).max() < LOGIT_TOL and np.abs(ref - want).max() < LOGIT_TOL
         assert np.abs(got - ref).max() < 2e-3, np.abs(got - ref).max()
@@ -613,7 +619,8 @@ def test_decoder_folded_rmsnorm_matches_separate_norm_kernels(toy, ckpt):
     """Default decoder path for up to 4 decoder positions: the three RMSNorms of a layer are folded into the weight-streaming
     GEMMs (the residual GEMMs leave fp16 rows + block sums of squares, the next GEMM forms the row factor itself).  Scores
     at L_d = 1 (product matrix: consumer and producer in one launch), 2 and 3 agree with the separate-kernel path and
-    the fp32 oracle; rows stay independent of the batch they are scored in (bit-exact)."""
+    the fp32 oracle; rows stay independent of the batch they are scored in (bit-exact within a GEMM family: calls of <= 16 rows at
+    L_d >= 2 take the few-row GEMV family, round 6)."""
     from llmrankers import _synth
     from oracle.t5_numpy import T5Oracle
     dims, state, eng = toy[ckpt]
@@ -630,8 +637,26 @@ def test_decoder_folded_rmsnorm_matches_separate_norm_kernels(toy, ckpt):
         fold = eng.score(seqs, prefix, ids)
         assert np.abs(fold - plain).max() < 5e-3, (prefix, np.abs(fold - plain).max())
         assert np.abs(fold[:9] - want).max() < LOGIT_TOL and np.abs(plain[:9] - want).max() < LOGIT_TOL, prefix
-        np.testing.assert_array_equal(eng.score(seqs[30:35], prefix, ids), fold[30:35])
-        np.testing.assert_array_equal(eng.score(seqs[3:4], prefix, ids), fold[3:4])
+        sub, one = eng.score(seqs[30:35], prefix, ids), eng.score(seqs[3:4], prefix, ids)
+        if len(prefix) == 1:
+            np.testing.assert_array_equal(sub, fold[30:35])
+            np.testing.assert_array_equal(one, fold[3:4])
+        else:
+            # a handful of rows (option dec_gemv_rows: default 4, the kernel's limit 16) at >= 2 positions run on the few-row GEMV family (another K summation order): fp16
+            # noise against the 74-row call, rows independent of the batch WITHIN the family, and the weight-streaming family
+            # (dec_gemv = 0) bit-equal to the large call
+            assert np.abs(sub - fold[30:35]).max() < 2e-3 and np.abs(one - fold[3:4]).max() < 2e-3, prefix   # (fp16 roundings of the stream flip)
+            try:
+                eng.set_option("dec_gemv_rows", 16)
+                sub16 = eng.score(seqs[30:35], prefix, ids)
+                np.testing.assert_array_equal(eng.score(seqs[32:33], prefix, ids), sub16[2:3])
+                np.testing.assert_array_equal(eng.score(seqs[2:5], prefix, ids)[1:2], one)
+                eng.set_option("dec_gemv", 0)
+                np.testing.assert_array_equal(eng.score(seqs[30:35], prefix, ids), fold[30:35])
+                np.testing.assert_array_equal(eng.score(seqs[3:4], prefix, ids), fold[3:4])
+            finally:
+                eng.set_option("dec_gemv", 1)
+                eng.set_option("dec_gemv_rows", DEC_GEMV_ROWS_DEFAULT)
     tok, _ = eng.greedy(seqs[:6], [0], 3)                                   # L_d grows 1 -> 3 across the steps
     for i in (0, 5):
         np.testing.assert_array_equal(eng.greedy(seqs[i:i + 1], [0], 3)[0][0], tok[i])
@@ -1413,6 +1438,7 @@ def test_long_sequence_attention_kernel_vs_oracle_tiled_kernel_and_batch_indepen
     dims = _synth.FLAN_T5_SMALL
     state = _synth.synth_state_dict(dims, seed=929, threads=8)
     eng = _engine(dims, state, max_tokens=16384, max_seqs=32, max_dec_len=4)
+    eng.set_option("dec_gemv", 0)      # (the subject is the ENCODER kernel: one decoder GEMM family for the one-prompt and the batched calls)
     seqs = _synth.synth_token_batch(3, 200, 900, dims.vocab, seed=41) + _synth.synth_token_batch(1, 385, 385, dims.vocab, seed=42) + \
         _synth.synth_token_batch(1, 193, 193, dims.vocab, seed=43) + _synth.synth_token_batch(1, 1300, 1300, dims.vocab, seed=45)
     ids = [5, 6, 7, 8]

@@ -1,5 +1,11 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-mkdir -p gpurun_out/x
-timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_rerank.py -x -q -m gpu -k "few_row or greedy or setwise or toy or pairwise or config3 or rerank_many or fused" 2>&1 | tail -n 8
-for o in "" "dec_gemv=0"; do echo "opts=$o"; RK_OPTS=$o RK_L=1450 RK_B=1 timeout 300 python tools/profile_compare.py 2>/dev/null; done | tee gpurun_out/x/compare_gemv.txt
+O=gpurun_out/x; mkdir -p $O
+: > $O/epi_ko_smallm.txt
+for M in 2048 8192 16384; do
+for n in base ko1 ko6 ko7 d3; do
+  echo "== $n M=$M" >> $O/epi_ko_smallm.txt
+  RK_ENGINE_LIB=exp/librk_$n.so RK_BENCH_M=$M RK_BENCH_FOLD=1 RK_GEMM_VARIANTS=5 timeout 300 python tools/gemm_bench.py 50 o,ffn_out 2>&1 | grep -v "JSON\|amdgpu\|tools\]" >> $O/epi_ko_smallm.txt
+done
+done
+cat $O/epi_ko_smallm.txt
