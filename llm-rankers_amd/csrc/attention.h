@@ -79,6 +79,18 @@ __device__ __forceinline__ float attn_row_sum(float x) {
   attn_swap32(a, b);
   return a + b;
 }
+// attn_tile_exp with the scale and a CONSTANT bias folded into the exponent's argument: e = exp2(s log2(e) + c), c = bias - m
+__device__ __forceinline__ void attn_tile_fma_exp(f32x16& s0, f32x16& s1, float c, float& psum) {
+  const f32x2 c2 = {c, c}, l2e = {ATT_LOG2E, ATT_LOG2E};
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const f32x2 d0 = __builtin_elementwise_fma(f32x2{s0[r], s0[r + 1]}, l2e, c2), d1 = __builtin_elementwise_fma(f32x2{s1[r], s1[r + 1]}, l2e, c2);
+    s0[r] = __builtin_amdgcn_exp2f(d0[0]); s0[r + 1] = __builtin_amdgcn_exp2f(d0[1]);
+    s1[r] = __builtin_amdgcn_exp2f(d1[0]); s1[r + 1] = __builtin_amdgcn_exp2f(d1[1]);
+    psum += s0[r] + s1[r];
+    psum += s0[r + 1] + s1[r + 1];
+  }
+}
 template <bool MASK, class BiasFn, bool CHUNKED = false>
 __device__ __forceinline__ void attn_tile_bias_max(f32x16& s0, f32x16& s1, float& tmax, int key_base, int L, BiasFn bias) {
   // registers 4g .. 4g+3 of s0 / s1 hold keys tile0 + 8g (+32) .. +8 (both half-waves): a group that lies wholly inside the
@@ -896,6 +908,17 @@ __global__ __launch_bounds__(NG * 384, ATTD_MINW) void attn_enc_dma_kernel(AttnE
 #define ATTL_IMG_HALFS (ATTL_KEYS * 64)
 #define ATTL_TAB_N 512
 #define ATTL_LDS_BYTES (4 * ATTL_IMG_HALFS * 2 + 2 * ATTL_TAB_N * 4 + (RK_LUT_N + 3) * 4)
+// ATTL_STAMP(k): the waves of workgroup ATTL_TRACE_WG record the shader clock (cycles since the kernel's start) at phase boundary k
+// of every chunk: p.trace[(wave * 16 + chunk) * 16 + k]  (measurement builds, engine option attn_trace, tools/attn_long_trace.py)
+#ifndef ATTL_TRACE_WG
+#define ATTL_TRACE_WG 40
+#endif
+#ifdef RK_MEASURE
+#define ATTL_STAMP(k) do { if (p.trace && blockIdx.x == ATTL_TRACE_WG && ch < 16 && wave < 12) { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); \
+    if ((threadIdx.x & 63) == 0) p.trace[(wave * 16 + ch) * 16 + (k)] = (float)(int)(t_ - attl_t0); } } while (0)
+#else
+#define ATTL_STAMP(k) do { } while (0)
+#endif
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel(AttnEncArgs p) {
   constexpr int ATTL_QUERIES = 32 * NW, ATTL_THREADS = 64 * NW;
@@ -918,6 +941,9 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
   const int q0 = Q0 + wave * 32;
   const bool active = q0 < L;                                                   // wave-uniform
   const int nch = (L + ATTL_KEYS - 1) / ATTL_KEYS;
+#ifdef RK_MEASURE
+  const long long attl_t0 = (long long)__builtin_amdgcn_s_memtime();
+#endif
   auto opaque_lane = [&]() {
     int lane;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
@@ -934,22 +960,40 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
     return c;
   };
   // K and V rows of chunk ch -> stage st: 32 pieces of 64 sixteen-byte slots (K image 16, V image 16) over the twelve waves
+  constexpr int ATTL_NP = (32 + NW - 1) / NW;                                    // pieces per wave and chunk
+  // byte offset of this lane's 16 bytes of piece k of chunk ch: row (tok0 + key) of the head's K / V columns, swizzled chunk.  (round 6)
+  // The per-lane part (row within the chunk, swizzle) is formed ONCE (boff); a chunk wholly inside the sequence adds a uniform
+  // stride - the address arithmetic of the eight pieces was ~110 of a chunk's ~590 VALU instructions.  The last chunk clamps its rows.
+  unsigned boff[ATTL_NP];
+  {
+    const int lane = opaque_lane();
+#pragma unroll
+    for (int k = 0; k < ATTL_NP; ++k) {
+      const int sub = (wave + NW * k) & 15, slot = sub * 64 + lane, r = slot >> 3, c = slot & 7;
+      boff[k] = ((unsigned)(tok0 + r) * (unsigned)p.ld + ((c ^ ATTD_SWZ(r)) << 3)) * 2u;
+    }
+  }
+  auto piece_off = [&](int lane, int ch, int k, int sub) {
+    if ((ch + 1) * ATTL_KEYS <= L) return boff[k] + (unsigned)ch * (unsigned)(ATTL_KEYS * 2) * (unsigned)p.ld;     // (uniform branch)
+    const int slot = sub * 64 + lane, r = slot >> 3, c = slot & 7;
+    int key = ch * ATTL_KEYS + r;
+    key = key < L ? key : L - 1;
+    return ((unsigned)(tok0 + key) * (unsigned)p.ld + ((c ^ ATTD_SWZ(r)) << 3)) * 2u;
+  };
+  auto issue_piece = [&](int lane, int ch, int st, int k) {
+    const int pid = wave + NW * k;
+    if (pid < 32) {
+      const int which = pid >> 4, sub = pid & 15;
+      const char* hb = (const char*)(p.qkv + (1 + which) * p.I + h * 64);
+      const unsigned off = piece_off(lane, ch, k, sub);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hb + off),
+                                       (__attribute__((address_space(3))) void*)(sbuf + (2 * st + which) * ATTL_IMG_HALFS + sub * 512),
+                                       16, 0, 0);
+    }
+  };
   auto issue_chunk = [&](int lane, int ch, int st) {
 #pragma unroll
-    for (int k = 0; k < (32 + NW - 1) / NW; ++k) {
-      const int pid = wave + NW * k;
-      if (pid < 32) {
-        const int which = pid >> 4, sub = pid & 15;
-        const int slot = sub * 64 + lane, r = slot >> 3, c = slot & 7;
-        int key = ch * ATTL_KEYS + r;
-        key = key < L ? key : L - 1;
-        const char* hb = (const char*)(p.qkv + (1 + which) * p.I + h * 64);
-        const unsigned off = ((unsigned)(tok0 + key) * (unsigned)p.ld + ((c ^ ATTD_SWZ(r)) << 3)) * 2u;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hb + off),
-                                         (__attribute__((address_space(3))) void*)(sbuf + (2 * st + which) * ATTL_IMG_HALFS + sub * 512),
-                                         16, 0, 0);
-      }
-    }
+    for (int k = 0; k < ATTL_NP; ++k) issue_piece(lane, ch, st, k);
   };
   // is any of the workgroup's queries within max_distance of chunk ch?  (then its table is built; uniform for the block)
   auto chunk_near_wg = [&](int ch) {
@@ -1056,8 +1100,19 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
     f32x16 s[2][2];
     qk_chunk(lane_ctx(opaque_lane()), kbuf, s);
     __builtin_amdgcn_sched_barrier(0);
+    ATTL_STAMP(1);
     float tmax = -1e30f;
-    {
+    constexpr bool FARFOLD = !NEAR && !MASK;
+    if constexpr (FARFOLD) {
+      // (round 6) a far chunk wholly inside the sequence: ONE bias constant for all 128 x 32 scores, and t -> s log2(e) + bias is
+      // monotonic, so the maximum is taken over the raw scores (max t = the same fma of max s, exactly) and the fma moves into the
+      // exponent's argument: exp2(fma(s, log2(e), bias - m)) - 32 packed FMAs per chunk less (the kernel is bound by its VALU slots)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = attn_max3(tmax, s[kt][0][r], s[kt][1][r]);
+      tmax = __builtin_fmaf(tmax, ATT_LOG2E, far_bias);
+    } else {
       const LaneCtx c1 = lane_ctx(opaque_lane());
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
@@ -1076,11 +1131,13 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
     }
     const float m_c = attn_row_max(tmax);
     const float m_new = attn_max3(m_run, m_c, m_c);
+    ATTL_STAMP(2);
     float psum = 0.f;
     unsigned pp[2][16];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      attn_tile_exp(s[kt][0], s[kt][1], m_new, psum);
+      if constexpr (FARFOLD) attn_tile_fma_exp(s[kt][0], s[kt][1], far_bias - m_new, psum);
+      else attn_tile_exp(s[kt][0], s[kt][1], m_new, psum);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const half2v a = {(half_t)s[kt][0][2 * i], (half_t)s[kt][0][2 * i + 1]};
@@ -1100,11 +1157,14 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
       o0[r] = x0[0]; o0[r + 1] = x0[1]; o1[r] = x1[0]; o1[r + 1] = x1[1];
     }
     __builtin_amdgcn_sched_barrier(0);
+    ATTL_STAMP(3);
     const LaneCtx c3 = lane_ctx(opaque_lane());
     pv_tile(c3, vbuf, 0, pp[0]);
     __builtin_amdgcn_sched_barrier(0);
+    ATTL_STAMP(4);
     pv_tile(c3, vbuf, 1, pp[1]);
     __builtin_amdgcn_sched_barrier(0);
+    ATTL_STAMP(5);
   };
 
   using T = std::integral_constant<bool, true>; using F = std::integral_constant<bool, false>;
@@ -1116,6 +1176,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
       build_table(ch + 1, st ^ 1);
     }
     __builtin_amdgcn_sched_barrier(0);
+    ATTL_STAMP(0);
     if (active) {
       const bool mask = (ch + 1) * ATTL_KEYS > L;
       // this wave's 32 queries against the chunk: range of key - query
@@ -1128,8 +1189,10 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // chunk ch + 1 has landed (it had this whole chunk to do so)
     __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the next table is written, every LDS read of this chunk retired
+    ATTL_STAMP(6);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    ATTL_STAMP(7);
   }
   // ---- context rows: normalise, pack, store (the short kernel's permlane32_swap pairing: two 16-byte stores per 32-column half) ----
   if (active) {

@@ -2394,7 +2394,6 @@ int64_t rk_debug_read(rk_engine* e, const char* name, float* out, int64_t max_fl
   if (n == "enc_hidden") { src = sl.hidden; cnt = (int64_t)sl.T * dm; is_half = false; }
 #ifdef RK_MEASURE
   else if (n == "attn_trace" && e->attn_trace) { src = e->attn_trace; cnt = 12 * 16 * 16; is_half = false; }
-  else if (n == "chain_trace" && e->chain_trace) { src = e->chain_trace; cnt = 256 * 64 * 4 * 2; is_half = false; }   // raw: two floats = one 64-bit stamp
 #endif
   else if (n == "enc_out") { src = sl.enc_out; cnt = (int64_t)sl.T * dm; }
   else if (n == "qkv") { src = sl.qkv; cnt = (int64_t)sl.T * 3 * I; }

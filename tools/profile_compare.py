@@ -6,6 +6,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(REPO, "llm-rankers_amd"), REPO]
 import torch  # noqa
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lib; _lib.use_env_library()   # RK_ENGINE_LIB: A/B build (tools only)
 from llmrankers import _synth
 from llmrankers._engine import RkEngine
 
