@@ -981,8 +981,12 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // Measured (r04, separately compiled libraries alternated on one box): 0 / 2 / 4 = 7 694-7 731 / 7 678-7 766 / 7 644-7 731 passages/s -
 // no difference: it is not the issuing wave's stall that sets the 2 us of a K tile but the CU's LDS-DMA throughput beside a busy
 // matrix pipe (64 pieces x ~50 cycles; probe r03), wherever the instructions sit.  Left at 0.
+// Residual epilogue of the ping-pong kernel: the old fp32 rows are requested this many 16-row slabs ahead of their use (64 registers at
+// 3; the operand fragments are dead by then).  Round 6 (profiles/r06_epilogue_knockouts.txt): O alone 216 -> 202 us at M = 58 880,
+// FFN-out unchanged, the pipelined bench 7 698 -> 7 743 passages/s (six alternating runs each); 7 spills.  The K-split instantiation
+// (247 VGPRs) keeps 0.  Same bits.
 #ifndef GEMM_PP2_EDEPTH
-#define GEMM_PP2_EDEPTH 0
+#define GEMM_PP2_EDEPTH 3
 #endif
 #ifndef GEMM_PP2_RISSUE
 #define GEMM_PP2_RISSUE 0
@@ -1307,7 +1311,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   // fp32 outputs: 16 rows per pass (16 x 272 B per wave); fp16 outputs fit whole 32-row slabs (32 x 144 B)
   constexpr bool F32OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32;
   constexpr int EROWS = F32OUT ? 16 : 32;
-  if (finish) gemm_epilogue_staged<EPI, 2, 4, false, EROWS, GEMM_PP2_EDEPTH>(p, acc, mbase, nbase, lane, gemm_smem + 114688 + wave * 4608, rsc);
+  if (finish) gemm_epilogue_staged<EPI, 2, 4, false, EROWS, SPLIT ? 0 : GEMM_PP2_EDEPTH>(p, acc, mbase, nbase, lane, gemm_smem + 114688 + wave * 4608, rsc);
   if (next >= ntiles) break;
   tile = next;
   __syncthreads();   // staging rows are read before the next tile's DMA wraps around to W1 | stage 1
