@@ -938,6 +938,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
   const int Q0 = qb * ATTL_QUERIES;
   if (L <= ATT_ROW_MAXL || Q0 >= L) return;                                     // uniform for the whole block
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  __builtin_assume(wave >= 0 && wave < NW);
   const int q0 = Q0 + wave * 32;
   const bool active = q0 < L;                                                   // wave-uniform
   const int nch = (L + ATTL_KEYS - 1) / ATTL_KEYS;
@@ -973,27 +974,33 @@ __global__ __launch_bounds__(64 * NW, NW >= 6 ? 3 : 2) void attn_enc_long_kernel
       boff[k] = ((unsigned)(tok0 + r) * (unsigned)p.ld + ((c ^ ATTD_SWZ(r)) << 3)) * 2u;
     }
   }
-  auto piece_off = [&](int lane, int ch, int k, int sub) {
-    if ((ch + 1) * ATTL_KEYS <= L) return boff[k] + (unsigned)ch * (unsigned)(ATTL_KEYS * 2) * (unsigned)p.ld;     // (uniform branch)
-    const int slot = sub * 64 + lane, r = slot >> 3, c = slot & 7;
-    int key = ch * ATTL_KEYS + r;
-    key = key < L ? key : L - 1;
-    return ((unsigned)(tok0 + key) * (unsigned)p.ld + ((c ^ ATTD_SWZ(r)) << 3)) * 2u;
-  };
-  auto issue_piece = [&](int lane, int ch, int st, int k) {
+  auto issue_piece = [&](auto insidec, int lane, int ch, int st, int k) {
     const int pid = wave + NW * k;
-    if (pid < 32) {
+    if (pid < 32) {                                          // (decided at compile time wherever NW k + NW <= 32: wave < NW is assumed below)
       const int which = pid >> 4, sub = pid & 15;
       const char* hb = (const char*)(p.qkv + (1 + which) * p.I + h * 64);
-      const unsigned off = piece_off(lane, ch, k, sub);
+      unsigned off;
+      if constexpr (decltype(insidec)::value) {
+        off = boff[k] + (unsigned)ch * (unsigned)(ATTL_KEYS * 2) * (unsigned)p.ld;
+      } else {
+        const int slot = sub * 64 + lane, r = slot >> 3, c = slot & 7;
+        int key = ch * ATTL_KEYS + r;
+        key = key < L ? key : L - 1;
+        off = ((unsigned)(tok0 + key) * (unsigned)p.ld + ((c ^ ATTD_SWZ(r)) << 3)) * 2u;
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hb + off),
                                        (__attribute__((address_space(3))) void*)(sbuf + (2 * st + which) * ATTL_IMG_HALFS + sub * 512),
                                        16, 0, 0);
     }
   };
   auto issue_chunk = [&](int lane, int ch, int st) {
+    if ((ch + 1) * ATTL_KEYS <= L) {                         // one uniform branch per chunk: every row of the chunk exists
 #pragma unroll
-    for (int k = 0; k < ATTL_NP; ++k) issue_piece(lane, ch, st, k);
+      for (int k = 0; k < ATTL_NP; ++k) issue_piece(std::integral_constant<bool, true>{}, lane, ch, st, k);
+    } else {
+#pragma unroll
+      for (int k = 0; k < ATTL_NP; ++k) issue_piece(std::integral_constant<bool, false>{}, lane, ch, st, k);
+    }
   };
   // is any of the workgroup's queries within max_distance of chunk ch?  (then its table is built; uniform for the block)
   auto chunk_near_wg = [&](int ch) {

@@ -983,8 +983,8 @@ __device__ __forceinline__ void gemm_wait_vmcnt() {
 // matrix pipe (64 pieces x ~50 cycles; probe r03), wherever the instructions sit.  Left at 0.
 // Residual epilogue of the ping-pong kernel: the old fp32 rows are requested this many 16-row slabs ahead of their use (64 registers at
 // 3; the operand fragments are dead by then).  Round 6 (profiles/r06_epilogue_knockouts.txt): O alone 216 -> 202 us at M = 58 880,
-// FFN-out unchanged, the pipelined bench 7 698 -> 7 743 passages/s (six alternating runs each); 7 spills.  The K-split instantiation
-// (247 VGPRs) keeps 0.  Same bits.
+// FFN-out unchanged, the pipelined bench 7 698 -> 7 743 passages/s (six alternating runs each); all eight slabs ahead (7) spills and is
+// slower (247 us).  The K-split instantiation (247 VGPRs) keeps 0.  Same bits.
 #ifndef GEMM_PP2_EDEPTH
 #define GEMM_PP2_EDEPTH 3
 #endif

@@ -2,7 +2,7 @@
 //
 // Replaces the same Linears as gemm_skinny_kernel (hf: models/t5/modeling_t5.py:206-209, 106-123 inside T5Stack's decoder blocks)
 // for the call shape of the reference's one-prompt generate / forward (ref: llmrankers/setwise.py:93-95, 184: decoder prefix
-// "<pad> Passage", 2 rows; rk_t5_greedy2's tree pass: 13 rows).  Why a second kernel: the weight-streaming MFMA kernel cuts N into
+// "<pad> Passage", 2 rows; the second greedy step: 3).  Why a second kernel: the weight-streaming MFMA kernel cuts N into
 // 32-column tiles - 32 workgroups for the 1 024-column projections, each streaming 64 KB in two dependent rounds, an LDS tree and
 // an epilogue: 6.0 / 8.6 / 10.2 us per launch (store / residual / GEGLU; profiles/r06_compare_kernel_trace.txt) where a chip-wide
 // launch that does nothing costs ~4 us.  tools/probes/probe_persist_gemv.hip measured the alternative: one wave per output column
@@ -16,7 +16,8 @@
 // factor (consumer side), fp32 residual add + fp16 stream copy + per-workgroup sums of squares (producer side: `ssq` holds ONE
 // partial per producing workgroup, the consumer adds them in a fixed order), GEGLU / ReLU.
 // Numerics: the same products as every other GEMM of the engine, another summation order (lane-strided K, then the tree); which
-// family a decoder pass uses follows from its row count (<= 16) and position count (>= 2) - see DESIGN.md section 4.
+// family a decoder pass uses follows from its row count (<= option dec_gemv_rows: 4 by default, the measured cross-over against the
+// MFMA kernel - profiles/r06_few_rows_ab.txt; this kernel takes up to 16) and position count (>= 2) - see DESIGN.md section 4.
 #pragma once
 #include "gemm.h"
 
