@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs p) {
   if constexpr (RS) {
     const unsigned roff = (unsigned)(m0 + wm * 128 + l31) * 4u;
     // (s_nop 4: should the base pair ever come out of a spill lane right here - v_readlane is a VALU write of an SGPR, a VMEM read of
-    // it needs five wait states, and the hazard recognizer does not look inside inline asm; gemm_chain.h met exactly that)
+    // it needs five wait states, and the hazard recognizer does not look inside inline asm; round 5's chained-launch kernel met exactly that)
     asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=&v"(rsc[0]) : "v"(roff), "s"(p.rowscale));
     asm volatile("global_load_dword %0, %1, %2 offset:128" : "=&v"(rsc[1]) : "v"(roff), "s"(p.rowscale));
     asm volatile("global_load_dword %0, %1, %2 offset:256" : "=&v"(rsc[2]) : "v"(roff), "s"(p.rowscale));

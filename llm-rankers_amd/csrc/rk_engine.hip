@@ -2239,7 +2239,7 @@ const OptionDesc kOptions[] = {
   {"attn_heads_per_wg", &rk_engine::Options::attn_heads_per_wg, 0, 4096, nullptr, "short-sequence attention: (sequence, head) items per wave group, 0 = dealt evenly; same bits"},
   {"xattn_direct", &rk_engine::Options::xattn_direct, 0, 1, nullptr, "decoder prefixes <= 16: query-side cross-attention (1) or materialised K / V (0)"},
   {"attn_short", &rk_engine::Options::attn_short, 0, 6, "0,5,6", "sequences <= 192 keys: DMA kernel with two (5) / one (6) wave group per workgroup, or the tiled kernel (0); same bits"},
-  {"gemm_variant", &rk_engine::Options::gemm_variant, 0, 120, nullptr, "tile variant: 0 auto, 1..6 see choose_variant, 7 stream-K; measurement builds: 80+ / 100+ knock-outs"},
+  {"gemm_variant", &rk_engine::Options::gemm_variant, 0, 120, nullptr, "tile variant: 0 auto, 1..6 see choose_variant; measurement builds: 80+ / 100+ knock-outs"},
   {"dec_fuse_rows", &rk_engine::Options::dec_fuse_rows, 0, 32, nullptr, "rows per workgroup of dec_cross_qk_kernel (0 = auto); same bits"},
   {"dec_fuse", &rk_engine::Options::dec_fuse, 0, 2, nullptr, "few-row decoder: projections around the query-side cross-attention fused at one position (1), always (2), never (0)"},
   {"llama_attn_nw", &rk_engine::Options::llama_attn_nw, 0, 8, "0,4,8", "waves per workgroup of the Llama LDS-DMA attention kernel (0 = default 8); same bits"},

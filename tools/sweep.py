@@ -4,7 +4,7 @@
 measured exactly like bench.py's timed region (same GroupPipeline / timed_run).  GPU-minutes are scarce: a sweep of ten
 variants costs one engine build instead of ten.
 
-    python tools/sweep.py "G=8,steps=64,warmup=16" "G=8,steps=64,warmup=16,gemm_stagger=1200"
+    python tools/sweep.py "G=8,steps=64,warmup=16" "G=8,steps=64,warmup=16,gemm_split=0"
 """
 import json
 import os
