@@ -212,19 +212,22 @@ def ragged_leg(eng, dims, B, G, n_slots):
 def setwise_leg(state):
     """SURVEY 8d S3 / BASELINE configs[2]: one setwise heapsort query (hits=100, num_child=10, k=10) end to end through
     SetwiseLlmRanker.rerank on its own engine (label rows of the head boosted so that generations are labels, as with a
-    trained checkpoint), both scorings; and sixteen queries in lockstep (rerank_many, the CLI's default).  tools/bench_setwise_query.py."""
+    trained checkpoint), both scorings; and the CLI's default number of queries in lockstep (rerank_many; 32 since the end of round 6).
+    tools/bench_setwise_query.py."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("rk_bench_setwise", os.path.join(REPO, "tools", "bench_setwise_query.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     # 140-word passages are cut to the full 128 tokens of run.py's default --passage_length and the query is ~31 tokens: prompts
     # of ~1.56k tokens = S3's 11 x 134 + 32 + 30 (rounds 1-4 ran this leg on 60-word passages: ~0.9k-token prompts)
-    res = mod.run(state=state, reps=2, many=16, one_by_one=False, words=140, query_words=24)
+    from llmrankers._batching import default_queries_per_call
+    nq = default_queries_per_call("setwise", 100)
+    res = mod.run(state=state, reps=2, many=nq, one_by_one=False, words=140, query_words=24)
     for v in res.values():
         v.pop("top10", None)
     res["workload"] = "S3 at its stated size: flan-t5-large dims, setwise heapsort, hits=100 num_child=10 k=10, 128-token passages + " \
                       "~31-token query (fixture tokenizer; avg_prompt_tokens per compare is reported), level-batched build phase; " \
-                      "*_many16 = sixteen queries ranked in lockstep (SetwiseLlmRanker.rerank_many = run.py's default for setwise; eight until the end of round 5: 55.7 / 59.6 ms per query)"
+                      f"*_many{nq} = {nq} queries ranked in lockstep (SetwiseLlmRanker.rerank_many = run.py's default for setwise; sixteen until the end of round 6: 47.1 / 51.3 ms per query in the leases of that round)"
     return res
 
 

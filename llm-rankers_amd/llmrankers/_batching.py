@@ -215,14 +215,16 @@ def default_queries_per_call(kind: str, hits: int) -> int:
     up to 256 prompts that pipeline over the engine's two slots AND launches while the later queries are still being tokenised
     (T5Runtime.score_stream), so per call only the first launch sequence's tokenisation and the last one's decoder chain are
     exposed (tools/per_call_sweep.py at hits=100, one box, round 4: 6 / 8 / 12 / 16 queries per call = 7 430 / 7 432 / 7 649 / 7 749
-    passages/s; before the streaming launch 6 / 8 = 7 098 / 6 992 and the default was 6); setwise: sixteen heapsorts in lockstep
+    passages/s; before the streaming launch 6 / 8 = 7 098 / 6 992 and the default was 6); setwise: thirty-two heapsorts in lockstep
     (tools/bench_setwise_query.py, configs[2] shape at ~0.9k-token prompts, rounds 2-4: 1 / 4 / 6 / 8 queries = 106 / 47.7 / 41.0 /
     37.4 ms per query, `likelihood`; at the stated size, ~1.56k-token prompts, round 5: 1 / 8 / 16 queries = 127 / 55.7 / 48.1 ms
-    `likelihood`, 129 / 59.6 / 52.0 ms `generation` - sixteen prompts per sift-down step fill the encoder GEMMs' rounds over the
-    CUs better than eight, and still fit one engine call of either runtime: 25k tokens, 16 sequences); anything else one query at
-    a time."""
+    `likelihood`, 129 / 59.6 / 52.0 ms `generation`; round 6, profiles/r06_lockstep_sweep.txt: 16 / 24 / 32 / 48 queries = 46.8 /
+    45.4 / 44.4 / 41.7 ms `likelihood`, 50.7 / 47.7 / 46.0 / 44.6 ms `generation` - the more prompts per sift-down step, the
+    better the encoder GEMMs' rounds over the CUs are filled.  Thirty-two = two alternating groups of sixteen prompts, the most
+    that still fits ONE engine call of either runtime: 25k tokens of T5Runtime's 49k, the 16 sequences of LlamaRuntime); anything
+    else one query at a time."""
     if kind == "pointwise":
         return max(1, min(16, -(-1600 // max(1, int(hits)))))
     if kind == "setwise":
-        return 16
+        return 32
     return 1

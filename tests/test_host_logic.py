@@ -428,11 +428,11 @@ def test_setwise_rerank_many_equals_one_query_at_a_time(runtimes, scoring):
 
 
 def test_default_queries_per_call():
-    """run.py --queries_per_call 0 (auto): pointwise enough queries for 1 600 passages per call, capped at 16; setwise sixteen
-    heapsorts in lockstep; everything else one query at a time (llmrankers/_batching.py)."""
+    """run.py --queries_per_call 0 (auto): pointwise enough queries for 1 600 passages per call, capped at 16; setwise thirty-two
+    heapsorts in lockstep (two alternating groups of sixteen prompts); everything else one query at a time (llmrankers/_batching.py)."""
     from llmrankers._batching import default_queries_per_call as d
     assert [d("pointwise", h) for h in (2000, 1000, 512, 100, 64, 20, 4, 0)] == [1, 2, 4, 16, 16, 16, 16, 16]
-    assert d("setwise", 100) == 16 and d("pairwise", 100) == 1 and d("other", 100) == 1
+    assert d("setwise", 100) == 32 and d("pairwise", 100) == 1 and d("other", 100) == 1
 
 
 class _EventEngine:

@@ -58,7 +58,7 @@ def run(state=None, reps=3, many=None, one_by_one=True, words=None, query_words=
     words = int(os.environ.get("RK_WORDS", "60")) if words is None else words
     query_words = int(os.environ.get("RK_QUERY_WORDS", "7")) if query_words is None else query_words
     # (this tool's runtime wrapper does not chunk: the build phase of NQ queries in lockstep is 9 NQ prompts of ~900 tokens)
-    eng = RkEngine(dims, 0, max_tokens=max(32768, (20000 if words > 80 else 12000) * nq_cap), max_seqs=256, max_dec_len=8)
+    eng = RkEngine(dims, 0, max_tokens=max(32768, (20000 if words > 80 else 12000) * nq_cap), max_seqs=max(256, 10 * nq_cap), max_dec_len=8)
     # random weights would generate arbitrary tokens ("Unexpected output" on every compare): like the goldens
     # (tests/golden/setwise_large.json) the lm_head rows of the passage labels a prompt can hold (A .. K at num_child = 10)
     # and EOS are scaled x6, so that a generation is "<label> </s>" as with a trained checkpoint - the case the product
